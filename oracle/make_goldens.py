@@ -1,0 +1,184 @@
+"""Generate tests/golden/*.npz by running the REAL reference in the build container.
+
+TEST INFRASTRUCTURE ONLY.  Run once here (`python -m oracle.make_goldens`); the .npz files (inputs are
+regenerated from seeds, outputs are stored) are committed.  /root/reference never travels.
+
+Fixtures
+  fa_A.npz / fa_B.npz     FA-only fits ('reg' d=20 + 'mult' d=40, N=512, Kc=10, prune=1) with
+                          condition_a_VAE/favae.py (variant A) and domain_adaptation/favae.py (variant B).
+  fa_A_prune.npz          variant A with Kc=30 on rank-3 data, 40 iterations: pruning removes factors.
+  vae_step.npz            three optimiser steps of celeba_deepvanilla_vae.ImgVAE (z=20, batch 16) with an FA
+                          prior: losses, mu/std, gradient and parameter checksums.
+  vae_epoch.npz           ImgVAE.trainloop (N=24 => batches 16+8... uses batch 64 => one batch of 24) for
+                          3 epochs + update_x + reconstruction: epoch metrics, X moments, checksums.
+  favae_A.npz             full variant-A fit, one image view (z=8) + one 'mult' view, N=32, Kc=4, 2 iterations
+                          (50 + 5 epochs as the reference schedules them).
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle import ref_harness as rh  # noqa: E402
+
+
+def fa_inputs(n=512, rank=5, seed=1):
+    rs = np.random.RandomState(seed)
+    Zt = rs.randn(n, rank)
+    X0 = Zt @ rs.randn(rank, 20) + 0.1 * rs.randn(n, 20)
+    lab = (Zt @ rs.randn(rank, 40) > 0).astype(int)
+    return X0, lab
+
+
+def img_inputs(n, seed=1, zt=None):
+    rs = np.random.RandomState(seed)
+    Zt = rs.randn(n, 5) if zt is None else zt
+    Pm = rs.randn(5, 3 * 64 * 64) * 0.7
+    img = (1 / (1 + np.exp(-(Zt @ Pm)))).reshape(n, 3, 64, 64).astype(np.float32)
+    lab = (Zt @ rs.randn(5, 40) > 0).astype(int)
+    return img, lab
+
+
+def checksum(t):
+    a = np.asarray(t, dtype=np.float64).ravel()
+    idx = np.linspace(0, a.size - 1, 64).astype(np.int64)
+    return np.concatenate(([a.sum(), np.sqrt((a * a).sum())], a[idx]))
+
+
+def dump_q(model, out, tag=""):
+    q = model.q_dist
+    out[tag + "L"] = np.array(model.L, dtype=np.float64)
+    out[tag + "Kc"] = np.array(q.Kc)
+    out[tag + "Z_mean"] = q.Z["mean"]
+    out[tag + "Z_cov"] = q.Z["cov"]
+    out[tag + "Z_prodT"] = q.Z["prodT"]
+    for m in range(model.m):
+        out[tag + "W%d_mean" % m] = q.W[m]["mean"]
+        out[tag + "W%d_cov" % m] = q.W[m]["cov"]
+        out[tag + "b%d_mean" % m] = q.b[m]["mean"]
+        out[tag + "tau%d" % m] = np.array([q.tau[m]["a"], np.ravel(q.tau[m]["b"])[0]])
+        out[tag + "alpha%d_b" % m] = q.alpha[m]["b"]
+        out[tag + "X%d_mean" % m] = model.X[m]["mean"]
+        out[tag + "X%d_cov" % m] = model.X[m]["cov"]
+        out[tag + "xi%d" % m] = q.xi[m]
+
+
+def run_quiet(fn):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        return fn()
+
+
+def gen_fa(folder, name, Kc=10, iters=4, rank=5, pretrained_kw=True):
+    fav = rh.import_reference(folder)
+    X0, lab = fa_inputs(rank=rank)
+    model = fav.SSHIBA(Kc, 1)
+    v0, v1 = model.struct_data(X0, "reg"), model.struct_data(lab, "mult")
+    kw = dict(max_iter=iters, pruning_crit=1e-3, verbose=1, store=False)
+    if pretrained_kw:
+        kw["pretrained"] = 0
+    run_quiet(lambda: model.fit(v0, v1, **kw))
+    out = {}
+    dump_q(model, out)
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, "L =", model.L[-3:], "Kc =", model.q_dist.Kc)
+
+
+def gen_vae_step():
+    import torch
+    vm = rh.import_vae_module("condition_a_VAE", "celeba_deepvanilla_vae")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    vae = run_quiet(lambda: vm.ImgVAE(dimx=20, channels=3, lr=1e-3, h=64, w=64, dataset="g"))
+    B = 16
+    img, _ = img_inputs(B)
+    rs = np.random.RandomState(7)
+    prior = torch.from_numpy(rs.randn(B, 20) * 0.5)           # float64, as Z@W^T+b arrives (:209)
+    tau = torch.Tensor(np.asarray(np.array([1.7])))           # (:210)
+    images = torch.tensor(img)
+    out = {}
+    vae.train()
+    for step in range(3):
+        std_P = torch.sqrt(torch.ones_like(prior) * (1 / tau))
+        vae.optim.zero_grad()
+        torch.manual_seed(100 + step)
+        rec, mu_Q, std_Q, z = vae.forward(images)
+        rec_err = -vae.gaussian_LL(images, rec)
+        kl = vae.kl_div(mu_Q, std_Q, prior, std_P)
+        loss = rec_err + 1 * kl
+        loss.backward()
+        out["s%d_loss" % step] = np.array([loss.item(), rec_err.item(), kl.item()])
+        out["s%d_mu" % step] = mu_Q.detach().numpy()
+        out["s%d_std" % step] = std_Q.detach().numpy()
+        out["s%d_rec" % step] = checksum(rec.detach().numpy())
+        for k, p in vae.named_parameters():
+            out["s%d_g_%s" % (step, k)] = checksum(p.grad.numpy())
+        vae.optim.step()
+        for k, p in vae.state_dict().items():
+            out["s%d_p_%s" % (step, k)] = checksum(p.numpy())
+    np.savez_compressed(os.path.join(OUT, "vae_step.npz"), **out)
+    print("vae_step losses", [out["s%d_loss" % s] for s in range(3)])
+
+
+def gen_vae_epoch():
+    import torch
+    vm = rh.import_vae_module("condition_a_VAE", "celeba_deepvanilla_vae")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    vae = run_quiet(lambda: vm.ImgVAE(dimx=8, channels=3, lr=1e-3, h=64, w=64, dataset="g"))
+    N = 24
+    img, _ = img_inputs(N)
+    rs = np.random.RandomState(3)
+    Z = dict(mean=rs.randn(N, 4), cov=np.eye(4))
+    W = dict(mean=rs.randn(8, 4) * 0.3, cov=np.eye(4))
+    b = dict(mean=rs.randn(1, 8) * 0.1, cov=np.eye(8))
+    tau = np.array([2.5])
+    keep = run_quiet(lambda: vae.trainloop(img=img, Z=Z, W=W, b=b, tau=tau, epochs=3, favae=True, beta=1))
+    mu, var = run_quiet(lambda: vae.update_x(img=img))
+    rec = run_quiet(lambda: vae.reconstruction(mu, var))
+    out = dict(keep=np.array(keep), elbo=np.array(vae.elbo_training, dtype=np.float64),
+               rec_loss=np.array(vae.reconstruc_during_training, dtype=np.float64),
+               kl=np.array(vae.KL_QandP, dtype=np.float64), mu=mu, var=var, rec=checksum(rec))
+    for k, p in vae.state_dict().items():
+        out["p_" + k] = checksum(p.numpy())
+    np.savez_compressed(os.path.join(OUT, "vae_epoch.npz"), **out)
+    print("vae_epoch elbo", out["elbo"])
+
+
+def gen_favae_A():
+    fav = rh.import_reference("condition_a_VAE")
+    N = 32
+    img, lab = img_inputs(N)
+    model = fav.SSHIBA(4, 1)
+    v0 = model.struct_data(img, "img", latent_dim=8, lr=1e-3, dataset="g")
+    v1 = model.struct_data(lab, "mult")
+    run_quiet(lambda: model.fit(v0, v1, max_iter=2, pruning_crit=1e-3, verbose=1, pretrained=0, store=False))
+    out = {}
+    dump_q(model, out)
+    out["elbo_last"] = np.array(model.img_vae[0].elbo_training, dtype=np.float64)
+    out["total_elbo0"] = np.array(model.total_elbo[0], dtype=np.float64)
+    for k, p in model.img_vae[0].state_dict().items():
+        out["p_" + k] = checksum(p.numpy())
+    np.savez_compressed(os.path.join(OUT, "favae_A.npz"), **out)
+    print("favae_A L =", model.L)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["fa", "vae_step", "vae_epoch", "favae_A"]
+    if "fa" in which:
+        gen_fa("condition_a_VAE", "fa_A.npz")
+        gen_fa("domain_adaptation", "fa_B.npz", pretrained_kw=False)
+        gen_fa("condition_a_VAE", "fa_A_prune.npz", Kc=30, iters=40, rank=3)
+    if "vae_step" in which:
+        gen_vae_step()
+    if "vae_epoch" in which:
+        gen_vae_epoch()
+    if "favae_A" in which:
+        gen_favae_A()

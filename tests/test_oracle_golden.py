@@ -1,0 +1,126 @@
+"""Pin the CPU oracle (oracle/) against vectors produced by the real reference (oracle/make_goldens.py).
+
+The reference ships no tests or fixtures; these goldens are outputs of the reference
+itself, run in the build container with the shims of SURVEY.md section 8(c).  CPU only.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import fa_inputs, img_inputs, checksum
+from oracle import fa_numpy as fa
+from oracle import vae_torch as vt
+
+
+def _close(a, b, rtol=1e-9, atol=1e-10):
+    np.testing.assert_allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=rtol, atol=atol)
+
+
+def _check_q(model, g, rtol=1e-8):
+    q = model.q_dist
+    _close(model.L, g["L"], rtol=rtol)
+    assert q.Kc == int(g["Kc"])
+    _close(q.Z["mean"], g["Z_mean"], rtol=rtol, atol=1e-9)
+    _close(q.Z["cov"], g["Z_cov"], rtol=rtol, atol=1e-12)
+    for m in range(model.m):
+        _close(q.W[m]["mean"], g["W%d_mean" % m], rtol=rtol, atol=1e-9)
+        _close(q.b[m]["mean"], g["b%d_mean" % m], rtol=rtol, atol=1e-9)
+        _close([q.tau[m]["a"], np.ravel(q.tau[m]["b"])[0]], g["tau%d" % m], rtol=rtol)
+        _close(q.alpha[m]["b"], g["alpha%d_b" % m], rtol=rtol)
+        _close(model.X[m]["mean"], g["X%d_mean" % m], rtol=rtol, atol=1e-9)
+        _close(q.xi[m], g["xi%d" % m], rtol=rtol, atol=1e-9)
+
+
+@pytest.mark.parametrize("variant,name", [("A", "fa_A.npz"), ("B", "fa_B.npz")])
+def test_fa_only_matches_reference(golden, variant, name):
+    g = golden(name)
+    X0, lab = fa_inputs()
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = fa.SSHIBAOracle(10, 1, variant=variant)
+    model.fit(fa.struct_data(X0, "reg"), fa.struct_data(lab, "mult"), max_iter=4, pruning_crit=1e-3)
+    _check_q(model, g)
+
+
+def test_fa_pruning_matches_reference(golden):
+    g = golden("fa_A_prune.npz")
+    X0, lab = fa_inputs(rank=3)
+    np.random.seed(0)
+    model = fa.SSHIBAOracle(30, 1, variant="A")
+    model.fit(fa.struct_data(X0, "reg"), fa.struct_data(lab, "mult"), max_iter=40, pruning_crit=1e-3)
+    assert model.q_dist.Kc < 30
+    _check_q(model, g, rtol=1e-6)
+
+
+def test_vae_three_steps_match_reference(golden):
+    g = golden("vae_step.npz")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    P, B = vt.init_state(20, 3)
+    names = list(P.keys())
+    opt = torch.optim.Adam([P[k] for k in names], 1e-3)
+    Bn = 16
+    img, _ = img_inputs(Bn)
+    prior = torch.from_numpy(np.random.RandomState(7).randn(Bn, 20) * 0.5)
+    tau = torch.Tensor(np.asarray(np.array([1.7])))
+    images = torch.tensor(img)
+    for step in range(3):
+        opt.zero_grad()
+        torch.manual_seed(100 + step)
+        loss, rec_err, kl, mu, std, z, rec = vt.loss_terms(P, B, images, prior, tau, 0.01, 1)
+        loss.backward()
+        _close([loss.item(), rec_err.item(), kl.item()], g["s%d_loss" % step], rtol=1e-6)
+        _close(mu.detach().numpy(), g["s%d_mu" % step], rtol=1e-5, atol=1e-6)
+        _close(std.detach().numpy(), g["s%d_std" % step], rtol=1e-5, atol=1e-6)
+        _close(checksum(rec.detach().numpy()), g["s%d_rec" % step], rtol=1e-5, atol=1e-6)
+        for k in names:
+            _close(checksum(P[k].grad.numpy()), g["s%d_g_%s" % (step, k)], rtol=1e-4, atol=1e-5)
+        opt.step()
+        for k in names:
+            _close(checksum(P[k].detach().numpy()), g["s%d_p_%s" % (step, k)], rtol=1e-5, atol=1e-6)
+        for k in B:
+            _close(checksum(B[k].numpy()), g["s%d_p_%s" % (step, k)], rtol=1e-5, atol=1e-6)
+
+
+def test_vae_trainloop_update_x_reconstruction_match_reference(golden):
+    g = golden("vae_epoch.npz")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    vae = vt.OracleImgVAE(dimx=8, channels=3, lr=1e-3, dataset="g")
+    N = 24
+    img, _ = img_inputs(N)
+    rs = np.random.RandomState(3)
+    Z = dict(mean=rs.randn(N, 4), cov=np.eye(4))
+    W = dict(mean=rs.randn(8, 4) * 0.3, cov=np.eye(4))
+    b = dict(mean=rs.randn(1, 8) * 0.1, cov=np.eye(8))
+    keep = vae.trainloop(img=img, Z=Z, W=W, b=b, tau=np.array([2.5]), epochs=3, favae=True, beta=1)
+    mu, var = vae.update_x(img=img)
+    rec = vae.reconstruction(mu, var)
+    assert bool(keep) == bool(g["keep"])
+    _close(vae.elbo_training, g["elbo"], rtol=1e-6)
+    _close(vae.reconstruc_during_training, g["rec_loss"], rtol=1e-6)
+    _close(vae.KL_QandP, g["kl"], rtol=1e-6)
+    _close(mu, g["mu"], rtol=1e-4, atol=1e-5)
+    _close(var, g["var"], rtol=1e-4, atol=1e-7)
+    _close(checksum(rec), g["rec"], rtol=1e-4, atol=1e-5)
+    for k, p in vae.state_dict().items():
+        _close(checksum(p.numpy()), g["p_" + k], rtol=1e-4, atol=1e-6)
+
+
+def test_full_variant_A_fit_matches_reference(golden):
+    """One image view (z=8) + one multilabel view, N=32, Kc=4, two SSHIBA iterations (50 + 5 epochs)."""
+    g = golden("favae_A.npz")
+    N = 32
+    img, lab = img_inputs(N)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = fa.SSHIBAOracle(4, 1, variant="A", vae_factory=lambda **kw: vt.OracleImgVAE(**kw))
+    v0 = fa.struct_data(img, "img", latent_dim=8, lr=1e-3, dataset="g")
+    v1 = fa.struct_data(lab, "mult")
+    model.fit(v0, v1, max_iter=2, pruning_crit=1e-3)
+    _close(model.L, g["L"], rtol=1e-5)
+    _close(model.img_vae[0].elbo_training, g["elbo_last"], rtol=1e-5)
+    _close(model.total_elbo[0], g["total_elbo0"], rtol=1e-5)
+    _close(model.q_dist.Z["mean"], g["Z_mean"], rtol=1e-3, atol=1e-5)
+    _close(model.X[0]["mean"], g["X0_mean"], rtol=1e-3, atol=1e-5)
+    _close(model.q_dist.W[0]["mean"], g["W0_mean"], rtol=1e-3, atol=1e-6)
