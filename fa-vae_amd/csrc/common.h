@@ -1,0 +1,68 @@
+// Shared device/host helpers for libfavae_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define FAVAE_OK 0
+#define FAVAE_NOT_SPD 1          // numerical flag: the matrix handed to the Cholesky inverse is not SPD
+#define FAVAE_ERR_ARG (-1)
+#define FAVAE_ERR_HIP (-2)
+
+extern "C" void favae_set_error(const char* fmt, ...);
+
+#define FAVAE_CHECK_ARG(cond, ...)                 \
+    do {                                           \
+        if (!(cond)) {                             \
+            favae_set_error(__VA_ARGS__);          \
+            return FAVAE_ERR_ARG;                  \
+        }                                          \
+    } while (0)
+
+#define FAVAE_HIP(call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            favae_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return FAVAE_ERR_HIP;                                                               \
+        }                                                                                       \
+    } while (0)
+
+#define FAVAE_LAUNCH_CHECK() FAVAE_HIP(hipGetLastError())
+
+typedef unsigned short bf16_t;  // storage type of a bfloat16 element
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) double f64x4;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+
+// round-to-nearest-even; NaN stays NaN (quiet)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <class T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+template <class T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }

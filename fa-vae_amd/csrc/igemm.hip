@@ -1,0 +1,494 @@
+// Implicit-GEMM convolution kernels for the FA-VAE conv VAE on gfx950 (MI355X).
+//
+// Replaces the ATen/cuDNN calls behind reference condition_a_VAE/celeba_deepvanilla_vae.py:25-99
+// (nn.Conv2d k3 s2 p1, nn.ConvTranspose2d k3 s2 p1 op1, nn.Conv2d k3 s1 p1, nn.Linear) and their autograd
+// backward (loss.backward(), :249).  Activations are NHWC, weights are [Cout][tap][Cin] ("OHWI"), so both
+// GEMM operands are contiguous along the reduction index and one 32x32 MFMA tile loop serves all layers:
+//
+//   igemm_kc  gather  form : out[n,oy,ox,co] = sum_{tap,ci} in[n, oy*s-p+kh, ox*s-p+kw, ci] * w[co][tap][ci]
+//                            (Conv2d forward, ConvTranspose2d input gradient, Linear forward / input gradient)
+//             scatter form : out[n,y,x,co]   = sum_{tap,ci : (y+p-kh)%s==0} in[n,(y+p-kh)/s,(x+p-kw)/s,ci] * w[co][tap][ci]
+//                            (ConvTranspose2d forward, Conv2d input gradient), one launch z-slice per output
+//                            parity class so that no MFMA is spent on structurally-zero taps
+//   igemm_pm               : dw[r][tap][c] += sum_{pixels} R[pix][r] * C[pix'][c]   (all weight gradients)
+//
+// T = float  -> v_mfma_f32_32x32x2_f32 (exact fp32, parity path);  T = bf16 -> v_mfma_f32_32x32x16_bf16.
+// Accumulation is always fp32; outputs are fp32.
+#include <algorithm>
+#include "common.h"
+#include "favae_hip.h"
+
+namespace {
+
+constexpr int BK = 32;  // reduction elements per LDS stage
+
+template <class T> struct Frag;
+template <> struct Frag<float> { float v[8]; };
+template <> struct Frag<bf16_t> { bf16x8 v; };
+
+__device__ __forceinline__ void mma32(f32x16& acc, const Frag<float>& a, const Frag<float>& b) {
+    // lane (r, h) holds k = 8h..8h+7 of its row/column; the k order inside the 16-deep step is a
+    // permutation applied to both operands, so 8 x (32x32x2) sums exactly the 16 products.
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(f32x16& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+
+// fragment of 8 consecutive reduction elements from a [row][k] LDS image
+__device__ __forceinline__ void frag_kc(Frag<float>& f, const char* p) {
+    const float4 lo = *(const float4*)p, hi = *(const float4*)(p + 16);
+    f.v[0] = lo.x; f.v[1] = lo.y; f.v[2] = lo.z; f.v[3] = lo.w;
+    f.v[4] = hi.x; f.v[5] = hi.y; f.v[6] = hi.z; f.v[7] = hi.w;
+}
+__device__ __forceinline__ void frag_kc(Frag<bf16_t>& f, const char* p) {
+    union { uint4 u; bf16x8 b; } c;
+    c.u = *(const uint4*)p;
+    f.v = c.b;
+}
+
+// fragment from a [k][channel] LDS image (reduction index strided): lane (r, h) needs k = k0+8h+j, channel cb+r
+__device__ __forceinline__ void frag_pm(Frag<float>& f, const char* lds, int RS, int k0, int cb, int lane) {
+    const char* p = lds + (k0 + 8 * (lane >> 5)) * RS + (cb + (lane & 31)) * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = *(const float*)(p + j * RS);
+}
+__device__ __forceinline__ void frag_pm(Frag<bf16_t>& f, const char* lds, int RS, int k0, int cb, int lane) {
+    // ds_read_b64_tr_b16: each 16-lane group reads a 4(k) x 16(channel) block and receives it column-major
+    const int i = lane & 15;
+    const char* p = lds + (k0 + 8 * (lane >> 5) + (i >> 2)) * RS + (cb + 16 * ((lane >> 4) & 1) + 4 * (i & 3)) * 2;
+    union { s16x4 s[2]; bf16x8 b; } c;
+    c.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    c.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * RS));
+    f.v = c.b;
+}
+
+template <class T> __device__ __forceinline__ void put_elem(uint4& v, int e, T x);
+template <> __device__ __forceinline__ void put_elem<float>(uint4& v, int e, float x) {
+    unsigned u = __float_as_uint(x);
+    if (e == 0) v.x = u; else if (e == 1) v.y = u; else if (e == 2) v.z = u; else v.w = u;
+}
+template <> __device__ __forceinline__ void put_elem<bf16_t>(uint4& v, int e, bf16_t x) {
+    unsigned u = ((unsigned)x) << (16 * (e & 1));
+    const int w = e >> 1;
+    if (w == 0) v.x |= u; else if (w == 1) v.y |= u; else if (w == 2) v.z |= u; else v.w |= u;
+}
+
+struct KcParams {
+    const void* in;
+    const void* w;
+    const float* bias;
+    float* out;
+    int Nb, Hi, Wi, Cin, Ho, Wo, Cout;
+    int ks, stride, pad, ldw, splitk, M, ntn, HoC, WoC;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// K-contiguous implicit GEMM (gather / scatter forms)
+// ---------------------------------------------------------------------------------------------------------
+template <class T, int BM, int BN, int WM, int WN, bool TR, bool SLOW>
+__global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
+    constexpr int VE = 16 / sizeof(T);
+    constexpr int VPR = BK / VE;
+    constexpr int RS = BK * sizeof(T) + 16;
+    constexpr int NVA = BM * VPR, NVB = BN * VPR;             // 16-byte vectors per stage
+    constexpr int VA = (NVA + 255) / 256, VB = (NVB + 255) / 256;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "wave layout");
+    __shared__ __attribute__((aligned(16))) char lds[(BM + BN) * RS];
+    char* ldsA = lds;
+    char* ldsB = lds + BM * RS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = (blockIdx.x / p.ntn) * BM, n0 = (blockIdx.x % p.ntn) * BN;
+    const int py = TR ? (int)(blockIdx.z >> 1) : 0, px = TR ? (int)(blockIdx.z & 1) : 0;
+    // valid taps of this launch slice
+    int nkh, nkw;
+    if (TR && p.stride == 2) { nkh = 1 + py; nkw = 1 + px; } else { nkh = p.ks; nkw = p.ks; }
+    const int ntap = nkh * nkw;
+    auto tap_kh = [&](int i) { return (TR && p.stride == 2) ? (py ? 2 * i : 1) : i; };
+    auto tap_kw = [&](int i) { return (TR && p.stride == 2) ? (px ? 2 * i : 1) : i; };
+
+    const int cpt = SLOW ? 1 : p.Cin / BK;
+    const int nchunk = SLOW ? (ntap * p.Cin + BK - 1) / BK : ntap * cpt;
+    const int per = (nchunk + p.splitk - 1) / p.splitk;
+    const int c_begin = blockIdx.y * per, c_end = min(nchunk, c_begin + per);
+
+    // the rows this thread stages
+    int a_n[VA], a_y[VA], a_x[VA];
+    bool a_ok[VA];
+#pragma unroll
+    for (int i = 0; i < VA; ++i) {
+        const int r = (tid + i * 256) / VPR, m = m0 + r;
+        a_ok[i] = m < p.M && (tid + i * 256) < NVA;
+        const int mm = a_ok[i] ? m : 0;
+        const int hw = p.HoC * p.WoC;
+        a_n[i] = mm / hw;
+        const int rem = mm - a_n[i] * hw;
+        a_y[i] = rem / p.WoC;
+        a_x[i] = rem - a_y[i] * p.WoC;
+    }
+    const int vecA = tid % VPR;  // same for every i because 256 % VPR == 0
+
+    auto in_coord = [&](int yy, int xx, int kh, int kw, int& iy, int& ix) -> bool {
+        if (TR) {
+            iy = (yy * p.stride + py + p.pad - kh) / p.stride;   // exact for the valid taps of this slice
+            ix = (xx * p.stride + px + p.pad - kw) / p.stride;
+        } else {
+            iy = yy * p.stride - p.pad + kh;
+            ix = xx * p.stride - p.pad + kw;
+        }
+        return iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+    };
+
+    uint4 va[VA], vb[VB];
+    auto load_chunk = [&](int c) {
+        if (!SLOW) {
+            const int t = c / cpt, ci0 = (c - t * cpt) * BK;
+            const int kh = tap_kh(t / nkw), kw = tap_kw(t % nkw);
+            const int kg = (kh * p.ks + kw) * p.Cin + ci0 + vecA * VE;
+#pragma unroll
+            for (int i = 0; i < VA; ++i) {
+                int iy, ix;
+                const bool ok = in_coord(a_y[i], a_x[i], kh, kw, iy, ix) && a_ok[i];
+                va[i] = make_uint4(0, 0, 0, 0);
+                if (ok) {
+                    const size_t off = ((size_t)(a_n[i] * p.Hi + iy) * p.Wi + ix) * p.Cin + ci0 + vecA * VE;
+                    va[i] = *(const uint4*)((const T*)p.in + off);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < VB; ++j) {
+                const int r = (tid + j * 256) / VPR, n = n0 + r;
+                vb[j] = make_uint4(0, 0, 0, 0);
+                if (n < p.Cout && (tid + j * 256) < NVB) vb[j] = *(const uint4*)((const T*)p.w + (size_t)n * p.ldw + kg);
+            }
+        } else {
+            const int ktot = ntap * p.Cin;
+#pragma unroll
+            for (int i = 0; i < VA; ++i) {
+                va[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const int k = c * BK + vecA * VE + e;
+                    T x = (T)0;
+                    if (k < ktot && a_ok[i]) {
+                        const int t = k / p.Cin, ci = k - t * p.Cin;
+                        const int kh = tap_kh(t / nkw), kw = tap_kw(t % nkw);
+                        int iy, ix;
+                        if (in_coord(a_y[i], a_x[i], kh, kw, iy, ix))
+                            x = ((const T*)p.in)[((size_t)(a_n[i] * p.Hi + iy) * p.Wi + ix) * p.Cin + ci];
+                    }
+                    put_elem<T>(va[i], e, x);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < VB; ++j) {
+                const int r = (tid + j * 256) / VPR, n = n0 + r;
+                vb[j] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const int k = c * BK + vecA * VE + e;
+                    T x = (T)0;
+                    if (k < ktot && n < p.Cout && (tid + j * 256) < NVB) {
+                        const int t = k / p.Cin, ci = k - t * p.Cin;
+                        const int kh = tap_kh(t / nkw), kw = tap_kw(t % nkw);
+                        x = ((const T*)p.w)[(size_t)n * p.ldw + (kh * p.ks + kw) * p.Cin + ci];
+                    }
+                    put_elem<T>(vb[j], e, x);
+                }
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if (c_begin < c_end) load_chunk(c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
+#pragma unroll
+        for (int i = 0; i < VA; ++i)
+            if ((tid + i * 256) < NVA) *(uint4*)(ldsA + ((tid + i * 256) / VPR) * RS + vecA * 16) = va[i];
+#pragma unroll
+        for (int j = 0; j < VB; ++j)
+            if ((tid + j * 256) < NVB) *(uint4*)(ldsB + ((tid + j * 256) / VPR) * RS + vecA * 16) = vb[j];
+        __syncthreads();
+        if (c + 1 < c_end) load_chunk(c + 1);  // in flight while the MFMAs below run
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            Frag<T> fa[TM], fb[TN];
+            const int koff = (kk * 16 + 8 * (lane >> 5)) * (int)sizeof(T);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) frag_kc(fa[a], ldsA + (wm * WTM + a * 32 + (lane & 31)) * RS + koff);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) frag_kc(fb[b], ldsB + (wn * WTN + b * 32 + (lane & 31)) * RS + koff);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) mma32(acc[a][b], fa[a], fb[b]);
+        }
+        __syncthreads();
+    }
+    if (c_begin >= c_end && !(blockIdx.y == 0)) return;
+
+    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m >= p.M) continue;
+            size_t opix = (size_t)m;
+            if (TR) {
+                const int hw = p.HoC * p.WoC;
+                const int nb = m / hw, rem = m - nb * hw, yy = rem / p.WoC, xx = rem - yy * p.WoC;
+                opix = ((size_t)nb * p.Ho + (yy * p.stride + py)) * p.Wo + (xx * p.stride + px);
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int n = n0 + wn * WTN + b * 32 + (lane & 31);
+                if (n >= p.Cout) continue;
+                float v = acc[a][b][r];
+                if (add_bias) v += p.bias[n];
+                float* dst = p.out + opix * p.Cout + n;
+                if (p.splitk > 1) atomicAdd(dst, v); else *dst = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// pixel-major implicit GEMM (weight gradients)
+// ---------------------------------------------------------------------------------------------------------
+struct PmParams {
+    const void* rp;
+    const void* cp;
+    float* dw;
+    int Rc, Cc, r_large, c_large;
+    int Nb, Hs, Ws, Hl, Wl, ks, stride, pad, splitk, ntn, K;
+};
+
+template <class T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
+    constexpr int VE = 16 / sizeof(T);
+    constexpr int RSR = BM * sizeof(T) + 16, RSC = BN * sizeof(T) + 16;
+    constexpr int VPR_R = BM / VE, VPR_C = BN / VE;
+    constexpr int NVR = BK * VPR_R, NVC = BK * VPR_C;
+    constexpr int VR = (NVR + 255) / 256, VC = (NVC + 255) / 256;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "wave layout");
+    __shared__ __attribute__((aligned(16))) char lds[BK * (RSR + RSC)];
+    char* ldsR = lds;
+    char* ldsC = lds + BK * RSR;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r0 = (blockIdx.x / p.ntn) * BM, c0 = (blockIdx.x % p.ntn) * BN;
+    const int tap = blockIdx.z, kh = tap / p.ks, kw = tap % p.ks;
+    const int nchunk = (p.K + BK - 1) / BK;
+    const int per = (nchunk + p.splitk - 1) / p.splitk;
+    const int c_begin = blockIdx.y * per, c_end = min(nchunk, c_begin + per);
+    if (c_begin >= c_end) return;
+
+    auto load_vec = [&](const void* base, int C, bool large, int ch0, int v, int vpr, int chunk) -> uint4 {
+        const int prow = v / vpr, cv = v - prow * vpr;
+        const int pix = chunk * BK + prow;
+        uint4 out = make_uint4(0, 0, 0, 0);
+        if (pix >= p.K || prow >= BK) return out;
+        size_t spix = (size_t)pix;
+        if (large) {
+            const int hw = p.Hs * p.Ws;
+            const int n = pix / hw, rem = pix - n * hw, h = rem / p.Ws, w = rem - h * p.Ws;
+            const int y = h * p.stride - p.pad + kh, x = w * p.stride - p.pad + kw;
+            if (y < 0 || y >= p.Hl || x < 0 || x >= p.Wl) return out;
+            spix = ((size_t)n * p.Hl + y) * p.Wl + x;
+        }
+        const int ch = ch0 + cv * VE;
+        if (C % VE == 0) {
+            if (ch < C) out = *(const uint4*)((const T*)base + spix * C + ch);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VE; ++e)
+                if (ch + e < C) put_elem<T>(out, e, ((const T*)base)[spix * C + ch + e]);
+        }
+        return out;
+    };
+
+    uint4 vr[VR], vc[VC];
+    auto load_chunk = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < VR; ++i) vr[i] = load_vec(p.rp, p.Rc, p.r_large, r0, tid + i * 256, VPR_R, chunk);
+#pragma unroll
+        for (int i = 0; i < VC; ++i) vc[i] = load_vec(p.cp, p.Cc, p.c_large, c0, tid + i * 256, VPR_C, chunk);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    load_chunk(c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
+#pragma unroll
+        for (int i = 0; i < VR; ++i) {
+            const int v = tid + i * 256;
+            if (v < NVR) *(uint4*)(ldsR + (v / VPR_R) * RSR + (v % VPR_R) * 16) = vr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VC; ++i) {
+            const int v = tid + i * 256;
+            if (v < NVC) *(uint4*)(ldsC + (v / VPR_C) * RSC + (v % VPR_C) * 16) = vc[i];
+        }
+        __syncthreads();
+        if (c + 1 < c_end) load_chunk(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            Frag<T> fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) frag_pm(fa[a], ldsR, RSR, kk * 16, wm * WTM + a * 32, lane);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) frag_pm(fb[b], ldsC, RSC, kk * 16, wn * WTN + b * 32, lane);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) mma32(acc[a][b], fa[a], fb[b]);
+        }
+        __syncthreads();
+    }
+
+    const int ntaps = p.ks * p.ks;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = r0 + wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= p.Rc) continue;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int col = c0 + wn * WTN + b * 32 + (lane & 31);
+                if (col < p.Cc) atomicAdd(p.dw + ((size_t)row * ntaps + tap) * p.Cc + col, acc[a][b][r]);
+            }
+        }
+}
+
+template <class T, bool TR, bool SLOW, int BM, int BN, int WM, int WN>
+int launch_kc(const KcParams& p, int classes, hipStream_t st) {
+    dim3 grid(cdiv(p.M, BM) * p.ntn, p.splitk, classes);
+    hipLaunchKernelGGL((igemm_kc<T, BM, BN, WM, WN, TR, SLOW>), grid, dim3(256), 0, st, p);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+template <class T, bool TR>
+int dispatch_kc(KcParams p, int classes, int target_blocks, hipStream_t st) {
+    const bool slow = (p.Cin % BK) != 0;
+    int BM, BN;
+    if (slow) { BM = 64; BN = 64; }
+    else if (p.Cout <= 32 && !TR) { BM = 128; BN = 32; }
+    else if (p.Cout <= 64) { BN = 64; BM = p.M >= 4096 ? 128 : 64; }
+    else { BN = 128; BM = 128; if (p.M < 128 * 4) { BM = 64; BN = 64; } }
+    p.ntn = cdiv(p.Cout, BN);
+    // split the reduction when the tile grid alone cannot fill 256 CUs
+    const int ntap_max = p.ks * p.ks;
+    const int nchunk = slow ? cdiv(ntap_max * p.Cin, BK) : ntap_max * (p.Cin / BK);
+    const int blocks = cdiv(p.M, BM) * p.ntn * classes;
+    int sk = 1;
+    if (p.splitk > 0) sk = p.splitk;
+    else if (blocks < target_blocks) sk = std::min(std::max(1, nchunk / 4), cdiv(target_blocks, blocks));
+    p.splitk = std::max(1, std::min(sk, nchunk));
+    if (p.splitk > 1)
+        FAVAE_HIP(hipMemsetAsync(p.out, 0, (size_t)p.Nb * p.Ho * p.Wo * p.Cout * sizeof(float), st));
+    if (slow) return launch_kc<T, TR, true, 64, 64, 2, 2>(p, classes, st);
+    if (BM == 128 && BN == 32) {
+        if constexpr (!TR) return launch_kc<T, TR, false, 128, 32, 4, 1>(p, classes, st);
+    }
+    if (BM == 128 && BN == 64) return launch_kc<T, TR, false, 128, 64, 2, 2>(p, classes, st);
+    if (BM == 64 && BN == 64) return launch_kc<T, TR, false, 64, 64, 2, 2>(p, classes, st);
+    return launch_kc<T, TR, false, 128, 128, 2, 2>(p, classes, st);
+}
+
+template <class T>
+int dispatch_pm(PmParams p, hipStream_t st) {
+    int BM, BN;
+    if (p.Rc <= 32) { BM = 32; BN = 128; }
+    else if (p.Cc <= 32) { BM = 128; BN = 32; }
+    else if (p.Rc <= 64 || p.Cc <= 64) { BM = 64; BN = 64; }
+    else { BM = 128; BN = 128; }
+    p.ntn = cdiv(p.Cc, BN);
+    const int nchunk = cdiv(p.K, BK);
+    const int blocks = cdiv(p.Rc, BM) * p.ntn * p.ks * p.ks;
+    int sk = p.splitk > 0 ? p.splitk : std::min(std::max(1, nchunk / 4), cdiv(1024, blocks));
+    p.splitk = std::max(1, std::min(sk, nchunk));
+    dim3 grid(cdiv(p.Rc, BM) * p.ntn, p.splitk, p.ks * p.ks);
+    if (BM == 32) hipLaunchKernelGGL((igemm_pm<T, 32, 128, 1, 4>), grid, dim3(256), 0, st, p);
+    else if (BN == 32) hipLaunchKernelGGL((igemm_pm<T, 128, 32, 4, 1>), grid, dim3(256), 0, st, p);
+    else if (BM == 64) hipLaunchKernelGGL((igemm_pm<T, 64, 64, 2, 2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_pm<T, 128, 128, 2, 2>), grid, dim3(256), 0, st, p);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+}  // namespace
+
+extern "C" int favae_conv_igemm(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi,
+                                int Cin, int Ho, int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk,
+                                int dtype, void* stream) {
+    FAVAE_CHECK_ARG(in && w && out, "favae_conv_igemm: null pointer");
+    FAVAE_CHECK_ARG(Nb > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Ho > 0 && Wo > 0 && Cout > 0, "favae_conv_igemm: bad shape");
+    FAVAE_CHECK_ARG((ks == 1 && pad == 0) || (ks == 3 && pad == 1), "favae_conv_igemm: ks/pad must be 1/0 or 3/1");
+    FAVAE_CHECK_ARG(stride == 1 || stride == 2, "favae_conv_igemm: stride must be 1 or 2");
+    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_conv_igemm: dtype");
+    FAVAE_CHECK_ARG(!(stride == 2 && ks != 3), "favae_conv_igemm: stride 2 needs ks 3");
+    if (scatter) FAVAE_CHECK_ARG(Ho == Hi * stride && Wo == Wi * stride, "favae_conv_igemm: scatter form needs Ho = s*Hi");
+    else FAVAE_CHECK_ARG(Ho == (Hi + 2 * pad - ks) / stride + 1 && Wo == (Wi + 2 * pad - ks) / stride + 1,
+                         "favae_conv_igemm: gather form output size mismatch");
+    FAVAE_CHECK_ARG((size_t)Nb * Ho * Wo < (1u << 31) && (size_t)Nb * Hi * Wi < (1u << 31), "favae_conv_igemm: too many pixels");
+    const int esz = dtype == FAVAE_F32 ? 4 : 2;
+    if (Cin % BK == 0) FAVAE_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)w % 16) == 0, "favae_conv_igemm: 16-byte alignment");
+    (void)esz;
+    KcParams p;
+    p.in = in; p.w = w; p.bias = bias; p.out = out;
+    p.Nb = Nb; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
+    p.ks = ks; p.stride = stride; p.pad = pad; p.ldw = ks * ks * Cin; p.splitk = splitk;
+    int classes = 1;
+    if (scatter && stride == 2) { classes = 4; p.HoC = Ho / 2; p.WoC = Wo / 2; }
+    else { p.HoC = Ho; p.WoC = Wo; }
+    p.M = Nb * p.HoC * p.WoC;
+    p.ntn = 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int target = 512;
+    if (dtype == FAVAE_F32) return scatter ? dispatch_kc<float, true>(p, classes, target, st) : dispatch_kc<float, false>(p, classes, target, st);
+    return scatter ? dispatch_kc<bf16_t, true>(p, classes, target, st) : dispatch_kc<bf16_t, false>(p, classes, target, st);
+}
+
+extern "C" int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const void* cols, int Cc, int cols_large,
+                                float* dw, int Nb, int Hs, int Ws, int Hl, int Wl, int ks, int stride, int pad,
+                                int splitk, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(rows && cols && dw, "favae_conv_wgrad: null pointer");
+    FAVAE_CHECK_ARG(Nb > 0 && Hs > 0 && Ws > 0 && Rc > 0 && Cc > 0, "favae_conv_wgrad: bad shape");
+    FAVAE_CHECK_ARG((ks == 1 && pad == 0) || (ks == 3 && pad == 1), "favae_conv_wgrad: ks/pad must be 1/0 or 3/1");
+    FAVAE_CHECK_ARG(stride == 1 || stride == 2, "favae_conv_wgrad: stride");
+    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_conv_wgrad: dtype");
+    FAVAE_CHECK_ARG(!(rows_large && cols_large), "favae_conv_wgrad: at most one gathered operand");
+    FAVAE_CHECK_ARG(Hs == (Hl + 2 * pad - ks) / stride + 1 && Ws == (Wl + 2 * pad - ks) / stride + 1,
+                    "favae_conv_wgrad: small/large size mismatch");
+    FAVAE_CHECK_ARG((size_t)Nb * Hl * Wl < (1u << 31), "favae_conv_wgrad: too many pixels");
+    FAVAE_CHECK_ARG(((uintptr_t)rows % 16) == 0 && ((uintptr_t)cols % 16) == 0, "favae_conv_wgrad: 16-byte alignment");
+    PmParams p;
+    p.rp = rows; p.cp = cols; p.dw = dw; p.Rc = Rc; p.Cc = Cc; p.r_large = rows_large; p.c_large = cols_large;
+    p.Nb = Nb; p.Hs = Hs; p.Ws = Ws; p.Hl = Hl; p.Wl = Wl; p.ks = ks; p.stride = stride; p.pad = pad;
+    p.splitk = splitk; p.ntn = 1; p.K = Nb * Hs * Ws;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == FAVAE_F32 ? dispatch_pm<float>(p, st) : dispatch_pm<bf16_t>(p, st);
+}

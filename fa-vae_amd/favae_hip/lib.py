@@ -1,0 +1,85 @@
+"""ctypes binding of libfavae_hip.so (the C ABI declared in include/favae_hip.h).
+
+PyTorch-ROCm tensors are used only as device buffers: every wrapper forwards `tensor.data_ptr()` and the
+current HIP stream.  There is no CPU fallback: if the library is missing the import fails loudly.
+"""
+import ctypes
+import os
+
+import torch
+
+F32, BF16 = 0, 1
+NOT_SPD = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libfavae_hip.so")
+
+
+class FavaeHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise FavaeHipError(
+            "libfavae_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C fa-vae_amd/csrc`; there is no CPU fallback." % _LIB_PATH)
+    return ctypes.CDLL(_LIB_PATH)
+
+
+_lib = _load()
+_lib.favae_last_error.restype = ctypes.c_char_p
+_lib.favae_version.restype = ctypes.c_int
+
+
+def raw():
+    return _lib
+
+
+def last_error():
+    return _lib.favae_last_error().decode()
+
+
+def check(rc, allow_flags=False):
+    if rc < 0 or (rc > 0 and not allow_flags):
+        raise FavaeHipError("libfavae_hip rc=%d: %s" % (rc, last_error()))
+    return rc
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return ctypes.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def dtype_code(t):
+    return F32 if t.dtype == torch.float32 else BF16
+
+
+_i = ctypes.c_int
+
+
+def conv_igemm(x, w, bias, out, ks, stride, pad, scatter, splitk=0):
+    """x [Nb,Hi,Wi,Cin] (f32|bf16), w [Cout, ks*ks, Cin] same dtype, bias [Cout] f32|None, out [Nb,Ho,Wo,Cout] f32."""
+    Nb, Hi, Wi, Cin = x.shape
+    _, Ho, Wo, Cout = out.shape
+    assert w.dtype == x.dtype and out.dtype == torch.float32 and w.shape[0] >= Cout
+    check(_lib.favae_conv_igemm(ptr(x), ptr(w), ptr(bias), ptr(out), _i(Nb), _i(Hi), _i(Wi), _i(Cin), _i(Ho), _i(Wo),
+                                _i(Cout), _i(ks), _i(stride), _i(pad), _i(scatter), _i(splitk), _i(dtype_code(x)),
+                                stream_ptr()))
+    return out
+
+
+def conv_wgrad(rows, rows_large, cols, cols_large, dw, Nb, Hs, Ws, Hl, Wl, ks, stride, pad, splitk=0):
+    """dw [Rc, ks*ks, Cc] f32 += sum_pix rows[pix, r] * cols[pix', c]."""
+    Rc, Cc = rows.shape[-1], cols.shape[-1]
+    assert rows.dtype == cols.dtype and dw.dtype == torch.float32
+    check(_lib.favae_conv_wgrad(ptr(rows), _i(Rc), _i(rows_large), ptr(cols), _i(Cc), _i(cols_large), ptr(dw), _i(Nb),
+                                _i(Hs), _i(Ws), _i(Hl), _i(Wl), _i(ks), _i(stride), _i(pad), _i(splitk),
+                                _i(dtype_code(rows)), stream_ptr()))
+    return dw

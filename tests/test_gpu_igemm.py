@@ -1,0 +1,188 @@
+"""GPU parity of the implicit-GEMM conv kernels (C ABI: favae_conv_igemm / favae_conv_wgrad) against torch-CPU
+fp32 references of the same op (the ops the reference calls: nn.Conv2d / nn.ConvTranspose2d / nn.Linear and
+their autograd gradients, condition_a_VAE/celeba_deepvanilla_vae.py:25-99,249).
+
+Tolerances: fp32 path rel 1e-5 of the output scale (exact-fp32 MFMA, only the summation order differs);
+bf16 path compares against the same op evaluated on bf16-rounded operands, rel 1e-4 (fp32 accumulation)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from favae_hip import lib
+    return lib
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def q(x, dt):
+    return x.to(dt).to(torch.float32)
+
+
+def assert_close(got, ref, tol):
+    got, ref = got.double(), ref.double()
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, "max err %.3e vs scale %.3e (tol %.1e)" % (err, scale, tol)
+
+
+DT = [(torch.float32, 1e-5), (torch.bfloat16, 1e-4)]
+
+
+@pytest.mark.parametrize("dt,tol", DT)
+@pytest.mark.parametrize("Nb,Cin,Cout,H,splitk", [(4, 64, 128, 16, 1), (3, 32, 64, 8, 0), (2, 256, 512, 8, 4),
+                                                 (5, 3, 64, 64, 1), (64, 512, 1024, 4, 0)])
+def test_conv_s2_forward(dt, tol, Nb, Cin, Cout, H, splitk):
+    lib = _lib()
+    g = torch.Generator().manual_seed(Nb * 1000 + Cin)
+    x = q(torch.randn(Nb, Cin, H, H, generator=g), dt)
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1, dt)
+    b = torch.randn(Cout, generator=g)
+    ref = nhwc(F.conv2d(x, w, b, stride=2, padding=1))
+    xd = nhwc(x).to(dt).cuda()
+    wd = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous().to(dt).cuda()
+    out = torch.empty(Nb, H // 2, H // 2, Cout, device="cuda")
+    lib.conv_igemm(xd, wd, b.cuda(), out, 3, 2, 1, 0, splitk)
+    assert_close(out.cpu(), ref, tol)
+
+
+@pytest.mark.parametrize("dt,tol", DT)
+@pytest.mark.parametrize("Nb,Cin,Cout,H,splitk", [(4, 128, 64, 4, 1), (3, 64, 64, 32, 0), (64, 1024, 512, 2, 0)])
+def test_convT_s2_forward(dt, tol, Nb, Cin, Cout, H, splitk):
+    lib = _lib()
+    g = torch.Generator().manual_seed(7 + Cin)
+    x = q(torch.randn(Nb, Cin, H, H, generator=g), dt)
+    w = q(torch.randn(Cin, Cout, 3, 3, generator=g) * 0.1, dt)
+    b = torch.randn(Cout, generator=g)
+    ref = nhwc(F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1))
+    xd = nhwc(x).to(dt).cuda()
+    wd = w.permute(1, 2, 3, 0).reshape(Cout, 9, Cin).contiguous().to(dt).cuda()
+    out = torch.empty(Nb, 2 * H, 2 * H, Cout, device="cuda")
+    lib.conv_igemm(xd, wd, b.cuda(), out, 3, 2, 1, 1, splitk)
+    assert_close(out.cpu(), ref, tol)
+
+
+@pytest.mark.parametrize("dt,tol", DT)
+def test_conv_s2_input_gradient_is_scatter_form(dt, tol):
+    lib = _lib()
+    g = torch.Generator().manual_seed(11)
+    Nb, Cin, Cout, H = 3, 64, 128, 16
+    x = torch.randn(Nb, Cin, H, H, generator=g, requires_grad=True)
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1, dt)
+    dy = q(torch.randn(Nb, Cout, H // 2, H // 2, generator=g), dt)
+    F.conv2d(x, w, None, stride=2, padding=1).backward(dy)
+    dyd = nhwc(dy).to(dt).cuda()
+    wt = w.permute(1, 2, 3, 0).reshape(Cin, 9, Cout).contiguous().to(dt).cuda()   # [Cin][tap][Cout]
+    out = torch.empty(Nb, H, H, Cin, device="cuda")
+    lib.conv_igemm(dyd, wt, None, out, 3, 2, 1, 1, 0)
+    assert_close(out.cpu(), nhwc(x.grad), tol)
+
+
+@pytest.mark.parametrize("dt,tol", DT)
+def test_convT_s2_input_gradient_is_gather_form(dt, tol):
+    lib = _lib()
+    g = torch.Generator().manual_seed(12)
+    Nb, Cin, Cout, H = 3, 128, 64, 8
+    x = torch.randn(Nb, Cin, H, H, generator=g, requires_grad=True)
+    w = q(torch.randn(Cin, Cout, 3, 3, generator=g) * 0.1, dt)
+    dy = q(torch.randn(Nb, Cout, 2 * H, 2 * H, generator=g), dt)
+    F.conv_transpose2d(x, w, None, stride=2, padding=1, output_padding=1).backward(dy)
+    dyd = nhwc(dy).to(dt).cuda()
+    wt = w.permute(0, 2, 3, 1).reshape(Cin, 9, Cout).contiguous().to(dt).cuda()   # [CinT][tap][CoutT]
+    out = torch.empty(Nb, H, H, Cin, device="cuda")
+    lib.conv_igemm(dyd, wt, None, out, 3, 2, 1, 0, 0)
+    assert_close(out.cpu(), nhwc(x.grad), tol)
+
+
+@pytest.mark.parametrize("dt,tol", DT)
+def test_final_conv_s1_forward_and_input_gradient(dt, tol):
+    lib = _lib()
+    g = torch.Generator().manual_seed(13)
+    Nb, Cin, Cout, H = 2, 64, 3, 64
+    x = q(torch.randn(Nb, Cin, H, H, generator=g), dt).requires_grad_(True)
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1, dt)
+    b = torch.randn(Cout, generator=g)
+    y = F.conv2d(x, w, b, stride=1, padding=1)
+    dy = q(torch.randn(Nb, Cout, H, H, generator=g), dt)
+    y.backward(dy)
+    xd = nhwc(x.detach()).to(dt).cuda()
+    wd = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous().to(dt).cuda()
+    out = torch.empty(Nb, H, H, Cout, device="cuda")
+    lib.conv_igemm(xd, wd, b.cuda(), out, 3, 1, 1, 0, 0)
+    assert_close(out.cpu(), nhwc(y.detach()), tol)
+    dyd = nhwc(dy).to(dt).cuda()
+    wt = w.permute(1, 2, 3, 0).reshape(Cin, 9, Cout).contiguous().to(dt).cuda()
+    dx = torch.empty(Nb, H, H, Cin, device="cuda")
+    lib.conv_igemm(dyd, wt, None, dx, 3, 1, 1, 1, 0)
+    assert_close(dx.cpu(), nhwc(x.grad), tol)
+
+
+@pytest.mark.parametrize("dt,tol", DT)
+@pytest.mark.parametrize("Nb,K,Nout", [(64, 4096, 40), (64, 20, 4096), (17, 40, 4096)])
+def test_linear_as_1x1(dt, tol, Nb, K, Nout):
+    lib = _lib()
+    g = torch.Generator().manual_seed(K)
+    x = q(torch.randn(Nb, K, generator=g), dt)
+    w = q(torch.randn(Nout, K, generator=g) * 0.05, dt)
+    b = torch.randn(Nout, generator=g)
+    ref = F.linear(x, w, b)
+    out = torch.empty(Nb, 1, 1, Nout, device="cuda")
+    lib.conv_igemm(x.to(dt).cuda().view(Nb, 1, 1, K), w.to(dt).cuda().view(Nout, 1, K), b.cuda(), out, 1, 1, 0, 0, 0)
+    assert_close(out.cpu().view(Nb, Nout), ref, tol)
+
+
+@pytest.mark.parametrize("dt,tol", DT)
+@pytest.mark.parametrize("Nb,Cin,Cout,H", [(4, 64, 128, 16), (64, 512, 1024, 4), (3, 3, 64, 64)])
+def test_conv_s2_weight_gradient(dt, tol, Nb, Cin, Cout, H):
+    lib = _lib()
+    g = torch.Generator().manual_seed(21 + Cin)
+    x = q(torch.randn(Nb, Cin, H, H, generator=g), dt)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g, requires_grad=True)
+    dy = q(torch.randn(Nb, Cout, H // 2, H // 2, generator=g), dt)
+    F.conv2d(x, w, None, stride=2, padding=1).backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, 9, Cin)
+    dw = torch.zeros(Cout, 9, Cin, device="cuda")
+    lib.conv_wgrad(nhwc(dy).to(dt).cuda(), 0, nhwc(x).to(dt).cuda(), 1, dw, Nb, H // 2, H // 2, H, H, 3, 2, 1, 0)
+    assert_close(dw.cpu(), ref, tol)
+
+
+@pytest.mark.parametrize("dt,tol", DT)
+@pytest.mark.parametrize("Nb,Cin,Cout,H", [(4, 128, 64, 8), (64, 1024, 512, 2), (2, 64, 64, 32)])
+def test_convT_s2_weight_gradient(dt, tol, Nb, Cin, Cout, H):
+    lib = _lib()
+    g = torch.Generator().manual_seed(31 + Cin)
+    x = q(torch.randn(Nb, Cin, H, H, generator=g), dt)
+    w = torch.randn(Cin, Cout, 3, 3, generator=g, requires_grad=True)
+    dy = q(torch.randn(Nb, Cout, 2 * H, 2 * H, generator=g), dt)
+    F.conv_transpose2d(x, w, None, stride=2, padding=1, output_padding=1).backward(dy)
+    ref = w.grad.permute(1, 2, 3, 0).reshape(Cout, 9, Cin)                         # master layout [CoutT][tap][CinT]
+    dw = torch.zeros(Cout, 9, Cin, device="cuda")
+    lib.conv_wgrad(nhwc(dy).to(dt).cuda(), 1, nhwc(x).to(dt).cuda(), 0, dw, Nb, H, H, 2 * H, 2 * H, 3, 2, 1, 0)
+    assert_close(dw.cpu(), ref, tol)
+
+
+@pytest.mark.parametrize("dt,tol", DT)
+def test_final_conv_and_linear_weight_gradient(dt, tol):
+    lib = _lib()
+    g = torch.Generator().manual_seed(41)
+    Nb, Cin, Cout, H = 2, 64, 3, 64
+    x = q(torch.randn(Nb, Cin, H, H, generator=g), dt)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g, requires_grad=True)
+    dy = q(torch.randn(Nb, Cout, H, H, generator=g), dt)
+    F.conv2d(x, w, None, stride=1, padding=1).backward(dy)
+    dw = torch.zeros(Cout, 9, Cin, device="cuda")
+    lib.conv_wgrad(nhwc(dy).to(dt).cuda(), 0, nhwc(x).to(dt).cuda(), 1, dw, Nb, H, H, H, H, 3, 1, 1, 0)
+    assert_close(dw.cpu(), w.grad.permute(0, 2, 3, 1).reshape(Cout, 9, Cin), tol)
+    # linear: dW[out][in] = dy^T x
+    B, K, Nout = 64, 4096, 40
+    xl = q(torch.randn(B, K, generator=g), dt)
+    dyl = q(torch.randn(B, Nout, generator=g), dt)
+    dwl = torch.zeros(Nout, 1, K, device="cuda")
+    lib.conv_wgrad(dyl.to(dt).cuda(), 0, xl.to(dt).cuda(), 0, dwl, B, 1, 1, 1, 1, 1, 1, 0, 0)
+    assert_close(dwl.cpu().view(Nout, K), dyl.t() @ xl, tol)
