@@ -28,7 +28,12 @@ extern "C" void favae_set_error(const char* fmt, ...);
         }                                                                                       \
     } while (0)
 
-#define FAVAE_LAUNCH_CHECK() FAVAE_HIP(hipGetLastError())
+extern "C" int favae_debug_sync_enabled(void);
+#define FAVAE_LAUNCH_CHECK()                                              \
+    do {                                                                  \
+        FAVAE_HIP(hipGetLastError());                                     \
+        if (favae_debug_sync_enabled()) FAVAE_HIP(hipDeviceSynchronize()); \
+    } while (0)
 
 typedef unsigned short bf16_t;  // storage type of a bfloat16 element
 

@@ -1,0 +1,563 @@
+// Non-GEMM kernels of the conv-VAE training step on gfx950: BatchNorm(train/eval)+LeakyReLU forward and
+// backward, reparameterisation + KL against the FA prior, sigmoid + Gaussian log-likelihood, Adam, weight
+// re-layout, batch gather.  All of them are HBM-bound column reductions or element-wise passes over NHWC
+// [rows][C] matrices.  Reference: condition_a_VAE/celeba_deepvanilla_vae.py (line numbers cited per kernel).
+#include <algorithm>
+#include "common.h"
+#include "favae_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// deterministic two-pass column reduction over a row-major [R][C] matrix
+//   pass 1: block (slab, channel tile) -> partial[slab][v][c]   (fp64)
+//   pass 2: a per-use "finish" kernel sums the slabs in a fixed order
+// ---------------------------------------------------------------------------------------------------------
+struct RedGeom { int CL, RG, ctiles, nslab, rps; };
+
+RedGeom red_geom(long long R, int C) {
+    RedGeom g;
+    g.CL = std::min(C, 64);
+    g.RG = 256 / g.CL;
+    g.ctiles = cdiv(C, g.CL);
+    int target = std::max(1, 1024 / g.ctiles);
+    long long min_rows = (long long)g.RG * 8;
+    long long ns = std::max(1LL, std::min((long long)target, cdivll(R, min_rows)));
+    g.rps = (int)cdivll(R, ns);
+    g.nslab = (int)cdivll(R, g.rps);
+    return g;
+}
+
+template <int NV, class F>
+__global__ __launch_bounds__(256) void colreduce(int R, int C, int CL, int RG, int rps, double* partial, F f) {
+    __shared__ double sm[256 * NV];
+    const int tid = threadIdx.x, cl = tid % CL, rg = tid / CL;
+    const int c = blockIdx.y * CL + cl;
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+    if (rg < RG && c < C) {
+        const int r0 = blockIdx.x * rps, r1 = min(R, r0 + rps);
+        for (int r = r0 + rg; r < r1; r += RG) f(r, c, acc);
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) sm[v * 256 + tid] = acc[v];
+    __syncthreads();
+    if (rg == 0 && c < C) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            double s = 0.0;
+            for (int g = 0; g < RG; ++g) s += sm[v * 256 + g * CL + cl];
+            partial[((size_t)blockIdx.x * NV + v) * C + c] = s;
+        }
+    }
+}
+
+template <int NV, class F>
+int run_colreduce(long long R, int C, double* partial, size_t partial_cap, RedGeom& g, F f, hipStream_t st) {
+    g = red_geom(R, C);
+    FAVAE_CHECK_ARG((size_t)g.nslab * NV * C <= partial_cap, "column reduction: scratch too small (%zu < %zu doubles)",
+                    partial_cap, (size_t)g.nslab * NV * C);
+    hipLaunchKernelGGL((colreduce<NV, F>), dim3(g.nslab, g.ctiles), dim3(256), 0, st, (int)R, C, g.CL, g.RG, g.rps, partial, f);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+__device__ __forceinline__ double slab_sum(const double* partial, int nslab, int nv, int v, int C, int c) {
+    double s = 0.0;
+    for (int i = 0; i < nslab; ++i) s += partial[((size_t)i * nv + v) * C + c];
+    return s;
+}
+
+// ---- BatchNorm2d (train) statistics: nn.BatchNorm2d(h_dim), celeba_deepvanilla_vae.py:34,58,72 -------------
+struct StatsF {
+    const float* x; int C;
+    __device__ void operator()(int r, int c, double* acc) const {
+        const double v = x[(size_t)r * C + c];
+        acc[0] += v; acc[1] += v * v;
+    }
+};
+
+__global__ void bn_stats_finish(const double* partial, int nslab, int C, double R, float eps, float mom, float* mean,
+                                float* invstd, float* run_mean, float* run_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double s = slab_sum(partial, nslab, 2, 0, C, c), s2 = slab_sum(partial, nslab, 2, 1, C, c);
+    const double m = s / R;
+    double var = s2 / R - m * m;
+    if (var < 0) var = 0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+        const double unb = R > 1 ? var * R / (R - 1) : var;
+        run_mean[c] = (1.f - mom) * run_mean[c] + mom * (float)m;
+        run_var[c] = (1.f - mom) * run_var[c] + mom * (float)unb;
+    }
+}
+
+__global__ void bn_eval_prep(const float* run_mean, const float* run_var, int C, float eps, float* mean, float* invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = run_mean[c];
+    invstd[c] = 1.f / sqrtf(run_var[c] + eps);
+}
+
+// ---- BN apply + LeakyReLU(0.01) forward, 4 channels per thread -----------------------------------------------
+template <class T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+    *(float4*)p = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+    uint2 u;
+    u.x = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+    u.y = (unsigned)f32_to_bf16(c) | ((unsigned)f32_to_bf16(d) << 16);
+    *(uint2*)p = u;
+}
+template <class T> __device__ __forceinline__ float4 load4(const T* p);
+template <> __device__ __forceinline__ float4 load4<float>(const float* p) { return *(const float4*)p; }
+template <> __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
+    const uint2 u = *(const uint2*)p;
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+
+__device__ __forceinline__ float lrelu(float y) { return y > 0.f ? y : 0.01f * y; }
+
+template <class T>
+__global__ __launch_bounds__(256) void bn_lrelu_fwd(const float* __restrict__ raw, const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, T* __restrict__ act, size_t nvec, int C,
+                                                    int apply_act) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        const float4 x = *(const float4*)(raw + i * 4);
+        float y[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = invstd[c + j] * gamma[c + j];
+            y[j] = y[j] * a + (beta[c + j] - mean[c + j] * a);
+            if (apply_act) y[j] = lrelu(y[j]);
+        }
+        store4<T>(act + i * 4, y[0], y[1], y[2], y[3]);
+    }
+}
+
+// ---- BN + LeakyReLU backward ---------------------------------------------------------------------------------
+template <class T>
+struct BnBwdRedF {
+    const float* dact; const T* act; const float* raw; const float* mean; const float* invstd; int C;
+    __device__ void operator()(int r, int c, double* acc) const {
+        const size_t i = (size_t)r * C + c;
+        const float a = to_f32<T>(act[i]);
+        const float d = dact[i] * (a > 0.f ? 1.f : 0.01f);
+        const float xh = (raw[i] - mean[c]) * invstd[c];
+        acc[0] += d; acc[1] += (double)d * xh;
+    }
+};
+
+__global__ void bn_bwd_finish(const double* partial, int nslab, int C, float* dgamma, float* dbeta, float* s1s2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double s1 = slab_sum(partial, nslab, 2, 0, C, c), s2 = slab_sum(partial, nslab, 2, 1, C, c);
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    s1s2[c] = (float)s1;
+    s1s2[C + c] = (float)s2;
+}
+
+template <class T>
+struct BnBwdApplyF {
+    const float* dact; const T* act; const float* raw; const float* mean; const float* invstd; const float* gamma;
+    const float* s1s2; T* draw; int C; float invR;
+    __device__ void operator()(int r, int c, double* acc) const {
+        const size_t i = (size_t)r * C + c;
+        const float a = to_f32<T>(act[i]);
+        const float d = dact[i] * (a > 0.f ? 1.f : 0.01f);
+        const float xh = (raw[i] - mean[c]) * invstd[c];
+        const float g = gamma[c] * invstd[c] * (d - s1s2[c] * invR - xh * s1s2[C + c] * invR);
+        draw[i] = from_f32<T>(g);
+        acc[0] += g;
+    }
+};
+
+template <class T>
+struct ColsumF {
+    const T* x; int C;
+    __device__ void operator()(int r, int c, double* acc) const { acc[0] += to_f32<T>(x[(size_t)r * C + c]); }
+};
+
+__global__ void colsum_finish(const double* partial, int nslab, int C, float* out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) out[c] = (float)slab_sum(partial, nslab, 1, 0, C, c);
+}
+
+// ---- reparameterise + KL(q || N(mu_P, 1/tau)) : celeba_deepvanilla_vae.py:86-92,137-150,231-232 --------------
+// one block; B*z is at most a few tens of thousands of elements
+template <class T>
+__global__ __launch_bounds__(256) void reparam_kl_fwd(const float* __restrict__ fc, const float* __restrict__ eps,
+                                                      const double* __restrict__ prior, const int* __restrict__ idx,
+                                                      float tau, int B, int z, T* __restrict__ zlat,
+                                                      float* __restrict__ stdq, double* __restrict__ kl_out) {
+    __shared__ double sm[4];
+    const double std_p = sqrt((double)(1.0f / tau));
+    const double sp = fmin(fmax(std_p, 1e-6), 1e20);
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < B * z; i += 256) {
+        const int b = i / z, k = i - b * z;
+        const float mu = fc[b * 2 * z + k];
+        const float lv = fc[b * 2 * z + z + k] + 1e-6f;
+        const float sd = expf(0.5f * lv);
+        stdq[i] = sd;
+        zlat[i] = from_f32<T>(eps[i] * sd + mu);
+        const double mp = prior ? prior[(size_t)(idx ? idx[b] : b) * z + k] : 0.0;
+        const double sq = fmin(fmax((double)sd, 1e-6), 1e20);
+        const double vr = (sq / sp) * (sq / sp);
+        const double t1 = ((double)mu - mp) / sp;
+        acc += 0.5 * (vr + t1 * t1 - 1.0 - log(vr));
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *kl_out = (sm[0] + sm[1] + sm[2] + sm[3]) / B;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void reparam_kl_bwd(const float* __restrict__ fc, const float* __restrict__ eps,
+                                                      const double* __restrict__ prior, const int* __restrict__ idx,
+                                                      const float* __restrict__ stdq, const float* __restrict__ dz, float tau,
+                                                      float beta, int B, int z, T* __restrict__ dfc) {
+    const double std_p = sqrt((double)(1.0f / tau));
+    const double sp = fmin(fmax(std_p, 1e-6), 1e20);
+    const double w = (double)beta / B;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < B * z; i += gridDim.x * 256) {
+        const int b = i / z, k = i - b * z;
+        const float mu = fc[b * 2 * z + k];
+        const float sd = stdq[i];
+        const double mp = prior ? prior[(size_t)(idx ? idx[b] : b) * z + k] : 0.0;
+        const bool in_rng = sd >= 1e-6f && sd <= 1e20f;
+        const double sq = fmin(fmax((double)sd, 1e-6), 1e20);
+        const float dkl_mu = (float)(w * ((double)mu - mp) / (sp * sp));
+        const float dkl_sd = in_rng ? (float)(w * (sq / (sp * sp) - 1.0 / sq)) : 0.f;
+        const float g = dz[i];
+        const float dmu = g + dkl_mu;
+        const float dsd = g * eps[i] + dkl_sd;
+        dfc[b * 2 * z + k] = from_f32<T>(dmu);
+        dfc[b * 2 * z + z + k] = from_f32<T>(dsd * 0.5f * sd);
+    }
+}
+
+// eval-mode head of update_x: mu and var = std^2 as float64 rows of X.mean / X.cov (:331-358)
+__global__ void encode_head(const float* __restrict__ fc, int B, int z, double* __restrict__ xmean, double* __restrict__ xcov) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * z) return;
+    const int b = i / z, k = i - b * z;
+    const float sd = expf(0.5f * (fc[b * 2 * z + z + k] + 1e-6f));
+    xmean[i] = (double)fc[b * 2 * z + k];
+    xcov[i] = (double)(sd * sd);
+}
+
+// ---- sigmoid + Gaussian log-likelihood and its gradient (:77, 152-171) ---------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void sigmoid_ll(const float* __restrict__ raw, const float* __restrict__ x, size_t n,
+                                                  float inv_var_B, T* __restrict__ draw, double* __restrict__ partial) {
+    __shared__ double sm[4];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float s = 1.f / (1.f + expf(-raw[i]));
+        const float d = s - x[i];
+        acc += (double)d * d;
+        draw[i] = from_f32<T>(d * inv_var_B * s * (1.f - s));
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ void ll_finish(const double* partial, int n, double D, double var_x, double B, double* rec_err) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += partial[i];
+        // -mean_b LL_b ,  LL_b = -0.5 (D ln 2pi + D ln var + SSE_b / var)
+        *rec_err = 0.5 * (D * log(2.0 * M_PI) + D * log(var_x)) + 0.5 * s / (var_x * B);
+    }
+}
+
+__global__ void sigmoid_only(const float* __restrict__ raw, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = 1.f / (1.f + expf(-raw[i]));
+}
+
+// ---- Adam (torch.optim.Adam defaults, :131,250) over the flat parameter arena ---------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t n4, float b1, float b2, float eps,
+                                                   float step_size, float bc2_sqrt) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 P = ((float4*)p)[i], G = ((const float4*)g)[i], M = ((float4*)m)[i], V = ((float4*)v)[i];
+        float* pp = (float*)&P; float* gg = (float*)&G; float* mm = (float*)&M; float* vv = (float*)&V;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mm[j] = mm[j] + (1.f - b1) * (gg[j] - mm[j]);
+            vv[j] = vv[j] * b2 + (1.f - b2) * gg[j] * gg[j];
+            const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+            pp[j] = pp[j] - step_size * (mm[j] / denom);
+        }
+        ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V;
+    }
+}
+
+// ---- weight re-layout: master fp32 [Co][taps][Ci] -> T copy (same layout) and T transpose [Ci][taps][Co] -----
+template <class T>
+__global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w, T* __restrict__ wc, T* __restrict__ wt, int Co,
+                                                    int taps, int Ci) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int co = co0 + i, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < Co && ci < Ci) {
+            const size_t o = ((size_t)co * taps + tap) * Ci + ci;
+            v = w[o];
+            if (wc) wc[o] = from_f32<T>(v);
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    if (wt) {
+        for (int i = ty; i < 32; i += 8) {
+            const int ci = ci0 + i, co = co0 + tx;
+            if (co < Co && ci < Ci) wt[((size_t)ci * taps + tap) * Co + co] = from_f32<T>(tile[tx][i]);
+        }
+    }
+}
+
+// ---- batch gather: rows of the resident fp32 NHWC dataset -> fp32 batch (LL target) + T batch (conv input) ----
+template <class T>
+__global__ __launch_bounds__(256) void gather_batch(const float* __restrict__ data, const int* __restrict__ idx, int B,
+                                                    size_t row4, float* __restrict__ xf, T* __restrict__ xt) {
+    const size_t total = (size_t)B * row4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / row4, j = i - b * row4;
+        const size_t src = (size_t)(idx ? idx[b] : (int)b) * row4 + j;
+        const float4 v = ((const float4*)data)[src];
+        if (xf) ((float4*)xf)[i] = v;
+        if (xt) store4<T>(xt + i * 4, v.x, v.y, v.z, v.w);
+    }
+}
+
+template <class T>
+__global__ void cast_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = from_f32<T>(in[i]);
+}
+
+// NCHW <-> NHWC with optional channel padding (Cp >= C, pad = 0)
+__global__ void nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, size_t N, int C, int HW, int Cp) {
+    const size_t total = N * HW * Cp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % Cp);
+        const size_t p = i / Cp, n = p / HW, hw = p - n * HW;
+        out[i] = c < C ? in[(n * C + c) * HW + hw] : 0.f;
+    }
+}
+__global__ void nhwc_to_nchw_f64(const float* __restrict__ in, double* __restrict__ out, size_t N, int C, int HW, int Cp) {
+    const size_t total = N * C * HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t hw = i % HW, q = i / HW, c = q % C, n = q / C;
+        out[i] = (double)in[(n * HW + hw) * Cp + c];
+    }
+}
+
+inline int ew_grid(size_t n) { return (int)std::min<size_t>(4096, std::max<size_t>(1, (n + 255) / 256)); }
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int favae_bn_stats(const float* raw, long long R, int C, float eps, float momentum, float* mean, float* invstd,
+                              float* run_mean, float* run_var, double* scratch, size_t scratch_doubles, void* stream) {
+    FAVAE_CHECK_ARG(raw && mean && invstd && scratch && R > 0 && C > 0 && R < (1LL << 31), "favae_bn_stats: bad argument");
+    RedGeom g;
+    int rc = run_colreduce<2>(R, C, scratch, scratch_doubles, g, StatsF{raw, C}, ST);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_stats_finish, dim3(cdiv(C, 64)), dim3(64), 0, ST, scratch, g.nslab, C, (double)R, eps, momentum, mean,
+                       invstd, run_mean, run_var);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_bn_eval_prep(const float* run_mean, const float* run_var, int C, float eps, float* mean, float* invstd,
+                                  void* stream) {
+    FAVAE_CHECK_ARG(run_mean && run_var && mean && invstd && C > 0, "favae_bn_eval_prep: bad argument");
+    hipLaunchKernelGGL(bn_eval_prep, dim3(cdiv(C, 64)), dim3(64), 0, ST, run_mean, run_var, C, eps, mean, invstd);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_bn_lrelu_fwd(const float* raw, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, void* act, long long R, int C, int apply_act, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(raw && mean && invstd && gamma && beta && act && R > 0 && C > 0 && C % 4 == 0, "favae_bn_lrelu_fwd: bad argument");
+    const size_t nvec = (size_t)R * C / 4;
+    if (dtype == FAVAE_F32)
+        hipLaunchKernelGGL(bn_lrelu_fwd<float>, dim3(ew_grid(nvec)), dim3(256), 0, ST, raw, mean, invstd, gamma, beta, (float*)act, nvec, C, apply_act);
+    else
+        hipLaunchKernelGGL(bn_lrelu_fwd<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, ST, raw, mean, invstd, gamma, beta, (bf16_t*)act, nvec, C, apply_act);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+template <class T>
+static int bn_bwd_impl(const float* dact, const T* act, const float* raw, const float* mean, const float* invstd,
+                       const float* gamma, T* draw, float* dgamma, float* dbeta, float* dbias, long long R, int C,
+                       double* scratch, size_t cap, float* s1s2, hipStream_t st) {
+    RedGeom g;
+    int rc = run_colreduce<2>(R, C, scratch, cap, g, BnBwdRedF<T>{dact, act, raw, mean, invstd, C}, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finish, dim3(cdiv(C, 64)), dim3(64), 0, st, scratch, g.nslab, C, dgamma, dbeta, s1s2);
+    FAVAE_LAUNCH_CHECK();
+    rc = run_colreduce<1>(R, C, scratch, cap, g,
+                          BnBwdApplyF<T>{dact, act, raw, mean, invstd, gamma, s1s2, draw, C, (float)(1.0 / (double)R)}, st);
+    if (rc) return rc;
+    if (dbias) {
+        hipLaunchKernelGGL(colsum_finish, dim3(cdiv(C, 64)), dim3(64), 0, st, scratch, g.nslab, C, dbias);
+        FAVAE_LAUNCH_CHECK();
+    }
+    return FAVAE_OK;
+}
+
+extern "C" int favae_bn_lrelu_bwd(const float* dact, const void* act, const float* raw, const float* mean,
+                                  const float* invstd, const float* gamma, void* draw, float* dgamma, float* dbeta,
+                                  float* dbias, long long R, int C, double* scratch, size_t scratch_doubles, float* s1s2,
+                                  int dtype, void* stream) {
+    FAVAE_CHECK_ARG(dact && act && raw && mean && invstd && gamma && draw && dgamma && dbeta && scratch && s1s2,
+                    "favae_bn_lrelu_bwd: null pointer");
+    FAVAE_CHECK_ARG(R > 0 && R < (1LL << 31) && C > 0, "favae_bn_lrelu_bwd: bad shape");
+    if (dtype == FAVAE_F32)
+        return bn_bwd_impl<float>(dact, (const float*)act, raw, mean, invstd, gamma, (float*)draw, dgamma, dbeta, dbias, R, C, scratch, scratch_doubles, s1s2, ST);
+    return bn_bwd_impl<bf16_t>(dact, (const bf16_t*)act, raw, mean, invstd, gamma, (bf16_t*)draw, dgamma, dbeta, dbias, R, C, scratch, scratch_doubles, s1s2, ST);
+}
+
+extern "C" int favae_colsum(const void* x, long long R, int C, float* out, double* scratch, size_t scratch_doubles, int dtype,
+                            void* stream) {
+    FAVAE_CHECK_ARG(x && out && scratch && R > 0 && R < (1LL << 31) && C > 0, "favae_colsum: bad argument");
+    RedGeom g;
+    int rc = dtype == FAVAE_F32 ? run_colreduce<1>(R, C, scratch, scratch_doubles, g, ColsumF<float>{(const float*)x, C}, ST)
+                                : run_colreduce<1>(R, C, scratch, scratch_doubles, g, ColsumF<bf16_t>{(const bf16_t*)x, C}, ST);
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_finish, dim3(cdiv(C, 64)), dim3(64), 0, ST, scratch, g.nslab, C, out);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_reparam_kl_fwd(const float* fc, const float* eps, const double* prior, const int* idx, float tau, int B,
+                                    int z, void* zlat, float* stdq, double* kl_out, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(fc && eps && zlat && stdq && kl_out && B > 0 && z > 0 && tau > 0, "favae_reparam_kl_fwd: bad argument");
+    if (dtype == FAVAE_F32)
+        hipLaunchKernelGGL(reparam_kl_fwd<float>, dim3(1), dim3(256), 0, ST, fc, eps, prior, idx, tau, B, z, (float*)zlat, stdq, kl_out);
+    else
+        hipLaunchKernelGGL(reparam_kl_fwd<bf16_t>, dim3(1), dim3(256), 0, ST, fc, eps, prior, idx, tau, B, z, (bf16_t*)zlat, stdq, kl_out);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_reparam_kl_bwd(const float* fc, const float* eps, const double* prior, const int* idx, const float* stdq,
+                                    const float* dz, float tau, float beta, int B, int z, void* dfc, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(fc && eps && stdq && dz && dfc && B > 0 && z > 0 && tau > 0, "favae_reparam_kl_bwd: bad argument");
+    const int grid = cdiv(B * z, 256);
+    if (dtype == FAVAE_F32)
+        hipLaunchKernelGGL(reparam_kl_bwd<float>, dim3(grid), dim3(256), 0, ST, fc, eps, prior, idx, stdq, dz, tau, beta, B, z, (float*)dfc);
+    else
+        hipLaunchKernelGGL(reparam_kl_bwd<bf16_t>, dim3(grid), dim3(256), 0, ST, fc, eps, prior, idx, stdq, dz, tau, beta, B, z, (bf16_t*)dfc);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_encode_head(const float* fc, int B, int z, double* xmean, double* xcov, void* stream) {
+    FAVAE_CHECK_ARG(fc && xmean && xcov && B > 0 && z > 0, "favae_encode_head: bad argument");
+    hipLaunchKernelGGL(encode_head, dim3(cdiv(B * z, 256)), dim3(256), 0, ST, fc, B, z, xmean, xcov);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_sigmoid_ll(const float* raw, const float* x, int B, long long D, float var_x, void* draw, double* rec_err,
+                                double* scratch, size_t scratch_doubles, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(raw && x && draw && rec_err && scratch && B > 0 && D > 0 && var_x > 0, "favae_sigmoid_ll: bad argument");
+    const size_t n = (size_t)B * D;
+    const int grid = (int)std::min<size_t>(1024, (n + 255) / 256);
+    FAVAE_CHECK_ARG((size_t)grid <= scratch_doubles, "favae_sigmoid_ll: scratch too small");
+    const float ivb = 1.f / (var_x * (float)B);
+    if (dtype == FAVAE_F32)
+        hipLaunchKernelGGL(sigmoid_ll<float>, dim3(grid), dim3(256), 0, ST, raw, x, n, ivb, (float*)draw, scratch);
+    else
+        hipLaunchKernelGGL(sigmoid_ll<bf16_t>, dim3(grid), dim3(256), 0, ST, raw, x, n, ivb, (bf16_t*)draw, scratch);
+    FAVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ll_finish, dim3(1), dim3(64), 0, ST, scratch, grid, (double)D, (double)var_x, (double)B, rec_err);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_sigmoid(const float* raw, float* out, long long n, void* stream) {
+    FAVAE_CHECK_ARG(raw && out && n > 0, "favae_sigmoid: bad argument");
+    hipLaunchKernelGGL(sigmoid_only, dim3(ew_grid((size_t)n)), dim3(256), 0, ST, raw, out, (size_t)n);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                               float eps, long long step, void* stream) {
+    FAVAE_CHECK_ARG(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "favae_adam_step: bad argument (n must be a multiple of 4)");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid((size_t)n / 4)), dim3(256), 0, ST, p, g, m, v, (size_t)n / 4, beta1, beta2, eps, step_size, bc2_sqrt);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_weight_prep(const float* w, void* w_copy, void* w_transposed, int Co, int taps, int Ci, int dtype,
+                                 void* stream) {
+    FAVAE_CHECK_ARG(w && Co > 0 && taps > 0 && Ci > 0 && (w_copy || w_transposed), "favae_weight_prep: bad argument");
+    dim3 grid(cdiv(Ci, 32), cdiv(Co, 32), taps);
+    if (dtype == FAVAE_F32)
+        hipLaunchKernelGGL(wprep_kernel<float>, grid, dim3(256), 0, ST, w, (float*)w_copy, (float*)w_transposed, Co, taps, Ci);
+    else
+        hipLaunchKernelGGL(wprep_kernel<bf16_t>, grid, dim3(256), 0, ST, w, (bf16_t*)w_copy, (bf16_t*)w_transposed, Co, taps, Ci);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_gather_batch(const float* data, const int* idx, int B, long long row_floats, float* x_f32, void* x_t,
+                                  int dtype, void* stream) {
+    FAVAE_CHECK_ARG(data && B > 0 && row_floats > 0 && row_floats % 4 == 0 && (x_f32 || x_t), "favae_gather_batch: bad argument");
+    const size_t row4 = (size_t)row_floats / 4;
+    const int grid = ew_grid((size_t)B * row4);
+    if (dtype == FAVAE_F32)
+        hipLaunchKernelGGL(gather_batch<float>, dim3(grid), dim3(256), 0, ST, data, idx, B, row4, x_f32, (float*)x_t);
+    else
+        hipLaunchKernelGGL(gather_batch<bf16_t>, dim3(grid), dim3(256), 0, ST, data, idx, B, row4, x_f32, (bf16_t*)x_t);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_cast(const float* in, void* out, long long n, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(in && out && n > 0, "favae_cast: bad argument");
+    if (dtype == FAVAE_F32)
+        hipLaunchKernelGGL(cast_kernel<float>, dim3(ew_grid((size_t)n)), dim3(256), 0, ST, in, (float*)out, (size_t)n);
+    else
+        hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(ew_grid((size_t)n)), dim3(256), 0, ST, in, (bf16_t*)out, (size_t)n);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_nchw_to_nhwc(const float* in, float* out, long long N, int C, int HW, int Cpad, void* stream) {
+    FAVAE_CHECK_ARG(in && out && N > 0 && C > 0 && HW > 0 && Cpad >= C, "favae_nchw_to_nhwc: bad argument");
+    hipLaunchKernelGGL(nchw_to_nhwc, dim3(ew_grid((size_t)N * HW * Cpad)), dim3(256), 0, ST, in, out, (size_t)N, C, HW, Cpad);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_nhwc_to_nchw_f64(const float* in, double* out, long long N, int C, int HW, int Cpad, void* stream) {
+    FAVAE_CHECK_ARG(in && out && N > 0 && C > 0 && HW > 0 && Cpad >= C, "favae_nhwc_to_nchw_f64: bad argument");
+    hipLaunchKernelGGL(nhwc_to_nchw_f64, dim3(ew_grid((size_t)N * C * HW)), dim3(256), 0, ST, in, out, (size_t)N, C, HW, Cpad);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}

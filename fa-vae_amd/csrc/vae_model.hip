@@ -1,0 +1,381 @@
+// The conv-VAE executor: sequences one training step / encoder pass / decoder pass of the FA-VAE network
+// (reference condition_a_VAE/celeba_deepvanilla_vae.py:16-105 architecture, :227-250 step) out of the kernels in
+// igemm.hip and vae_kernels.hip.  The host passes device buffers (PyTorch tensors used as memory); this file owns
+// the layer table, the carve-up of the workspace and the launch order.  Nothing here allocates device memory.
+#include <algorithm>
+#include <new>
+#include <vector>
+#include "common.h"
+#include "favae_hip.h"
+
+namespace {
+
+enum Kind { CONV_S2 = 0, LINEAR = 1, CONVT_S2 = 2, CONV_S1 = 3 };
+
+struct Layer {
+    int kind, Cin, Cout, Hin, Hout, taps;
+    bool bn;
+    long long w_off, b_off, g_off, be_off;  // parameter arena (floats)
+    long long rm_off, rv_off;               // BN buffer arena (floats)
+    long long wc_off, wt_off;               // shadow arena (elements of dtype); -1 = not materialised
+};
+
+constexpr int NL = 13;
+constexpr int L_FC = 5, L_DI = 6, L_OUT = 12;
+
+inline long long al8(long long x) { return (x + 7) & ~7LL; }
+
+void build_layers(int z, int ch, Layer* L, long long* nparam, long long* nbuf, long long* nshadow, bool f32) {
+    const int hid[5] = {64, 128, 256, 512, 1024};
+    int c = ch, h = 64;
+    for (int i = 0; i < 5; ++i) {
+        L[i] = Layer{CONV_S2, c, hid[i], h, h / 2, 9, true};
+        c = hid[i];
+        h /= 2;
+    }
+    L[L_FC] = Layer{LINEAR, 4096, 2 * z, 1, 1, 1, false};
+    L[L_DI] = Layer{LINEAR, z, 4096, 1, 1, 1, false};
+    c = 1024; h = 2;
+    for (int i = 0; i < 4; ++i) {
+        L[7 + i] = Layer{CONVT_S2, c, hid[3 - i], h, 2 * h, 9, true};
+        c = hid[3 - i];
+        h *= 2;
+    }
+    L[11] = Layer{CONVT_S2, 64, 64, 32, 64, 9, true};
+    L[L_OUT] = Layer{CONV_S1, 64, ch, 64, 64, 9, false};
+    long long po = 0, bo = 0, so = 0;
+    for (int i = 0; i < NL; ++i) {
+        Layer& l = L[i];
+        const long long wn = (long long)l.Cout * l.taps * l.Cin;
+        l.w_off = po; po = al8(po + wn);
+        l.b_off = po; po = al8(po + l.Cout);
+        l.g_off = l.be_off = l.rm_off = l.rv_off = -1;
+        if (l.bn) {
+            l.g_off = po; po = al8(po + l.Cout);
+            l.be_off = po; po = al8(po + l.Cout);
+            l.rm_off = bo; bo = al8(bo + l.Cout);
+            l.rv_off = bo; bo = al8(bo + l.Cout);
+        }
+        l.wc_off = -1;
+        if (!f32) { l.wc_off = so; so = al8(so + wn); }
+        l.wt_off = -1;
+        if (i != 0) { l.wt_off = so; so = al8(so + wn); }   // enc.0 has no input gradient
+    }
+    *nparam = po; *nbuf = bo; *nshadow = so;
+}
+
+struct Vae {
+    int z, ch, Bmax, dtype, esz;
+    Layer L[NL];
+    long long nparam, nbuf, nshadow;
+    float *P, *G, *M, *V, *BUF;
+    char* SH;
+    // workspace
+    float* raw[NL]; char* act[NL]; float* dact[NL]; char* draw[NL];
+    float *mean[NL], *invstd[NL];
+    float *xf, *stdq, *dz, *s1s2;
+    char *xt, *zlat;
+    double *scratch, *metrics2;
+    size_t scratch_doubles;
+    const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(SH + L[l].wc_off * esz); }
+    const void* Wt(int l) const { return (const void*)(SH + L[l].wt_off * esz); }
+    long long rows(int l, int B) const { return (long long)B * L[l].Hout * L[l].Hout; }
+};
+
+struct Carver {
+    char* base; size_t off, cap;
+    void* take(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+void carve(Vae& v, char* base, size_t cap, size_t* need) {
+    Carver c{base, 0, cap};
+    const int B = v.Bmax;
+    for (int l = 0; l < NL; ++l) {
+        const size_t n = (size_t)v.rows(l, B) * v.L[l].Cout;
+        v.raw[l] = (float*)c.take(n * 4);
+        v.act[l] = (char*)c.take(n * v.esz);
+        v.dact[l] = (float*)c.take(n * 4);
+        v.draw[l] = (char*)c.take(n * v.esz);
+        v.mean[l] = (float*)c.take((size_t)v.L[l].Cout * 4);
+        v.invstd[l] = (float*)c.take((size_t)v.L[l].Cout * 4);
+    }
+    const size_t img = (size_t)B * 64 * 64 * v.ch;
+    v.xf = (float*)c.take(img * 4);
+    v.xt = (char*)c.take(img * v.esz);
+    v.zlat = (char*)c.take((size_t)B * v.z * v.esz);
+    v.stdq = (float*)c.take((size_t)B * v.z * 4);
+    v.dz = (float*)c.take((size_t)B * v.z * 4);
+    v.s1s2 = (float*)c.take(2 * 1024 * 4);
+    v.scratch_doubles = 2 * 1024 * 64 + 4096;
+    v.scratch = (double*)c.take(v.scratch_doubles * 8);
+    v.metrics2 = (double*)c.take(2 * 8);
+    *need = c.off + 256;
+}
+
+#define RC(x) do { int rc_ = (x); if (rc_ != FAVAE_OK) return rc_; } while (0)
+
+int conv_fwd(Vae& v, int l, const void* in, int B, void* st) {
+    const Layer& L = v.L[l];
+    const float* bias = v.P + L.b_off;
+    switch (L.kind) {
+    case CONV_S2:
+        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 2, 1, 0, 0, v.dtype, st);
+    case CONV_S1:
+        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 1, 1, 0, 0, v.dtype, st);
+    case CONVT_S2:
+        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 2, 1, 1, 0, v.dtype, st);
+    default:
+        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, 1, 1, L.Cin, 1, 1, L.Cout, 1, 1, 0, 0, 0, v.dtype, st);
+    }
+}
+
+int bn_fwd(Vae& v, int l, int B, bool train, void* st) {
+    const Layer& L = v.L[l];
+    const long long R = v.rows(l, B);
+    if (train)
+        RC(favae_bn_stats(v.raw[l], R, L.Cout, 1e-5f, 0.1f, v.mean[l], v.invstd[l], v.BUF + L.rm_off, v.BUF + L.rv_off, v.scratch, v.scratch_doubles, st));
+    else
+        RC(favae_bn_eval_prep(v.BUF + L.rm_off, v.BUF + L.rv_off, L.Cout, 1e-5f, v.mean[l], v.invstd[l], st));
+    return favae_bn_lrelu_fwd(v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.P + L.be_off, v.act[l], R, L.Cout, 1, v.dtype, st);
+}
+
+int encoder_fwd(Vae& v, int B, bool train, void* st) {
+    const void* in = v.xt;
+    for (int l = 0; l < 5; ++l) {
+        RC(conv_fwd(v, l, in, B, st));
+        RC(bn_fwd(v, l, B, train, st));
+        in = v.act[l];
+    }
+    return conv_fwd(v, L_FC, in, B, st);
+}
+
+int decoder_fwd(Vae& v, int B, bool train, void* st) {
+    RC(conv_fwd(v, L_DI, v.zlat, B, st));
+    RC(favae_cast(v.raw[L_DI], v.act[L_DI], (long long)B * 4096, v.dtype, st));
+    const void* in = v.act[L_DI];
+    for (int l = 7; l <= 11; ++l) {
+        RC(conv_fwd(v, l, in, B, st));
+        RC(bn_fwd(v, l, B, train, st));
+        in = v.act[l];
+    }
+    return conv_fwd(v, L_OUT, in, B, st);
+}
+
+int bn_bwd(Vae& v, int l, int B, void* st) {
+    const Layer& L = v.L[l];
+    return favae_bn_lrelu_bwd(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.draw[l], v.G + L.g_off,
+                              v.G + L.be_off, v.G + L.b_off, v.rows(l, B), L.Cout, v.scratch, v.scratch_doubles, v.s1s2, v.dtype, st);
+}
+
+// weight gradient of layer l given draw[l] and the layer input
+int wgrad(Vae& v, int l, const void* in, int B, void* st) {
+    const Layer& L = v.L[l];
+    float* dw = v.G + L.w_off;
+    switch (L.kind) {
+    case CONV_S2:
+        return favae_conv_wgrad(v.draw[l], L.Cout, 0, in, L.Cin, 1, dw, B, L.Hout, L.Hout, L.Hin, L.Hin, 3, 2, 1, 0, v.dtype, st);
+    case CONV_S1:
+        return favae_conv_wgrad(v.draw[l], L.Cout, 0, in, L.Cin, 1, dw, B, L.Hout, L.Hout, L.Hin, L.Hin, 3, 1, 1, 0, v.dtype, st);
+    case CONVT_S2:
+        return favae_conv_wgrad(v.draw[l], L.Cout, 1, in, L.Cin, 0, dw, B, L.Hin, L.Hin, L.Hout, L.Hout, 3, 2, 1, 0, v.dtype, st);
+    default:
+        return favae_conv_wgrad(v.draw[l], L.Cout, 0, in, L.Cin, 0, dw, B, 1, 1, 1, 1, 1, 1, 0, 0, v.dtype, st);
+    }
+}
+
+// input gradient of layer l: draw[l] -> out (fp32, shaped like the layer input)
+int dgrad(Vae& v, int l, float* out, int B, void* st) {
+    const Layer& L = v.L[l];
+    switch (L.kind) {
+    case CONV_S2:   // scatter form with [Cin][tap][Cout]
+        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, 2, 1, 1, 0, v.dtype, st);
+    case CONV_S1:
+        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, 1, 1, 1, 0, v.dtype, st);
+    case CONVT_S2:  // gather form
+        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, 2, 1, 0, 0, v.dtype, st);
+    default:
+        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, 1, 1, L.Cout, 1, 1, L.Cin, 1, 1, 0, 0, 0, v.dtype, st);
+    }
+}
+
+}  // namespace
+
+struct favae_vae { Vae v; };
+
+extern "C" long long favae_vae_param_count(int z, int channels) {
+    Layer L[NL]; long long a, b, c;
+    build_layers(z, channels, L, &a, &b, &c, true);
+    return a;
+}
+extern "C" long long favae_vae_buffer_count(int z, int channels) {
+    Layer L[NL]; long long a, b, c;
+    build_layers(z, channels, L, &a, &b, &c, true);
+    return b;
+}
+extern "C" long long favae_vae_shadow_bytes(int z, int channels, int dtype) {
+    Layer L[NL]; long long a, b, c;
+    build_layers(z, channels, L, &a, &b, &c, dtype == FAVAE_F32);
+    return c * (dtype == FAVAE_F32 ? 4 : 2) + 256;
+}
+extern "C" long long favae_vae_workspace_bytes(int z, int channels, int batch_max, int dtype) {
+    Vae v{};
+    v.z = z; v.ch = channels; v.Bmax = batch_max; v.dtype = dtype; v.esz = dtype == FAVAE_F32 ? 4 : 2;
+    build_layers(z, channels, v.L, &v.nparam, &v.nbuf, &v.nshadow, dtype == FAVAE_F32);
+    size_t need;
+    carve(v, nullptr, 0, &need);
+    return (long long)need;
+}
+extern "C" int favae_vae_num_layers(void) { return NL; }
+
+/* info[0..9] = kind, Cin, Cout, taps, has_bn, w_off, b_off, gamma_off, beta_off, run_mean_off, run_var_off (11 values) */
+extern "C" int favae_vae_layer_info(int z, int channels, int layer, long long* info) {
+    FAVAE_CHECK_ARG(layer >= 0 && layer < NL && info, "favae_vae_layer_info: bad layer");
+    Layer L[NL]; long long a, b, c;
+    build_layers(z, channels, L, &a, &b, &c, true);
+    const Layer& l = L[layer];
+    info[0] = l.kind; info[1] = l.Cin; info[2] = l.Cout; info[3] = l.taps; info[4] = l.bn;
+    info[5] = l.w_off; info[6] = l.b_off; info[7] = l.g_off; info[8] = l.be_off; info[9] = l.rm_off; info[10] = l.rv_off;
+    return FAVAE_OK;
+}
+
+extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_max, int dtype, float* params, float* grads,
+                                float* adam_m, float* adam_v, float* bn_buffers, void* shadow, size_t shadow_bytes,
+                                void* workspace, size_t workspace_bytes) {
+    FAVAE_CHECK_ARG(out && params && grads && adam_m && adam_v && bn_buffers && shadow && workspace, "favae_vae_create: null pointer");
+    FAVAE_CHECK_ARG(z > 0 && z % 2 == 0 && channels > 0 && channels <= 4 && batch_max > 0 && batch_max <= 4096, "favae_vae_create: bad shape (z even, channels<=4)");
+    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_vae_create: dtype");
+    FAVAE_CHECK_ARG(((uintptr_t)params % 256) == 0 && ((uintptr_t)shadow % 256) == 0 && ((uintptr_t)workspace % 256) == 0 &&
+                    ((uintptr_t)grads % 256) == 0, "favae_vae_create: buffers must be 256-byte aligned");
+    favae_vae* h = new (std::nothrow) favae_vae();
+    FAVAE_CHECK_ARG(h, "favae_vae_create: out of host memory");
+    Vae& v = h->v;
+    v.z = z; v.ch = channels; v.Bmax = batch_max; v.dtype = dtype; v.esz = dtype == FAVAE_F32 ? 4 : 2;
+    build_layers(z, channels, v.L, &v.nparam, &v.nbuf, &v.nshadow, dtype == FAVAE_F32);
+    v.P = params; v.G = grads; v.M = adam_m; v.V = adam_v; v.BUF = bn_buffers; v.SH = (char*)shadow;
+    size_t need;
+    carve(v, (char*)workspace, workspace_bytes, &need);
+    if (need > workspace_bytes || (size_t)v.nshadow * v.esz > shadow_bytes) {
+        delete h;
+        favae_set_error("favae_vae_create: workspace %zu < %zu or shadow %zu < %zu", workspace_bytes, need, shadow_bytes, (size_t)v.nshadow * v.esz);
+        return FAVAE_ERR_ARG;
+    }
+    *out = h;
+    return FAVAE_OK;
+}
+
+extern "C" int favae_vae_destroy(favae_vae* h) {
+    delete h;
+    return FAVAE_OK;
+}
+
+/* Rebuild the dtype copies / transposes of every weight from the fp32 master arena (after Adam or load_state_dict). */
+extern "C" int favae_vae_refresh_weights(favae_vae* h, void* st) {
+    FAVAE_CHECK_ARG(h, "favae_vae_refresh_weights: null handle");
+    Vae& v = h->v;
+    for (int l = 0; l < NL; ++l) {
+        const Layer& L = v.L[l];
+        void* wc = L.wc_off >= 0 ? v.SH + L.wc_off * v.esz : nullptr;
+        void* wt = L.wt_off >= 0 ? v.SH + L.wt_off * v.esz : nullptr;
+        if (wc || wt) RC(favae_weight_prep(v.P + L.w_off, wc, wt, L.Cout, L.taps, L.Cin, v.dtype, st));
+    }
+    return FAVAE_OK;
+}
+
+/* One forward + backward of the training step (cA/celeba_deepvanilla_vae.py:229-249): gradients land in the grads
+ * arena; metrics2_out (device, 2 doubles) receives (reconstruction_error, kl_div).  No optimiser step. */
+extern "C" int favae_vae_train_fwdbwd(favae_vae* h, const float* data_nhwc, const int* idx, int B, const float* eps,
+                                      const double* prior, float tau, float beta, float var_x, double* metrics2_out, void* st) {
+    FAVAE_CHECK_ARG(h && data_nhwc && eps && metrics2_out, "favae_vae_train_fwdbwd: null pointer");
+    Vae& v = h->v;
+    FAVAE_CHECK_ARG(B > 1 && B <= v.Bmax, "favae_vae_train_fwdbwd: batch %d outside (1, %d]", B, v.Bmax);
+    FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));
+    RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, v.xf, v.xt, v.dtype, st));
+    RC(encoder_fwd(v, B, true, st));
+    RC(favae_reparam_kl_fwd(v.raw[L_FC], eps, prior, idx, tau, B, v.z, v.zlat, v.stdq, metrics2_out + 1, v.dtype, st));
+    RC(decoder_fwd(v, B, true, st));
+    const long long D = (long long)64 * 64 * v.ch;
+    RC(favae_sigmoid_ll(v.raw[L_OUT], v.xf, B, D, var_x, v.draw[L_OUT], metrics2_out, v.scratch, v.scratch_doubles, v.dtype, st));
+    // ---- backward ----
+    RC(favae_colsum(v.draw[L_OUT], v.rows(L_OUT, B), v.ch, v.G + v.L[L_OUT].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
+    RC(wgrad(v, L_OUT, v.act[11], B, st));
+    RC(dgrad(v, L_OUT, v.dact[11], B, st));
+    for (int l = 11; l >= 7; --l) {
+        RC(bn_bwd(v, l, B, st));
+        RC(wgrad(v, l, v.act[l - 1], B, st));
+        RC(dgrad(v, l, v.dact[l - 1], B, st));
+    }
+    RC(favae_cast(v.dact[L_DI], v.draw[L_DI], (long long)B * 4096, v.dtype, st));
+    RC(favae_colsum(v.draw[L_DI], B, 4096, v.G + v.L[L_DI].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
+    RC(wgrad(v, L_DI, v.zlat, B, st));
+    RC(dgrad(v, L_DI, v.dz, B, st));
+    RC(favae_reparam_kl_bwd(v.raw[L_FC], eps, prior, idx, v.stdq, v.dz, tau, beta, B, v.z, v.draw[L_FC], v.dtype, st));
+    RC(favae_colsum(v.draw[L_FC], B, 2 * v.z, v.G + v.L[L_FC].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
+    RC(wgrad(v, L_FC, v.act[4], B, st));
+    RC(dgrad(v, L_FC, v.dact[4], B, st));
+    for (int l = 4; l >= 1; --l) {
+        RC(bn_bwd(v, l, B, st));
+        RC(wgrad(v, l, v.act[l - 1], B, st));
+        RC(dgrad(v, l, v.dact[l - 1], B, st));
+    }
+    RC(bn_bwd(v, 0, B, st));
+    RC(wgrad(v, 0, v.xt, B, st));
+    return FAVAE_OK;
+}
+
+/* Adam over the whole arena (optim.step(), :250) followed by the weight re-layout the next forward needs. */
+extern "C" int favae_vae_adam(favae_vae* h, float lr, float beta1, float beta2, float eps, long long step, void* st) {
+    FAVAE_CHECK_ARG(h, "favae_vae_adam: null handle");
+    Vae& v = h->v;
+    RC(favae_adam_step(v.P, v.G, v.M, v.V, v.nparam, lr, beta1, beta2, eps, step, st));
+    return favae_vae_refresh_weights(h, st);
+}
+
+/* A whole epoch of steps on one device: perm [n] sample order, eps [n][z] in visiting order, metrics [nsteps][2].
+ * Equivalent to the inner loop :227-255 with batch size `batch`; the last batch may be short. */
+extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const int* perm, long long n, int batch,
+                                     const float* eps, const double* prior, float tau, float beta, float var_x, float lr,
+                                     long long step0, double* metrics, void* st) {
+    FAVAE_CHECK_ARG(h && perm && metrics && n > 1 && batch > 1, "favae_vae_train_epoch: bad argument");
+    Vae& v = h->v;
+    long long s = 0;
+    for (long long o = 0; o < n; o += batch, ++s) {
+        const int B = (int)std::min<long long>(batch, n - o);
+        FAVAE_CHECK_ARG(B > 1, "favae_vae_train_epoch: a trailing batch of one sample has no batch statistics");
+        RC(favae_vae_train_fwdbwd(h, data_nhwc, perm + o, B, eps + o * v.z, prior, tau, beta, var_x, metrics + 2 * s, st));
+        RC(favae_vae_adam(h, lr, 0.9f, 0.999f, 1e-8f, step0 + s + 1, st));
+    }
+    return FAVAE_OK;
+}
+
+/* Eval-mode encoder over B samples (update_x, :331-358): X.mean / X.cov rows as float64. */
+extern "C" int favae_vae_encode(favae_vae* h, const float* data_nhwc, const int* idx, int B, double* xmean, double* xcov, void* st) {
+    FAVAE_CHECK_ARG(h && data_nhwc && xmean && xcov, "favae_vae_encode: null pointer");
+    Vae& v = h->v;
+    FAVAE_CHECK_ARG(B > 0 && B <= v.Bmax, "favae_vae_encode: batch");
+    RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, nullptr, v.xt, v.dtype, st));
+    RC(encoder_fwd(v, B, false, st));
+    return favae_encode_head(v.raw[L_FC], B, v.z, xmean, xcov, st);
+}
+
+/* Eval-mode decoder (reconstruction / decoder(), :94-99, 360-385): zin [B][z] fp32 -> out [B][64][64][ch] fp32 NHWC. */
+extern "C" int favae_vae_decode(favae_vae* h, const float* zin, int B, float* out_nhwc, void* st) {
+    FAVAE_CHECK_ARG(h && zin && out_nhwc, "favae_vae_decode: null pointer");
+    Vae& v = h->v;
+    FAVAE_CHECK_ARG(B > 0 && B <= v.Bmax, "favae_vae_decode: batch");
+    RC(favae_cast(zin, v.zlat, (long long)B * v.z, v.dtype, st));
+    RC(decoder_fwd(v, B, false, st));
+    return favae_sigmoid(v.raw[L_OUT], out_nhwc, (long long)B * 64 * 64 * v.ch, st);
+}
+
+/* Debug/parity access to the executor's internal buffers: which = 0 raw, 1 act, 2 dact, 3 draw. */
+extern "C" int favae_vae_debug_ptr(favae_vae* h, int which, int layer, void** out) {
+    FAVAE_CHECK_ARG(h && out && layer >= 0 && layer < NL, "favae_vae_debug_ptr: bad argument");
+    Vae& v = h->v;
+    *out = which == 0 ? (void*)v.raw[layer] : which == 1 ? (void*)v.act[layer] : which == 2 ? (void*)v.dact[layer] : (void*)v.draw[layer];
+    return FAVAE_OK;
+}

@@ -51,6 +51,90 @@ int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const void* cols,
                      int Nb, int Hs, int Ws, int Hl, int Wl, int ks, int stride, int pad, int splitk, int dtype,
                      void* stream);
 
+/* ---- conv VAE: HBM-bound kernels ----------------------------------------------------------------------------- */
+
+/* nn.BatchNorm2d training statistics over the rows of raw [R][C] (cA/celeba_deepvanilla_vae.py:34,58,72): batch mean
+ * and 1/sqrt(biased var + eps) -> mean, invstd; running stats updated with `momentum` (unbiased var) when non-NULL.
+ * scratch: fp64 partial sums, at least 2*1024*64 doubles. */
+int favae_bn_stats(const float* raw, long long R, int C, float eps, float momentum, float* mean, float* invstd,
+                   float* run_mean, float* run_var, double* scratch, size_t scratch_doubles, void* stream);
+/* eval mode (self.eval(), :343,368): mean/invstd from the running statistics. */
+int favae_bn_eval_prep(const float* run_mean, const float* run_var, int C, float eps, float* mean, float* invstd,
+                       void* stream);
+/* act = LeakyReLU_0.01((raw-mean)*invstd*gamma+beta) stored as dtype (:34-35); apply_act=0 skips the LeakyReLU. */
+int favae_bn_lrelu_fwd(const float* raw, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                       void* act, long long R, int C, int apply_act, int dtype, void* stream);
+/* backward of BN(train)+LeakyReLU (autograd of :34-35 under loss.backward() :249): draw (dtype) = d loss / d raw,
+ * dgamma, dbeta, and dbias = column sums of draw (gradient of the preceding conv bias; NULL to skip).
+ * s1s2: 2*C floats of scratch. */
+int favae_bn_lrelu_bwd(const float* dact, const void* act, const float* raw, const float* mean, const float* invstd,
+                       const float* gamma, void* draw, float* dgamma, float* dbeta, float* dbias, long long R, int C,
+                       double* scratch, size_t scratch_doubles, float* s1s2, int dtype, void* stream);
+/* out[c] = sum_r x[r][c]  (bias gradients of layers without BN). */
+int favae_colsum(const void* x, long long R, int C, float* out, double* scratch, size_t scratch_doubles, int dtype,
+                 void* stream);
+/* Fused reparameterisation + KL against the FA prior (:86-92 encoder head, :89-92 reparameterize, :137-150 kl_div,
+ * :231-232 prior std).  fc [B][2z] = (mu | log_var_raw); eps [B][z]; prior [N][z] fp64 rows selected by idx[b]
+ * (NULL prior = N(0,I), :213-214; NULL idx = identity); tau as the fp32 the reference casts it to (:210).
+ * Outputs zlat [B][z] (dtype), stdq [B][z], *kl_out = mean_b sum_z KL (fp64). */
+int favae_reparam_kl_fwd(const float* fc, const float* eps, const double* prior, const int* idx, float tau, int B, int z,
+                         void* zlat, float* stdq, double* kl_out, int dtype, void* stream);
+/* Gradient of (rec + beta*KL) w.r.t. fc given dz = d rec / d zlat; dfc [B][2z] (dtype). */
+int favae_reparam_kl_bwd(const float* fc, const float* eps, const double* prior, const int* idx, const float* stdq,
+                         const float* dz, float tau, float beta, int B, int z, void* dfc, int dtype, void* stream);
+/* update_x head (:348-354): X.mean = mu, X.cov = std^2 as float64 rows. */
+int favae_encode_head(const float* fc, int B, int z, double* xmean, double* xcov, void* stream);
+/* Sigmoid (:77) + -mean_b gaussian_LL (:152-171) + gradient w.r.t. the pre-sigmoid output (dtype).
+ * raw, x: [B][D] fp32; *rec_err (fp64) = reconstruction_error of :238. scratch >= 1024 doubles. */
+int favae_sigmoid_ll(const float* raw, const float* x, int B, long long D, float var_x, void* draw, double* rec_err,
+                     double* scratch, size_t scratch_doubles, int dtype, void* stream);
+int favae_sigmoid(const float* raw, float* out, long long n, void* stream);
+/* torch.optim.Adam step (defaults, no weight decay; :131,250) over a flat fp32 arena of n (multiple of 4) floats. */
+int favae_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                    float eps, long long step, void* stream);
+/* master fp32 [Co][taps][Ci] -> dtype copy (same layout, may be NULL) and dtype transpose [Ci][taps][Co] (may be NULL). */
+int favae_weight_prep(const float* w, void* w_copy, void* w_transposed, int Co, int taps, int Ci, int dtype, void* stream);
+/* rows idx[b] of the resident fp32 NHWC dataset -> fp32 batch and/or dtype batch (DataLoader batch, :227-229). */
+int favae_gather_batch(const float* data, const int* idx, int B, long long row_floats, float* x_f32, void* x_t, int dtype,
+                       void* stream);
+int favae_cast(const float* in, void* out, long long n, int dtype, void* stream);
+int favae_nchw_to_nhwc(const float* in, float* out, long long N, int C, int HW, int Cpad, void* stream);
+int favae_nhwc_to_nchw_f64(const float* in, double* out, long long N, int C, int HW, int Cpad, void* stream);
+
+/* ---- conv VAE executor (the training step of ImgVAE.trainloop, cA/celeba_deepvanilla_vae.py:227-250) ------------
+ * The network is the reference's fixed architecture (:25-78: 5 x [Conv3x3 s2 + BN + LeakyReLU], two Linear heads,
+ * Linear + 4 x [ConvT3x3 s2 + BN + LeakyReLU], ConvT + BN + LeakyReLU + Conv3x3 + Sigmoid) on 64x64 images.
+ * The caller owns every buffer (params/grads/Adam moments: favae_vae_param_count floats each; BN running stats:
+ * favae_vae_buffer_count floats; shadow + workspace: sizes from the *_bytes queries); all 256-byte aligned.
+ * Layer order: 0-4 enc.i, 5 (fc_mu|fc_var), 6 decoder_input, 7-10 dec.i, 11 final_layer.0/1, 12 final_layer.3. */
+typedef struct favae_vae favae_vae;
+long long favae_vae_param_count(int z, int channels);
+long long favae_vae_buffer_count(int z, int channels);
+long long favae_vae_shadow_bytes(int z, int channels, int dtype);
+long long favae_vae_workspace_bytes(int z, int channels, int batch_max, int dtype);
+int favae_vae_num_layers(void);
+/* info[11] = kind(0 conv s2,1 linear,2 convT s2,3 conv s1), Cin, Cout, taps, has_bn, w_off, b_off, gamma_off, beta_off,
+ * running_mean_off, running_var_off (offsets in floats; weights are [Cout][taps][Cin]). */
+int favae_vae_layer_info(int z, int channels, int layer, long long* info);
+int favae_vae_create(favae_vae** out, int z, int channels, int batch_max, int dtype, float* params, float* grads,
+                     float* adam_m, float* adam_v, float* bn_buffers, void* shadow, size_t shadow_bytes, void* workspace,
+                     size_t workspace_bytes);
+int favae_vae_destroy(favae_vae* h);
+int favae_vae_refresh_weights(favae_vae* h, void* stream);
+/* forward + loss + backward of one mini-batch (:229-249); metrics2_out (device) = (reconstruction_error, kl_div). */
+int favae_vae_train_fwdbwd(favae_vae* h, const float* data_nhwc, const int* idx, int B, const float* eps,
+                           const double* prior, float tau, float beta, float var_x, double* metrics2_out, void* stream);
+/* optim.step() (:250) + weight re-layout. */
+int favae_vae_adam(favae_vae* h, float lr, float beta1, float beta2, float eps, long long step, void* stream);
+/* all mini-batches of one epoch (:227-255) on one device. perm [n], eps [n][z] in visiting order, metrics [steps][2]. */
+int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const int* perm, long long n, int batch, const float* eps,
+                          const double* prior, float tau, float beta, float var_x, float lr, long long step0,
+                          double* metrics, void* stream);
+/* eval-mode encoder of update_x (:331-358) and eval-mode decoder of reconstruction/decoder (:94-99, 360-385). */
+int favae_vae_encode(favae_vae* h, const float* data_nhwc, const int* idx, int B, double* xmean, double* xcov, void* stream);
+int favae_vae_decode(favae_vae* h, const float* zin, int B, float* out_nhwc, void* stream);
+int favae_vae_debug_ptr(favae_vae* h, int which, int layer, void** out);
+
 #ifdef __cplusplus
 }
 #endif

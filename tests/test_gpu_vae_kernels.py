@@ -1,0 +1,149 @@
+"""GPU parity of the HBM-bound VAE kernels (BN+LeakyReLU fwd/bwd, reparam+KL fwd/bwd, sigmoid+LL, Adam, weight
+re-layout) against torch-CPU float64 autograd of the same expressions (the ops the reference calls:
+condition_a_VAE/celeba_deepvanilla_vae.py:34-35, 86-92, 137-171, 131/250).  fp32 storage, tolerance 1e-5 of scale."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+i_, ll_, f_, sz_ = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_size_t
+
+
+def _L():
+    from favae_hip import lib
+    return lib
+
+
+def _err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("R,C", [(4096, 64), (65536, 64), (16384, 128), (256, 1024), (1000, 512)])
+def test_bn_lrelu_forward_backward(R, C):
+    L = _L()
+    raw_ = L.raw()
+    g = torch.Generator().manual_seed(R + C)
+    x = (torch.randn(R, C, generator=g, dtype=torch.float64) * 2 + 0.5).float().double().requires_grad_(True)
+    gamma = (torch.rand(C, generator=g, dtype=torch.float64) + 0.5).float().double().requires_grad_(True)
+    beta = torch.randn(C, generator=g, dtype=torch.float64).float().double().requires_grad_(True)
+    rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    y = F.batch_norm(x.view(R, C, 1, 1), rm, rv, gamma, beta, True, 0.1, 1e-5)
+    a = F.leaky_relu(y, 0.01)
+    da = torch.randn(R, C, 1, 1, generator=g, dtype=torch.float64).float().double()
+    a.backward(da)
+    dev = "cuda"
+    xd = x.detach().float().to(dev)
+    mean, invstd = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    rmd, rvd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    scratch = torch.zeros(2 * 1024 * 64 + 4096, dtype=torch.float64, device=dev)
+    L.check(raw_.favae_bn_stats(L.ptr(xd), ll_(R), i_(C), f_(1e-5), f_(0.1), L.ptr(mean), L.ptr(invstd), L.ptr(rmd), L.ptr(rvd),
+                                L.ptr(scratch), sz_(scratch.numel()), L.stream_ptr()))
+    assert _err(rmd, rm) < 1e-5 and _err(rvd, rv) < 1e-5
+    act = torch.zeros(R, C, device=dev)
+    g32, b32 = gamma.detach().float().to(dev), beta.detach().float().to(dev)
+    L.check(raw_.favae_bn_lrelu_fwd(L.ptr(xd), L.ptr(mean), L.ptr(invstd), L.ptr(g32), L.ptr(b32), L.ptr(act), ll_(R), i_(C), i_(1),
+                                    i_(0), L.stream_ptr()))
+    assert _err(act, a.detach().view(R, C)) < 1e-5
+    dad = da.view(R, C).float().to(dev).contiguous()
+    draw, dg, db, dbias = (torch.zeros(R, C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev),
+                           torch.zeros(C, device=dev))
+    s1s2 = torch.zeros(2 * C, device=dev)
+    L.check(raw_.favae_bn_lrelu_bwd(L.ptr(dad), L.ptr(act), L.ptr(xd), L.ptr(mean), L.ptr(invstd), L.ptr(g32), L.ptr(draw), L.ptr(dg),
+                                    L.ptr(db), L.ptr(dbias), ll_(R), i_(C), L.ptr(scratch), sz_(scratch.numel()), L.ptr(s1s2), i_(0),
+                                    L.stream_ptr()))
+    assert _err(dg, gamma.grad) < 1e-5
+    assert _err(db, beta.grad) < 1e-5
+    assert _err(draw, x.grad) < 1e-5
+    assert dbias.abs().max().item() < 1e-3 * x.grad.abs().max().item() * np.sqrt(R)
+
+
+@pytest.mark.parametrize("with_prior", [True, False])
+def test_reparam_kl_forward_backward(with_prior):
+    L = _L()
+    raw_ = L.raw()
+    B, z, N = 64, 20, 300
+    g = torch.Generator().manual_seed(5)
+    fc = (torch.randn(B, 2 * z, generator=g) * 0.7).double().requires_grad_(True)
+    eps = torch.randn(B, z, generator=g)
+    prior = torch.randn(N, z, generator=g, dtype=torch.float64)
+    idx = torch.randint(0, N, (B,), generator=g, dtype=torch.int32)
+    tau, beta = 1.7, 0.5
+    mu, lv = fc[:, :z], fc[:, z:] + 1e-6
+    std = torch.exp(0.5 * lv)
+    zl = eps.double() * std + mu
+    mp = prior[idx.long()] if with_prior else torch.zeros(B, z, dtype=torch.float64)
+    sp = torch.sqrt(torch.ones_like(mp) * float(np.float32(1.0) / np.float32(tau)))
+    kl = torch.distributions.kl_divergence(torch.distributions.Normal(mu, std), torch.distributions.Normal(mp, sp)).sum(1).mean()
+    dz = torch.randn(B, z, generator=g)
+    (beta * kl + (zl * dz.double()).sum()).backward()
+    dev = "cuda"
+    fcd, epsd = fc.detach().float().to(dev), eps.to(dev)
+    pd, idd = (prior.to(dev), idx.to(dev)) if with_prior else (None, None)
+    zlat, stdq, klo = torch.zeros(B, z, device=dev), torch.zeros(B, z, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
+    L.check(raw_.favae_reparam_kl_fwd(L.ptr(fcd), L.ptr(epsd), L.ptr(pd), L.ptr(idd), f_(tau), i_(B), i_(z), L.ptr(zlat), L.ptr(stdq),
+                                      L.ptr(klo), i_(0), L.stream_ptr()))
+    assert abs(klo.item() - kl.item()) < 1e-6 * abs(kl.item())
+    assert _err(zlat, zl.detach()) < 1e-6 and _err(stdq, std.detach()) < 1e-6
+    dfc, dzd = torch.zeros(B, 2 * z, device=dev), dz.to(dev)
+    L.check(raw_.favae_reparam_kl_bwd(L.ptr(fcd), L.ptr(epsd), L.ptr(pd), L.ptr(idd), L.ptr(stdq), L.ptr(dzd), f_(tau), f_(beta),
+                                      i_(B), i_(z), L.ptr(dfc), i_(0), L.stream_ptr()))
+    assert _err(dfc, fc.grad) < 1e-5
+
+
+def test_sigmoid_ll_and_gradient():
+    L = _L()
+    raw_ = L.raw()
+    B, D = 16, 12288
+    g = torch.Generator().manual_seed(6)
+    r = torch.randn(B, D, generator=g).double().requires_grad_(True)
+    x = torch.rand(B, D, generator=g)
+    s = torch.sigmoid(r)
+    ll = (-0.5 * (D * np.log(2 * np.pi) + D * np.log(0.01) + ((x.double() - s) ** 2 / 0.01).sum(-1))).mean()
+    (-ll).backward()
+    dev = "cuda"
+    draw, rec = torch.zeros(B, D, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
+    scratch = torch.zeros(4096, dtype=torch.float64, device=dev)
+    rd, xd = r.detach().float().to(dev), x.to(dev)     # keep both alive: ptr() of a temporary would be recycled
+    L.check(raw_.favae_sigmoid_ll(L.ptr(rd), L.ptr(xd), i_(B), ll_(D), f_(0.01), L.ptr(draw), L.ptr(rec),
+                                  L.ptr(scratch), sz_(scratch.numel()), i_(0), L.stream_ptr()))
+    assert abs(rec.item() + ll.item()) < 1e-6 * abs(ll.item())
+    assert _err(draw, r.grad) < 1e-5
+
+
+def test_adam_matches_torch_optim():
+    L = _L()
+    raw_ = L.raw()
+    n = 4096 * 3
+    g = torch.Generator().manual_seed(8)
+    p = torch.randn(n, generator=g, requires_grad=True)
+    opt = torch.optim.Adam([p], 1e-3)
+    dev = "cuda"
+    pd, md, vd = p.detach().clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=g) * (10.0 ** (step - 3))
+        p.grad = gr.clone()
+        opt.step()
+        grd = gr.to(dev)
+        L.check(raw_.favae_adam_step(L.ptr(pd), L.ptr(grd), L.ptr(md), L.ptr(vd), ll_(n), f_(1e-3), f_(0.9), f_(0.999), f_(1e-8),
+                                     ll_(step), L.stream_ptr()))
+        assert (pd.cpu() - p.detach()).abs().max().item() < 2e-7
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Co,taps,Ci", [(128, 9, 64), (3, 9, 64), (40, 1, 4096), (4096, 1, 20), (64, 9, 3)])
+def test_weight_prep(dt, Co, taps, Ci):
+    L = _L()
+    raw_ = L.raw()
+    w = torch.randn(Co, taps, Ci, generator=torch.Generator().manual_seed(Co))
+    dev = "cuda"
+    wc, wt = torch.zeros(Co, taps, Ci, dtype=dt, device=dev), torch.zeros(Ci, taps, Co, dtype=dt, device=dev)
+    wd = w.to(dev)
+    L.check(raw_.favae_weight_prep(L.ptr(wd), L.ptr(wc), L.ptr(wt), i_(Co), i_(taps), i_(Ci), i_(0 if dt == torch.float32 else 1),
+                                   L.stream_ptr()))
+    assert torch.equal(wc.cpu(), w.to(dt))
+    assert torch.equal(wt.cpu(), w.to(dt).permute(2, 1, 0).contiguous())
