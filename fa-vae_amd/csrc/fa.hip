@@ -1,0 +1,577 @@
+// Factor-analysis (SSHIBA mean-field) kernels of FA-VAE on gfx950, all float64 like the reference's NumPy code.
+//
+//   fa_atb        C = A^T [B | 1]      tall-skinny sufficient statistics X^T Z, Z^T Z, X^T X, column sums
+//                                      (reference condition_a_VAE/favae.py:989,1070,1091,1135-1139,1213) on
+//                                      v_mfma_f64_16x16x4_f64, deterministic two-pass slab reduction
+//   fa_rows_gemm  out = alpha (X P + c) + beta base   row-parallel N x d x K products: the Z mean (:986-987, 996-997),
+//                                      the FA prior mean Z W^T + b (celeba_deepvanilla_vae.py:209) and Z W^T + b of
+//                                      the multilabel update (:1212)
+//   fa_mult       fused multilabel X / xi update with the bound terms (:1197-1229, 1649, 1678)
+//   chol_inv      K x K SPD inverse + log-determinant in LDS (myInverse :904-922, update_w :1062-1065)
+//   slogdet       K x K LU log-determinant (HGauss :1586-1604 on the de-pruned covariances)
+//   small algebra single-block GEMM and the tau / b updates from the reduced statistics (:1077-1139)
+#include <algorithm>
+#include "common.h"
+#include "favae_hip.h"
+
+namespace {
+
+__device__ __forceinline__ f64x4 mfma_f64(double a, double b, f64x4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// C[da][dbp] = A^T [B | 1]   (dbp = db + ones)
+// One wave per (row slab, tile group): TI x TJ tiles of 16x16 accumulate over the slab's rows, 4 rows per MFMA
+// (lane l supplies row l>>4, column l&15 of both operands straight from global memory: 128-B row segments).
+// Slabs are summed in slab order by atb_finish => bitwise reproducible.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int TI = 4, TJ = 4;
+
+__global__ __launch_bounds__(64) void atb_kernel(const double* __restrict__ A, int lda, int da, const double* __restrict__ B,
+                                                 int ldb, int db, int ones, long long N, int rps, int gj,
+                                                 double* __restrict__ partial) {
+    const int lane = threadIdx.x, lr = lane >> 4, lc = lane & 15;
+    const int dbp = db + ones;
+    const int i0 = (blockIdx.y / gj) * (TI * 16), j0 = (blockIdx.y % gj) * (TJ * 16);
+    const long long n0 = (long long)blockIdx.x * rps, n1 = min(N, n0 + (long long)rps);
+    f64x4 acc[TI][TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (long long n = n0; n < n1; n += 4) {
+        const long long r = n + lr;
+        const bool ok = r < n1;
+        double av[TI], bv[TJ];
+#pragma unroll
+        for (int a = 0; a < TI; ++a) {
+            const int i = i0 + a * 16 + lc;
+            av[a] = (ok && i < da) ? A[r * lda + i] : 0.0;
+        }
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) {
+            const int j = j0 + b * 16 + lc;
+            bv[b] = !ok ? 0.0 : (j < db ? B[r * ldb + j] : (j == db && ones ? 1.0 : 0.0));
+        }
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+            for (int b = 0; b < TJ; ++b) acc[a][b] = mfma_f64(av[a], bv[b], acc[a][b]);
+    }
+    // C/D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
+    double* out = partial + (size_t)blockIdx.x * da * dbp;
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = i0 + a * 16 + lr + 4 * g, j = j0 + b * 16 + lc;
+                if (i < da && j < dbp) out[(size_t)i * dbp + j] = acc[a][b][g];
+            }
+}
+
+__global__ void atb_finish(const double* __restrict__ partial, int nslab, int n, double* __restrict__ C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < nslab; ++k) s += partial[(size_t)k * n + i];
+    C[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// out[N][K] = alpha * (X[N][d] @ P[d][K] + c[K]) + beta * base[N][K]      (accumulate: out += alpha * X @ P)
+// one wave = 16 rows x all K columns; A operand lane (row l&15, k l>>4), B operand lane (k l>>4, col l&15).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int MAXTJ = 13;  // K <= 208
+
+template <int NT>
+__global__ __launch_bounds__(256) void rows_gemm_kernel(const double* __restrict__ X, int ldx, int d, const double* __restrict__ P,
+                                                        int ldp, int K, const double* __restrict__ c, double alpha,
+                                                        const double* __restrict__ base, int ldbase, double beta,
+                                                        double* __restrict__ out, int ldo, long long N, int accumulate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane >> 4, lc = lane & 15;
+    const long long n0 = ((long long)blockIdx.x * 4 + wave) * 16;
+    if (n0 >= N) return;
+    f64x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const long long ra = n0 + lc;
+    const bool oka = ra < N;
+    for (int k0 = 0; k0 < d; k0 += 4) {
+        const int k = k0 + lr;
+        const double a = (oka && k < d) ? X[ra * ldx + k] : 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = t * 16 + lc;
+            const double b = (k < d && j < K) ? P[(size_t)k * ldp + j] : 0.0;
+            acc[t] = mfma_f64(a, b, acc[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int j = t * 16 + lc;
+        if (j >= K) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const long long r = n0 + lr + 4 * g;
+            if (r >= N) continue;
+            double v = acc[t][g];
+            if (accumulate) {
+                out[r * ldo + j] += alpha * v;
+            } else {
+                if (c) v += c[j];
+                v *= alpha;
+                if (base) v += beta * base[r * ldbase + j];
+                out[r * ldo + j] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// multilabel view: X.cov, X.mean, xi and the bound pieces in one pass (cA/favae.py:1197-1229, 1649, 1678)
+//   lam(xi)  = exp(log(sig(xi) - 1/2) - log(2 xi)),  sig(x) = exp(-log(1 + exp(-x)))      (:924-949, as written)
+//   cov = 1/(tau + 2 lam(xi)); mean = (t - 1/2 + tau*zwb) * cov; xi' = sqrt(cov + mean^2)
+//   partial[0] += log cov ; partial[1] += log sig(xi') + mean*t - (mean + xi')/2
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double ref_sigmoid(double x) { return exp(-log(1.0 + exp(-x))); }
+
+__global__ __launch_bounds__(256) void mult_kernel(const double* __restrict__ t, const double* __restrict__ zwb, double* __restrict__ xi,
+                                                   double* __restrict__ mean, double* __restrict__ cov, double tau, size_t n,
+                                                   double* __restrict__ partial) {
+    __shared__ double sm[8];
+    double a0 = 0.0, a1 = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double x = xi[i];
+        const double lam = exp(log(ref_sigmoid(x) - 0.5) - log(2.0 * x));
+        const double cv = 1.0 / (tau + 2.0 * lam);
+        const double mn = (t[i] - 0.5 + tau * zwb[i]) * cv;
+        const double xn = sqrt(cv + mn * mn);
+        cov[i] = cv; mean[i] = mn; xi[i] = xn;
+        a0 += log(cv);
+        a1 += log(ref_sigmoid(xn)) + mn * t[i] - 0.5 * (mn + xn);
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1);
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = a0; sm[4 + (threadIdx.x >> 6)] = a1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+        partial[2 * blockIdx.x + 1] = sm[4] + sm[5] + sm[6] + sm[7];
+    }
+}
+
+__global__ void pair_finish(const double* partial, int n, double* out2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int i = 0; i < n; ++i) { s0 += partial[2 * i]; s1 += partial[2 * i + 1]; }
+        out2[0] = s0; out2[1] = s1;
+    }
+}
+
+// xi = sqrt(cov + mean^2)  (Qdistribution init, :1912-1914)
+__global__ void xi_init_kernel(const double* mean, const double* cov, double* xi, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) xi[i] = sqrt(cov[i] + mean[i] * mean[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SPD inverse through the Cholesky factor, one workgroup, matrix resident in LDS (K <= 128) or in a global workspace.
+//   A' = (s s^T) o A + diag_add I ;  out = out_scale (s s^T) o A'^-1 ;  info[0] = 0 ok / 1 not SPD ;
+//   logdet[0] = log det A' ; logdet[1] = log det out
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chol_inv_kernel(const double* __restrict__ A, int lda, int K, const double* __restrict__ s,
+                                                       double diag_add, double out_scale, double* __restrict__ out, int ldo,
+                                                       double* __restrict__ gwork, int use_lds, double* __restrict__ logdet,
+                                                       int* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];   // [2 flag words][K*K][K] (no static LDS in front)
+    int& bad = *(int*)smem;
+    double* W = use_lds ? smem + 2 : gwork;        // K x K, row-major, lower triangle used
+    double* col = use_lds ? smem + 2 + (size_t)K * K : gwork + (size_t)K * K;   // K
+    const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    for (int e = tid; e < K * K; e += 256) {
+        const int i = e / K, j = e - i * K;
+        const double si = s ? s[i] : 1.0, sj = s ? s[j] : 1.0;
+        W[e] = si * sj * A[(size_t)i * lda + j] + (i == j ? diag_add : 0.0);
+    }
+    __syncthreads();
+    // right-looking Cholesky, lower
+    for (int j = 0; j < K; ++j) {
+        const double piv = W[j * K + j];
+        if (!(piv > 0.0)) { if (tid == 0) bad = 1; }
+        __syncthreads();
+        if (bad) break;
+        const double dj = sqrt(piv);
+        for (int i = j + tid; i < K; i += 256) W[i * K + j] = (i == j) ? dj : W[i * K + j] / dj;
+        __syncthreads();
+        const int m = K - j - 1;
+        for (int e = tid; e < m * m; e += 256) {
+            const int i = j + 1 + e / m, k = j + 1 + e % m;
+            if (k <= i) W[i * K + k] -= W[i * K + j] * W[k * K + j];
+        }
+        __syncthreads();
+    }
+    if (bad) {
+        const double nan = __longlong_as_double(0x7ff8000000000000LL);
+        for (int e = tid; e < K * K; e += 256) out[(size_t)(e / K) * ldo + (e % K)] = nan;
+        if (tid == 0) { info[0] = 1; logdet[0] = nan; logdet[1] = nan; }
+        return;
+    }
+    if (tid == 0) {
+        double ld = 0.0, ls = 0.0;
+        for (int j = 0; j < K; ++j) { ld += log(W[j * K + j]); if (s) ls += log(s[j]); }
+        logdet[0] = 2.0 * ld;
+        logdet[1] = K * log(out_scale) + 2.0 * ls - 2.0 * ld;
+        info[0] = 0;
+    }
+    // in-place inverse of the lower-triangular factor, last column first
+    for (int j = K - 1; j >= 0; --j) {
+        const double ljj = W[j * K + j];
+        for (int i = j + 1 + tid; i < K; i += 256) col[i] = W[i * K + j];
+        __syncthreads();
+        for (int i = j + 1 + tid; i < K; i += 256) {
+            double acc = 0.0;
+            for (int k = j + 1; k <= i; ++k) acc += W[i * K + k] * col[k];   // rows of the already inverted trailing block
+            W[i * K + j] = -acc / ljj;
+        }
+        if (tid == 0) W[j * K + j] = 1.0 / ljj;
+        __syncthreads();
+    }
+    // out = out_scale * (s s^T) o (Linv^T Linv)
+    for (int e = tid; e < K * K; e += 256) {
+        const int i = e / K, j = e - i * K;
+        if (j > i) continue;
+        double acc = 0.0;
+        for (int k = i; k < K; ++k) acc += W[k * K + i] * W[k * K + j];
+        const double si = s ? s[i] : 1.0, sj = s ? s[j] : 1.0;
+        const double v = out_scale * si * sj * acc;
+        out[(size_t)i * ldo + j] = v;
+        out[(size_t)j * ldo + i] = v;
+    }
+}
+
+// LU with partial pivoting: sign and log|det| of a general K x K matrix (np.linalg.slogdet)
+__global__ __launch_bounds__(256) void slogdet_kernel(const double* __restrict__ A, int lda, int K, double* __restrict__ gwork,
+                                                      int use_lds, double* __restrict__ out2) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];   // [piv_row, sgn, lad, pad][K*K]
+    int& piv_row = *(int*)smem;
+    double& sgn = smem[1];
+    double& lad = smem[2];
+    double* W = use_lds ? smem + 4 : gwork;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < K * K; e += 256) W[e] = A[(size_t)(e / K) * lda + (e % K)];
+    if (tid == 0) { sgn = 1.0; lad = 0.0; }
+    __syncthreads();
+    for (int j = 0; j < K; ++j) {
+        if (tid == 0) {
+            int p = j; double best = fabs(W[j * K + j]);
+            for (int i = j + 1; i < K; ++i) { const double v = fabs(W[i * K + j]); if (v > best) { best = v; p = i; } }
+            piv_row = p;
+        }
+        __syncthreads();
+        const int p = piv_row;
+        if (p != j) {
+            for (int k = tid; k < K; k += 256) { const double tmp = W[j * K + k]; W[j * K + k] = W[p * K + k]; W[p * K + k] = tmp; }
+        }
+        __syncthreads();
+        const double pv = W[j * K + j];
+        if (tid == 0) {
+            if (p != j) sgn = -sgn;
+            if (pv < 0) sgn = -sgn;
+            if (pv == 0.0) sgn = 0.0;
+            lad += log(fabs(pv));
+        }
+        if (pv == 0.0) break;
+        const int m = K - j - 1;
+        for (int i = j + 1 + tid; i < K; i += 256) W[i * K + j] /= pv;
+        __syncthreads();
+        for (int e = tid; e < m * m; e += 256) {
+            const int i = j + 1 + e / m, k = j + 1 + e % m;
+            W[i * K + k] -= W[i * K + j] * W[j * K + k];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) { out2[0] = sgn; out2[1] = sgn == 0.0 ? -INFINITY : lad; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// small dense fp64 GEMM (operands up to a few hundred on a side): C = alpha op(A) op(B) + beta C
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void small_gemm_kernel(int ta, int tb, int M, int N, int Kd, double alpha, const double* __restrict__ A,
+                                                         int lda, const double* __restrict__ B, int ldb, double beta,
+                                                         double* __restrict__ C, int ldc) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < M * N; e += gridDim.x * 256) {
+        const int i = e / N, j = e - i * N;
+        double acc = 0.0;
+        for (int k = 0; k < Kd; ++k) {
+            const double a = ta ? A[(size_t)k * lda + i] : A[(size_t)i * lda + k];
+            const double b = tb ? B[(size_t)j * ldb + k] : B[(size_t)k * ldb + j];
+            acc += a * b;
+        }
+        C[(size_t)i * ldc + j] = alpha * acc + (beta != 0.0 ? beta * C[(size_t)i * ldc + j] : 0.0);
+    }
+}
+
+// W.mean = tau * (XtZ - b^T colsumZ) Sigma_W   and   W.prodT = W^T W + d Sigma_W         (cA/favae.py:1070-1072)
+// xtz1: [d][K+1] = X^T [Z | 1]; ztz1 row K.. provides colsumZ via zsum[K]
+__global__ __launch_bounds__(256) void w_update_kernel(const double* __restrict__ xtz1, const double* __restrict__ zsum,
+                                                       const double* __restrict__ b, const double* __restrict__ wcov, double tau, int d,
+                                                       int K, double* __restrict__ wmean, double* __restrict__ wprodT,
+                                                       double* __restrict__ tmp) {
+    // tmp[d][K] = XtZ - b^T colsumZ
+    for (int e = threadIdx.x; e < d * K; e += 256) {
+        const int i = e / K, k = e - i * K;
+        tmp[e] = xtz1[(size_t)i * (K + 1) + k] - b[i] * zsum[k];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < d * K; e += 256) {
+        const int i = e / K, k = e - i * K;
+        double acc = 0.0;
+        for (int l = 0; l < K; ++l) acc += tmp[(size_t)i * K + l] * wcov[(size_t)l * K + k];
+        wmean[e] = tau * acc;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * K; e += 256) {
+        const int k = e / K, l = e - k * K;
+        double acc = 0.0;
+        for (int i = 0; i < d; ++i) acc += wmean[(size_t)i * K + k] * wmean[(size_t)i * K + l];
+        wprodT[e] = acc + d * wcov[e];
+    }
+}
+
+// b update (cA/favae.py:1077-1092) and tau update (:1121-1139) from reduced statistics.
+//   stats: xsum[d] (1^T X), zsum[K] (1^T Z), xtz1 [d][K+1], trxx = tr<X^T X> (incl. sum cov), zprodT, wprodT, wmean
+// out: bmean[d], scal[0]=b_cov00, scal[1]=b_prodT ; tau: scal[2]=a, scal[3]=b
+__global__ __launch_bounds__(256) void b_update_kernel(const double* __restrict__ xsum, const double* __restrict__ zsum,
+                                                       const double* __restrict__ wmean, double tau, double N, int d, int K,
+                                                       double* __restrict__ bmean, double* __restrict__ scal) {
+    __shared__ double sm[4];
+    const double bc = 1.0 / (1.0 + N * tau);
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < d; i += 256) {
+        double zw = 0.0;
+        for (int k = 0; k < K; ++k) zw += zsum[k] * wmean[(size_t)i * K + k];
+        const double v = tau * (xsum[i] - zw) * bc;
+        bmean[i] = v;
+        acc += v * v;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { scal[0] = bc; scal[1] = sm[0] + sm[1] + sm[2] + sm[3] + d * bc; }
+}
+
+__global__ __launch_bounds__(256) void tau_update_kernel(const double* __restrict__ xsum, const double* __restrict__ zsum,
+                                                         const double* __restrict__ xtz1, double trxx, const double* __restrict__ zprodT,
+                                                         const double* __restrict__ wprodT, const double* __restrict__ wmean,
+                                                         const double* __restrict__ bmean, double bprodT, double a0, double b0, double N,
+                                                         int d, int K, double* __restrict__ scal) {
+    __shared__ double sm[4];
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < K * K; e += 256) acc += wprodT[e] * zprodT[(size_t)(e % K) * K + e / K];       // tr(WW ZZ)
+    for (int e = threadIdx.x; e < d * K; e += 256) {
+        const int i = e / K, k = e - i * K;
+        acc += -2.0 * wmean[e] * xtz1[(size_t)i * (K + 1) + k]          // -2 tr(W Z^T X)
+               + 2.0 * zsum[k] * wmean[e] * bmean[i];                  // +2 sum(Z W^T b^T)
+    }
+    for (int i = threadIdx.x; i < d; i += 256) acc += -2.0 * xsum[i] * bmean[i];                                 // -2 sum(X b^T)
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double s = trxx + sm[0] + sm[1] + sm[2] + sm[3] + N * bprodT;
+        scal[2] = (a0 + 0.5 * d * N) / (d * N);
+        scal[3] = (b0 + 0.5 * s) / (d * N);
+    }
+}
+
+// alpha.b[k] = (b0 + diag(W.prodT)[k] / 2) / d   (:1107-1112)
+__global__ void alpha_update_kernel(const double* __restrict__ wprodT, double b0, int d, int K, double* __restrict__ alpha_b) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) alpha_b[k] = (b0 + 0.5 * wprodT[(size_t)k * K + k]) / d;
+}
+
+// aux = I + sum_m coef[m] * WprodT_m   (update_Z :970-971, 976-980) -- up to 8 views
+struct ZAuxArgs { const double* wp[8]; double coef[8]; int m; };
+__global__ void z_aux_kernel(ZAuxArgs a, int K, double* __restrict__ aux) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < K * K; e += gridDim.x * 256) {
+        double v = (e / K == e % K) ? 1.0 : 0.0;
+        for (int m = 0; m < a.m; ++m) v += a.coef[m] * a.wp[m][e];
+        aux[e] = v;
+    }
+}
+
+// keep the columns sel[0..Kn) of a row-major [N][K] matrix (pruning, :507)
+__global__ void gather_cols_kernel(const double* __restrict__ in, int K, const int* __restrict__ sel, int Kn, double* __restrict__ out,
+                                   size_t N) {
+    const size_t total = N * Kn;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / Kn;
+        out[i] = in[r * K + sel[i - r * Kn]];
+    }
+}
+
+inline int ew_grid(size_t n) { return (int)std::min<size_t>(2048, std::max<size_t>(1, (n + 255) / 256)); }
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+static void atb_geom(long long N, int da, int dbp, int* nslab, int* rps, int* gi, int* gj) {
+    *gi = cdiv(cdiv(da, 16), TI);
+    *gj = cdiv(cdiv(dbp, 16), TJ);
+    const int groups = (*gi) * (*gj);
+    long long ns = std::max(1LL, std::min<long long>(cdivll(N, 64), std::max(1, 4096 / groups)));
+    long long r = cdivll(N, ns);
+    r = (r + 3) & ~3LL;
+    *rps = (int)r;
+    *nslab = (int)cdivll(N, r);
+}
+
+extern "C" long long favae_fa_atb_scratch_doubles(long long N, int da, int db, int ones) {
+    int nslab, rps, gi, gj;
+    atb_geom(N, da, db + (ones ? 1 : 0), &nslab, &rps, &gi, &gj);
+    return (long long)nslab * da * (db + (ones ? 1 : 0));
+}
+
+extern "C" int favae_fa_atb(const double* A, int lda, int da, const double* B, int ldb, int db, int ones, long long N, double* C,
+                            double* scratch, size_t scratch_doubles, void* stream) {
+    FAVAE_CHECK_ARG(A && C && scratch && N > 0 && da > 0 && db >= 0 && (B || db == 0) && (db > 0 || ones), "favae_fa_atb: bad argument");
+    const int dbp = db + (ones ? 1 : 0);
+    int nslab, rps, gi, gj;
+    atb_geom(N, da, dbp, &nslab, &rps, &gi, &gj);
+    FAVAE_CHECK_ARG((size_t)nslab * da * dbp <= scratch_doubles, "favae_fa_atb: scratch too small (%zu < %zu)", scratch_doubles,
+                    (size_t)nslab * da * dbp);
+    hipLaunchKernelGGL(atb_kernel, dim3(nslab, gi * gj), dim3(64), 0, ST, A, lda, da, B ? B : A, ldb, db, ones ? 1 : 0, N, rps, gj, scratch);
+    FAVAE_LAUNCH_CHECK();
+    const int n = da * dbp;
+    hipLaunchKernelGGL(atb_finish, dim3(cdiv(n, 256)), dim3(256), 0, ST, scratch, nslab, n, C);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_fa_rows_gemm(const double* X, int ldx, int d, const double* P, int ldp, int K, const double* c, double alpha,
+                                  const double* base, int ldbase, double beta, double* out, int ldo, long long N, int accumulate,
+                                  void* stream) {
+    FAVAE_CHECK_ARG(X && P && out && N > 0 && d > 0 && K > 0, "favae_fa_rows_gemm: bad argument");
+    FAVAE_CHECK_ARG(K <= 16 * MAXTJ, "favae_fa_rows_gemm: K = %d exceeds %d", K, 16 * MAXTJ);
+    const int nt = cdiv(K, 16);
+    dim3 grid((unsigned)cdivll(N, 64)), block(256);
+#define RG_CASE(n) case n: hipLaunchKernelGGL(rows_gemm_kernel<n>, grid, block, 0, ST, X, ldx, d, P, ldp, K, c, alpha, base, ldbase, beta, out, ldo, N, accumulate); break;
+    switch (nt) {
+        RG_CASE(1) RG_CASE(2) RG_CASE(3) RG_CASE(4) RG_CASE(5) RG_CASE(6) RG_CASE(7) RG_CASE(8) RG_CASE(9) RG_CASE(10) RG_CASE(11) RG_CASE(12) RG_CASE(13)
+    }
+#undef RG_CASE
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_fa_mult_update(const double* t, const double* zwb, double* xi, double* mean, double* cov, double tau, long long n,
+                                    double* out2, double* scratch, size_t scratch_doubles, void* stream) {
+    FAVAE_CHECK_ARG(t && zwb && xi && mean && cov && out2 && scratch && n > 0, "favae_fa_mult_update: bad argument");
+    const int grid = ew_grid((size_t)n);
+    FAVAE_CHECK_ARG((size_t)2 * grid <= scratch_doubles, "favae_fa_mult_update: scratch too small");
+    hipLaunchKernelGGL(mult_kernel, dim3(grid), dim3(256), 0, ST, t, zwb, xi, mean, cov, tau, (size_t)n, scratch);
+    FAVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pair_finish, dim3(1), dim3(64), 0, ST, scratch, grid, out2);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_fa_xi_init(const double* mean, const double* cov, double* xi, long long n, void* stream) {
+    FAVAE_CHECK_ARG(mean && cov && xi && n > 0, "favae_fa_xi_init: bad argument");
+    hipLaunchKernelGGL(xi_init_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, ST, mean, cov, xi, (size_t)n);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+/* Synchronous: returns FAVAE_NOT_SPD (and fills out with NaN) when a pivot is not positive. */
+extern "C" int favae_chol_inv(const double* A, int lda, int K, const double* s, double diag_add, double out_scale, double* out,
+                              int ldo, double* work, double* logdet2, int* info_dev, void* stream) {
+    FAVAE_CHECK_ARG(A && out && work && logdet2 && info_dev && K > 0 && K <= 1024, "favae_chol_inv: bad argument");
+    const size_t full = ((size_t)K * K + K + 2) * sizeof(double);
+    const int use_lds = full <= 150 * 1024;
+    const size_t lds_bytes = use_lds ? full : 16;
+    if (lds_bytes > 64 * 1024)
+        FAVAE_HIP(hipFuncSetAttribute((const void*)chol_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), lds_bytes, ST, A, lda, K, s, diag_add, out_scale, out, ldo, work,
+                       use_lds, logdet2, info_dev);
+    FAVAE_LAUNCH_CHECK();
+    int info = 0;
+    FAVAE_HIP(hipMemcpyAsync(&info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ST));
+    FAVAE_HIP(hipStreamSynchronize(ST));
+    return info ? FAVAE_NOT_SPD : FAVAE_OK;
+}
+
+extern "C" int favae_slogdet(const double* A, int lda, int K, double* work, double* out2, void* stream) {
+    FAVAE_CHECK_ARG(A && work && out2 && K > 0 && K <= 1024, "favae_slogdet: bad argument");
+    const size_t full = ((size_t)K * K + 4) * sizeof(double);
+    const int use_lds = full <= 150 * 1024;
+    const size_t lds_bytes = use_lds ? full : 32;
+    if (lds_bytes > 64 * 1024)
+        FAVAE_HIP(hipFuncSetAttribute((const void*)slogdet_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(slogdet_kernel, dim3(1), dim3(256), lds_bytes, ST, A, lda, K, work, use_lds, out2);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_small_gemm(int transA, int transB, int M, int N, int Kd, double alpha, const double* A, int lda, const double* B,
+                                int ldb, double beta, double* C, int ldc, void* stream) {
+    FAVAE_CHECK_ARG(A && B && C && M > 0 && N > 0 && Kd > 0, "favae_small_gemm: bad argument");
+    hipLaunchKernelGGL(small_gemm_kernel, dim3(std::min(256, cdiv(M * N, 256))), dim3(256), 0, ST, transA, transB, M, N, Kd, alpha, A, lda, B,
+                       ldb, beta, C, ldc);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_fa_w_update(const double* xtz1, const double* zsum, const double* b, const double* wcov, double tau, int d, int K,
+                                 double* wmean, double* wprodT, double* tmp, void* stream) {
+    FAVAE_CHECK_ARG(xtz1 && zsum && b && wcov && wmean && wprodT && tmp && d > 0 && K > 0, "favae_fa_w_update: bad argument");
+    hipLaunchKernelGGL(w_update_kernel, dim3(1), dim3(256), 0, ST, xtz1, zsum, b, wcov, tau, d, K, wmean, wprodT, tmp);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_fa_b_update(const double* xsum, const double* zsum, const double* wmean, double tau, double N, int d, int K,
+                                 double* bmean, double* scal, void* stream) {
+    FAVAE_CHECK_ARG(xsum && zsum && wmean && bmean && scal && d > 0 && K > 0, "favae_fa_b_update: bad argument");
+    hipLaunchKernelGGL(b_update_kernel, dim3(1), dim3(256), 0, ST, xsum, zsum, wmean, tau, N, d, K, bmean, scal);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_fa_tau_update(const double* xsum, const double* zsum, const double* xtz1, double trxx, const double* zprodT,
+                                   const double* wprodT, const double* wmean, const double* bmean, double bprodT, double a0, double b0,
+                                   double N, int d, int K, double* scal, void* stream) {
+    FAVAE_CHECK_ARG(xsum && zsum && xtz1 && zprodT && wprodT && wmean && bmean && scal && d > 0 && K > 0, "favae_fa_tau_update: bad argument");
+    hipLaunchKernelGGL(tau_update_kernel, dim3(1), dim3(256), 0, ST, xsum, zsum, xtz1, trxx, zprodT, wprodT, wmean, bmean, bprodT, a0, b0, N,
+                       d, K, scal);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_fa_alpha_update(const double* wprodT, double b0, int d, int K, double* alpha_b, void* stream) {
+    FAVAE_CHECK_ARG(wprodT && alpha_b && d > 0 && K > 0, "favae_fa_alpha_update: bad argument");
+    hipLaunchKernelGGL(alpha_update_kernel, dim3(cdiv(K, 64)), dim3(64), 0, ST, wprodT, b0, d, K, alpha_b);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_fa_z_aux(const double* const* wprodT, const double* coef, int m, int K, double* aux, void* stream) {
+    FAVAE_CHECK_ARG(wprodT && coef && aux && m >= 0 && m <= 8 && K > 0, "favae_fa_z_aux: bad argument (at most 8 views)");
+    ZAuxArgs a;
+    a.m = m;
+    for (int i = 0; i < m; ++i) { a.wp[i] = wprodT[i]; a.coef[i] = coef[i]; }
+    hipLaunchKernelGGL(z_aux_kernel, dim3(std::min(64, cdiv(K * K, 256))), dim3(256), 0, ST, a, K, aux);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_gather_cols(const double* in, int K, const int* sel, int Kn, double* out, long long N, void* stream) {
+    FAVAE_CHECK_ARG(in && sel && out && K > 0 && Kn > 0 && Kn <= K && N > 0, "favae_gather_cols: bad argument");
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(ew_grid((size_t)N * Kn)), dim3(256), 0, ST, in, K, sel, Kn, out, (size_t)N);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}

@@ -1,0 +1,136 @@
+"""ctypes wrappers of the float64 factor-analysis kernels (csrc/fa.hip).  Tensors are device buffers only."""
+import ctypes
+
+import torch
+
+from . import lib as L
+
+_raw = L.raw()
+_raw.favae_fa_atb_scratch_doubles.restype = ctypes.c_longlong
+_i, _ll, _d, _sz = ctypes.c_int, ctypes.c_longlong, ctypes.c_double, ctypes.c_size_t
+F64 = torch.float64
+
+
+class Scratch:
+    """Grow-only fp64 scratch shared by the reductions of one device."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.buf = torch.empty(1 << 16, dtype=F64, device=dev)
+        self.work = torch.empty(1 << 16, dtype=F64, device=dev)
+        self.info = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.pair = torch.zeros(4, dtype=F64, device=dev)
+
+    def need(self, n):
+        if self.buf.numel() < n:
+            self.buf = torch.empty(int(n * 1.25), dtype=F64, device=self.dev)
+        return self.buf
+
+    def need_work(self, n):
+        if self.work.numel() < n:
+            self.work = torch.empty(int(n * 1.25), dtype=F64, device=self.dev)
+        return self.work
+
+
+def atb(A, B, ones, sc, out=None):
+    """C[da][db+ones] = A^T [B | 1]; A [N, da], B [N, db] or None."""
+    N, da = A.shape
+    db = 0 if B is None else B.shape[1]
+    dbp = db + (1 if ones else 0)
+    C = out if out is not None else torch.empty(da, dbp, dtype=F64, device=A.device)
+    n = _raw.favae_fa_atb_scratch_doubles(_ll(N), _i(da), _i(db), _i(1 if ones else 0))
+    s = sc.need(n)
+    L.check(_raw.favae_fa_atb(L.ptr(A), _i(A.stride(0)), _i(da), L.ptr(B), _i(0 if B is None else B.stride(0)), _i(db),
+                              _i(1 if ones else 0), _ll(N), L.ptr(C), L.ptr(s), _sz(s.numel()), L.stream_ptr()))
+    return C
+
+
+def rows_gemm(X, P, c, alpha, base, beta, out, accumulate=False):
+    """out = alpha (X P + c) + beta base  (accumulate: out += alpha X P)."""
+    N, d = X.shape
+    K = P.shape[1]
+    L.check(_raw.favae_fa_rows_gemm(L.ptr(X), _i(X.stride(0)), _i(d), L.ptr(P), _i(P.stride(0)), _i(K), L.ptr(c), _d(alpha),
+                                    L.ptr(base), _i(0 if base is None else base.stride(0)), _d(beta), L.ptr(out),
+                                    _i(out.stride(0)), _ll(N), _i(1 if accumulate else 0), L.stream_ptr()))
+    return out
+
+
+def mult_update(t, zwb, xi, mean, cov, tau, sc):
+    s = sc.need(4096)
+    L.check(_raw.favae_fa_mult_update(L.ptr(t), L.ptr(zwb), L.ptr(xi), L.ptr(mean), L.ptr(cov), _d(tau), _ll(t.numel()),
+                                      L.ptr(sc.pair), L.ptr(s), _sz(s.numel()), L.stream_ptr()))
+    return sc.pair[:2].cpu().numpy().copy()     # (sum log cov, bound term)
+
+
+def xi_init(mean, cov, xi):
+    L.check(_raw.favae_fa_xi_init(L.ptr(mean), L.ptr(cov), L.ptr(xi), _ll(mean.numel()), L.stream_ptr()))
+
+
+def chol_inv(A, sc, s=None, diag_add=0.0, out_scale=1.0):
+    """(inverse [K,K] device tensor, logdet_factored, logdet_out, ok)."""
+    K = A.shape[0]
+    out = torch.empty(K, K, dtype=F64, device=A.device)
+    w = sc.need_work(2 * K * K + K)
+    rc = L.check(_raw.favae_chol_inv(L.ptr(A), _i(A.stride(0)), _i(K), L.ptr(s), _d(diag_add), _d(out_scale), L.ptr(out),
+                                     _i(K), L.ptr(w), L.ptr(sc.pair), L.ptr(sc.info), L.stream_ptr()), allow_flags=True)
+    ld = sc.pair[:2].cpu().numpy()
+    return out, float(ld[0]), float(ld[1]), rc == 0
+
+
+def slogdet(A, sc):
+    K = A.shape[0]
+    w = sc.need_work(K * K)
+    L.check(_raw.favae_slogdet(L.ptr(A), _i(A.stride(0)), _i(K), L.ptr(w), L.ptr(sc.pair), L.stream_ptr()))
+    r = sc.pair[:2].cpu().numpy()
+    return float(r[0]), float(r[1])
+
+
+def small_gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None):
+    M = A.shape[1] if transA else A.shape[0]
+    Kd = A.shape[0] if transA else A.shape[1]
+    N = B.shape[0] if transB else B.shape[1]
+    C = out if out is not None else torch.empty(M, N, dtype=F64, device=A.device)
+    L.check(_raw.favae_small_gemm(_i(int(transA)), _i(int(transB)), _i(M), _i(N), _i(Kd), _d(alpha), L.ptr(A), _i(A.stride(0)),
+                                  L.ptr(B), _i(B.stride(0)), _d(beta), L.ptr(C), _i(C.stride(0)), L.stream_ptr()))
+    return C
+
+
+def w_update(xtz1, zsum, b, wcov, tau, wmean, wprodT, sc):
+    d, K1 = xtz1.shape
+    K = K1 - 1
+    tmp = sc.need_work(d * K)
+    L.check(_raw.favae_fa_w_update(L.ptr(xtz1), L.ptr(zsum), L.ptr(b), L.ptr(wcov), _d(tau), _i(d), _i(K), L.ptr(wmean),
+                                   L.ptr(wprodT), L.ptr(tmp), L.stream_ptr()))
+
+
+def b_update(xsum, zsum, wmean, tau, N, bmean, scal):
+    d, K = wmean.shape
+    L.check(_raw.favae_fa_b_update(L.ptr(xsum), L.ptr(zsum), L.ptr(wmean), _d(tau), _d(float(N)), _i(d), _i(K), L.ptr(bmean),
+                                   L.ptr(scal), L.stream_ptr()))
+
+
+def tau_update(xsum, zsum, xtz1, trxx, zprodT, wprodT, wmean, bmean, bprodT, a0, b0, N, scal):
+    d, K = wmean.shape
+    L.check(_raw.favae_fa_tau_update(L.ptr(xsum), L.ptr(zsum), L.ptr(xtz1), _d(trxx), L.ptr(zprodT), L.ptr(wprodT), L.ptr(wmean),
+                                     L.ptr(bmean), _d(bprodT), _d(a0), _d(b0), _d(float(N)), _i(d), _i(K), L.ptr(scal),
+                                     L.stream_ptr()))
+
+
+def alpha_update(wprodT, b0, d, alpha_b):
+    K = wprodT.shape[0]
+    L.check(_raw.favae_fa_alpha_update(L.ptr(wprodT), _d(b0), _i(d), _i(K), L.ptr(alpha_b), L.stream_ptr()))
+
+
+def z_aux(wprodTs, coefs, K, dev):
+    m = len(wprodTs)
+    aux = torch.empty(K, K, dtype=F64, device=dev)
+    ptrs = (ctypes.c_void_p * max(m, 1))(*[w.data_ptr() for w in wprodTs])
+    cf = (ctypes.c_double * max(m, 1))(*[float(c) for c in coefs])
+    L.check(_raw.favae_fa_z_aux(ptrs, cf, _i(m), _i(K), L.ptr(aux), L.stream_ptr()))
+    return aux
+
+
+def gather_cols(src, sel_dev, out):
+    N, K = src.shape
+    L.check(_raw.favae_gather_cols(L.ptr(src), _i(K), L.ptr(sel_dev), _i(sel_dev.numel()), L.ptr(out), _ll(N), L.stream_ptr()))
+    return out

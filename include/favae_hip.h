@@ -135,6 +135,53 @@ int favae_vae_encode(favae_vae* h, const float* data_nhwc, const int* idx, int B
 int favae_vae_decode(favae_vae* h, const float* zin, int B, float* out_nhwc, void* stream);
 int favae_vae_debug_ptr(favae_vae* h, int which, int layer, void** out);
 
+/* ---- factor-analysis half (SSHIBA mean-field updates, float64) -------------------------------------------------- */
+
+/* C[da][db+ones] = A^T [B | 1] over N rows: the sufficient statistics X^T Z, Z^T Z, X^T X and the column sums
+ * (cA/favae.py:989 Z^T Z, :1070 (X-b)^T Z, :1091 column sums, :1135-1139 traces, :1213 X^T X).  fp64 MFMA, slabs
+ * summed in a fixed order.  scratch >= favae_fa_atb_scratch_doubles(...). db may be 0 with ones=1 (column sums). */
+long long favae_fa_atb_scratch_doubles(long long N, int da, int db, int ones);
+int favae_fa_atb(const double* A, int lda, int da, const double* B, int ldb, int db, int ones, long long N, double* C,
+                 double* scratch, size_t scratch_doubles, void* stream);
+/* out[N][K] = alpha (X[N][d] P[d][K] + c[K]) + beta base[N][K]; accumulate=1: out += alpha X P.  K <= 208.
+ * q.Z['mean'] (cA/favae.py:986-987), the predictive means (:996-997), the FA prior Z W^T + b
+ * (cA/celeba_deepvanilla_vae.py:209) and Z W^T + b of the multilabel update (cA/favae.py:1212). */
+int favae_fa_rows_gemm(const double* X, int ldx, int d, const double* P, int ldp, int K, const double* c, double alpha,
+                       const double* base, int ldbase, double beta, double* out, int ldo, long long N, int accumulate,
+                       void* stream);
+/* Multilabel view, update_x + update_xi fused (cA/favae.py:1197-1229) with the entropy / bound sums (:1649, :1678):
+ * out2[0] = sum log cov, out2[1] = sum log sig(xi) + mean*t - (mean+xi)/2.  n = N*d elements. scratch >= 4096 doubles. */
+int favae_fa_mult_update(const double* t, const double* zwb, double* xi, double* mean, double* cov, double tau, long long n,
+                         double* out2, double* scratch, size_t scratch_doubles, void* stream);
+int favae_fa_xi_init(const double* mean, const double* cov, double* xi, long long n, void* stream);
+/* out = out_scale (s s^T) o ((s s^T) o A + diag_add I)^-1 through the Cholesky factor, one workgroup, LDS-resident for
+ * K <= ~135 (myInverse cA/favae.py:904-922; update_w :1062-1065 with s = alpha^-1/2, diag_add = 1/tau, out_scale = 1/tau).
+ * s may be NULL. work: 2*K*K doubles. logdet2[0] = log det of the factored matrix, logdet2[1] = log det out.
+ * SYNCHRONOUS; returns FAVAE_NOT_SPD and fills out with NaN when a pivot is not positive (the reference's NaN path). */
+int favae_chol_inv(const double* A, int lda, int K, const double* s, double diag_add, double out_scale, double* out,
+                   int ldo, double* work, double* logdet2, int* info_dev, void* stream);
+/* out2 = (sign, log|det|) of a general K x K matrix (np.linalg.slogdet in HGauss, cA/favae.py:1603). work: K*K doubles. */
+int favae_slogdet(const double* A, int lda, int K, double* work, double* out2, void* stream);
+/* C[M][N] = alpha op(A) op(B) + beta C for the small (d x K, K x K) products of update_w / update_Z / predict. */
+int favae_small_gemm(int transA, int transB, int M, int N, int Kd, double alpha, const double* A, int lda, const double* B,
+                     int ldb, double beta, double* C, int ldc, void* stream);
+/* W.mean = tau (X^T Z - b^T 1^T Z) Sigma_W, W.prodT = W^T W + d Sigma_W (cA/favae.py:1070-1072). xtz1 = X^T [Z|1]. */
+int favae_fa_w_update(const double* xtz1, const double* zsum, const double* b, const double* wcov, double tau, int d, int K,
+                      double* wmean, double* wprodT, double* tmp, void* stream);
+/* b update (cA/favae.py:1090-1092): bmean[d]; scal[0] = Sigma_b[0,0], scal[1] = <b b^T>. */
+int favae_fa_b_update(const double* xsum, const double* zsum, const double* wmean, double tau, double N, int d, int K,
+                      double* bmean, double* scal, void* stream);
+/* tau update (cA/favae.py:1134-1139) from reduced statistics: scal[2] = a, scal[3] = b. trxx = tr<X^T X> incl. sum cov. */
+int favae_fa_tau_update(const double* xsum, const double* zsum, const double* xtz1, double trxx, const double* zprodT,
+                        const double* wprodT, const double* wmean, const double* bmean, double bprodT, double a0, double b0,
+                        double N, int d, int K, double* scal, void* stream);
+/* alpha.b = (b0 + diag(W.prodT)/2)/d (cA/favae.py:1107-1112). */
+int favae_fa_alpha_update(const double* wprodT, double b0, int d, int K, double* alpha_b, void* stream);
+/* aux = I + sum_m coef[m] WprodT_m (cA/favae.py:970-971, 976-980). wprodT: HOST array of m device pointers, m <= 8. */
+int favae_fa_z_aux(const double* const* wprodT, const double* coef, int m, int K, double* aux, void* stream);
+/* out[N][Kn] = in[N][K][:, sel] (pruning of q.Z['mean'], cA/favae.py:507). */
+int favae_gather_cols(const double* in, int K, const int* sel, int Kn, double* out, long long N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
