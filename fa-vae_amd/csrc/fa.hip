@@ -73,11 +73,13 @@ __global__ __launch_bounds__(64) void atb_kernel(const double* __restrict__ A, i
 }
 
 __global__ void atb_finish(const double* __restrict__ partial, int nslab, int n, double* __restrict__ C) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5), part = threadIdx.x & 31;   // 8 outputs x 32 slab-parts
     double s = 0.0;
-    for (int k = 0; k < nslab; ++k) s += partial[(size_t)k * n + i];
-    C[i] = s;
+    if (i < n)
+        for (int k = part; k < nslab; k += 32) s += partial[(size_t)k * n + i];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (i < n && part == 0) C[i] = s;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -163,11 +165,10 @@ __global__ __launch_bounds__(256) void mult_kernel(const double* __restrict__ t,
 }
 
 __global__ void pair_finish(const double* partial, int n, double* out2) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int i = 0; i < n; ++i) { s0 += partial[2 * i]; s1 += partial[2 * i + 1]; }
-        out2[0] = s0; out2[1] = s1;
-    }
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) { s0 += partial[2 * i]; s1 += partial[2 * i + 1]; }
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out2[0] = s0; out2[1] = s1; }
 }
 
 // xi = sqrt(cov + mean^2)  (Qdistribution init, :1912-1914)
@@ -447,7 +448,7 @@ extern "C" int favae_fa_atb(const double* A, int lda, int da, const double* B, i
     hipLaunchKernelGGL(atb_kernel, dim3(nslab, gi * gj), dim3(64), 0, ST, A, lda, da, B ? B : A, ldb, db, ones ? 1 : 0, N, rps, gj, scratch);
     FAVAE_LAUNCH_CHECK();
     const int n = da * dbp;
-    hipLaunchKernelGGL(atb_finish, dim3(cdiv(n, 256)), dim3(256), 0, ST, scratch, nslab, n, C);
+    hipLaunchKernelGGL(atb_finish, dim3(cdiv(n, 8)), dim3(256), 0, ST, scratch, nslab, n, C);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

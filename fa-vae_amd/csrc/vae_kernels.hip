@@ -63,11 +63,21 @@ int run_colreduce(long long R, int C, double* partial, size_t partial_cap, RedGe
     return FAVAE_OK;
 }
 
+// finish kernels: 256 threads = 8 channels x 32 slab-parts; every part sums a strided subset of the slabs, the 32
+// parts are combined by a fixed xor tree (deterministic).  FIN_GRID(C) blocks.
+#define FIN_GRID(C) dim3(cdiv((C), 8))
+#define FIN_BLOCK dim3(256)
 __device__ __forceinline__ double slab_sum(const double* partial, int nslab, int nv, int v, int C, int c) {
+    const int part = threadIdx.x & 31;
     double s = 0.0;
-    for (int i = 0; i < nslab; ++i) s += partial[((size_t)i * nv + v) * C + c];
+    if (c < C)
+        for (int i = part; i < nslab; i += 32) s += partial[((size_t)i * nv + v) * C + c];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     return s;
 }
+#define FIN_CHANNEL() (blockIdx.x * 8 + (threadIdx.x >> 5))
+#define FIN_LEADER() ((threadIdx.x & 31) == 0)
 
 // ---- BatchNorm2d (train) statistics: nn.BatchNorm2d(h_dim), celeba_deepvanilla_vae.py:34,58,72 -------------
 struct StatsF {
@@ -80,9 +90,9 @@ struct StatsF {
 
 __global__ void bn_stats_finish(const double* partial, int nslab, int C, double R, float eps, float mom, float* mean,
                                 float* invstd, float* run_mean, float* run_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = FIN_CHANNEL();
     const double s = slab_sum(partial, nslab, 2, 0, C, c), s2 = slab_sum(partial, nslab, 2, 1, C, c);
+    if (c >= C || !FIN_LEADER()) return;
     const double m = s / R;
     double var = s2 / R - m * m;
     if (var < 0) var = 0;
@@ -156,9 +166,9 @@ struct BnBwdRedF {
 };
 
 __global__ void bn_bwd_finish(const double* partial, int nslab, int C, float* dgamma, float* dbeta, float* s1s2) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = FIN_CHANNEL();
     const double s1 = slab_sum(partial, nslab, 2, 0, C, c), s2 = slab_sum(partial, nslab, 2, 1, C, c);
+    if (c >= C || !FIN_LEADER()) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
     s1s2[c] = (float)s1;
@@ -187,8 +197,9 @@ struct ColsumF {
 };
 
 __global__ void colsum_finish(const double* partial, int nslab, int C, float* out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) out[c] = (float)slab_sum(partial, nslab, 1, 0, C, c);
+    const int c = FIN_CHANNEL();
+    const double v = slab_sum(partial, nslab, 1, 0, C, c);
+    if (c < C && FIN_LEADER()) out[c] = (float)v;
 }
 
 // ---- reparameterise + KL(q || N(mu_P, 1/tau)) : celeba_deepvanilla_vae.py:86-92,137-150,231-232 --------------
@@ -275,9 +286,10 @@ __global__ __launch_bounds__(256) void sigmoid_ll(const float* __restrict__ raw,
 }
 
 __global__ void ll_finish(const double* partial, int n, double D, double var_x, double B, double* rec_err) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+    s = wave_sum(s);
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += partial[i];
         // -mean_b LL_b ,  LL_b = -0.5 (D ln 2pi + D ln var + SSE_b / var)
         *rec_err = 0.5 * (D * log(2.0 * M_PI) + D * log(var_x)) + 0.5 * s / (var_x * B);
     }
@@ -380,7 +392,7 @@ extern "C" int favae_bn_stats(const float* raw, long long R, int C, float eps, f
     RedGeom g;
     int rc = run_colreduce<2>(R, C, scratch, scratch_doubles, g, StatsF{raw, C}, ST);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_stats_finish, dim3(cdiv(C, 64)), dim3(64), 0, ST, scratch, g.nslab, C, (double)R, eps, momentum, mean,
+    hipLaunchKernelGGL(bn_stats_finish, FIN_GRID(C), FIN_BLOCK, 0, ST, scratch, g.nslab, C, (double)R, eps, momentum, mean,
                        invstd, run_mean, run_var);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
@@ -413,13 +425,13 @@ static int bn_bwd_impl(const float* dact, const T* act, const float* raw, const 
     RedGeom g;
     int rc = run_colreduce<2>(R, C, scratch, cap, g, BnBwdRedF<T>{dact, act, raw, mean, invstd, C}, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finish, dim3(cdiv(C, 64)), dim3(64), 0, st, scratch, g.nslab, C, dgamma, dbeta, s1s2);
+    hipLaunchKernelGGL(bn_bwd_finish, FIN_GRID(C), FIN_BLOCK, 0, st, scratch, g.nslab, C, dgamma, dbeta, s1s2);
     FAVAE_LAUNCH_CHECK();
     rc = run_colreduce<1>(R, C, scratch, cap, g,
                           BnBwdApplyF<T>{dact, act, raw, mean, invstd, gamma, s1s2, draw, C, (float)(1.0 / (double)R)}, st);
     if (rc) return rc;
     if (dbias) {
-        hipLaunchKernelGGL(colsum_finish, dim3(cdiv(C, 64)), dim3(64), 0, st, scratch, g.nslab, C, dbias);
+        hipLaunchKernelGGL(colsum_finish, FIN_GRID(C), FIN_BLOCK, 0, st, scratch, g.nslab, C, dbias);
         FAVAE_LAUNCH_CHECK();
     }
     return FAVAE_OK;
@@ -444,7 +456,7 @@ extern "C" int favae_colsum(const void* x, long long R, int C, float* out, doubl
     int rc = dtype == FAVAE_F32 ? run_colreduce<1>(R, C, scratch, scratch_doubles, g, ColsumF<float>{(const float*)x, C}, ST)
                                 : run_colreduce<1>(R, C, scratch, scratch_doubles, g, ColsumF<bf16_t>{(const bf16_t*)x, C}, ST);
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_finish, dim3(cdiv(C, 64)), dim3(64), 0, ST, scratch, g.nslab, C, out);
+    hipLaunchKernelGGL(colsum_finish, FIN_GRID(C), FIN_BLOCK, 0, ST, scratch, g.nslab, C, out);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

@@ -1,0 +1,32 @@
+"""Time / profile the HIP conv-VAE training epoch on synthetic data (developer tool)."""
+import sys, time
+sys.path.insert(0, '/root/repo/fa-vae_amd')
+import numpy as np, torch
+from favae_hip.engine import VaeEngine
+dtype = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+z = 20
+eng = VaeEngine(z, 3, dtype=dtype)
+torch.manual_seed(0)
+sys.path.insert(0, '/root/repo')
+from oracle import vae_torch as vt
+P, Bf = vt.init_state(z, 3)
+sd = {k: v.detach() for k, v in P.items()}; sd.update(Bf)
+eng.load_state_dict(sd)
+rs = np.random.RandomState(1)
+img = rs.rand(N, 3, 64, 64).astype(np.float32)
+data = eng.upload_images(img)
+perm = torch.randperm(N).to(torch.int32).cuda()
+eps = torch.randn(N, z).cuda()
+prior = torch.randn(N, z, dtype=torch.float64).cuda()
+nsteps = (N + 63) // 64
+metrics = torch.zeros(nsteps, 2, dtype=torch.float64, device='cuda')
+eng.train_epoch(data, perm, eps, prior, 1.5, 1.0, 0.01, 1e-3, 64, metrics)
+torch.cuda.synchronize()
+for r in range(reps):
+    t = time.time()
+    eng.train_epoch(data, perm, eps, prior, 1.5, 1.0, 0.01, 1e-3, 64, metrics)
+    torch.cuda.synchronize()
+    dt = time.time() - t
+    print('%s epoch N=%d: %.3f s  %.3f ms/step  %.0f samples/s  loss %.1f' % (dtype, N, dt, 1e3 * dt / nsteps, N / dt, metrics[-1, 0].item()))
