@@ -414,6 +414,11 @@ __global__ void gather_cols_kernel(const double* __restrict__ in, int K, const i
     }
 }
 
+// out = a x + b y  (small K x K / d x K combinations such as Z.prodT = Z^T Z + N Sigma_Z, :989)
+__global__ void axpby_kernel(size_t n, double a, const double* __restrict__ x, double b, const double* __restrict__ y, double* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = a * x[i] + (y ? b * y[i] : 0.0);
+}
+
 inline int ew_grid(size_t n) { return (int)std::min<size_t>(2048, std::max<size_t>(1, (n + 255) / 256)); }
 
 }  // namespace
@@ -573,6 +578,13 @@ extern "C" int favae_fa_z_aux(const double* const* wprodT, const double* coef, i
 extern "C" int favae_gather_cols(const double* in, int K, const int* sel, int Kn, double* out, long long N, void* stream) {
     FAVAE_CHECK_ARG(in && sel && out && K > 0 && Kn > 0 && Kn <= K && N > 0, "favae_gather_cols: bad argument");
     hipLaunchKernelGGL(gather_cols_kernel, dim3(ew_grid((size_t)N * Kn)), dim3(256), 0, ST, in, K, sel, Kn, out, (size_t)N);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_axpby(long long n, double a, const double* x, double b, const double* y, double* out, void* stream) {
+    FAVAE_CHECK_ARG(n > 0 && x && out, "favae_axpby: bad argument");
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, ST, (size_t)n, a, x, b, y, out);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

@@ -295,6 +295,31 @@ __global__ void ll_finish(const double* partial, int n, double D, double var_x, 
     }
 }
 
+// sigmoid(raw) vs y: per-block partial (sum (y-s)^2, sum y, sum y^2), then one block adds them onto acc3
+__global__ __launch_bounds__(256) void sigmoid_sse(const float* __restrict__ raw, const float* __restrict__ y, size_t n,
+                                                   double* __restrict__ partial) {
+    __shared__ double sm[12];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float s = 1.f / (1.f + expf(-raw[i]));
+        const double t = y[i], d = t - (double)s;
+        a0 += d * d; a1 += t; a2 += t * t;
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[w] = a0; sm[4 + w] = a1; sm[8 + w] = a2; }
+    __syncthreads();
+    if (threadIdx.x < 3) partial[3 * blockIdx.x + threadIdx.x] = sm[4 * threadIdx.x] + sm[4 * threadIdx.x + 1] + sm[4 * threadIdx.x + 2] + sm[4 * threadIdx.x + 3];
+}
+__global__ void sse_finish(const double* partial, int n, double* acc3) {
+    for (int v = 0; v < 3; ++v) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n; i += 64) s += partial[3 * i + v];
+        s = wave_sum(s);
+        if (threadIdx.x == 0) acc3[v] += s;
+    }
+}
+
 __global__ void sigmoid_only(const float* __restrict__ raw, float* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         out[i] = 1.f / (1.f + expf(-raw[i]));
@@ -504,6 +529,18 @@ extern "C" int favae_sigmoid_ll(const float* raw, const float* x, int B, long lo
         hipLaunchKernelGGL(sigmoid_ll<bf16_t>, dim3(grid), dim3(256), 0, ST, raw, x, n, ivb, (bf16_t*)draw, scratch);
     FAVAE_LAUNCH_CHECK();
     hipLaunchKernelGGL(ll_finish, dim3(1), dim3(64), 0, ST, scratch, grid, (double)D, (double)var_x, (double)B, rec_err);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_sigmoid_sse(const float* raw, const float* y, long long n, double* acc3, double* scratch,
+                                 size_t scratch_doubles, void* stream) {
+    FAVAE_CHECK_ARG(raw && y && acc3 && scratch && n > 0, "favae_sigmoid_sse: bad argument");
+    const int grid = (int)std::min<size_t>(1024, ((size_t)n + 255) / 256);
+    FAVAE_CHECK_ARG((size_t)3 * grid <= scratch_doubles, "favae_sigmoid_sse: scratch too small");
+    hipLaunchKernelGGL(sigmoid_sse, dim3(grid), dim3(256), 0, ST, raw, y, (size_t)n, scratch);
+    FAVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sse_finish, dim3(1), dim3(64), 0, ST, scratch, grid, acc3);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

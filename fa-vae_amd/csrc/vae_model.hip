@@ -292,7 +292,7 @@ extern "C" int favae_vae_train_fwdbwd(favae_vae* h, const float* data_nhwc, cons
                                       const double* prior, float tau, float beta, float var_x, double* metrics2_out, void* st) {
     FAVAE_CHECK_ARG(h && data_nhwc && eps && metrics2_out, "favae_vae_train_fwdbwd: null pointer");
     Vae& v = h->v;
-    FAVAE_CHECK_ARG(B > 1 && B <= v.Bmax, "favae_vae_train_fwdbwd: batch %d outside (1, %d]", B, v.Bmax);
+    FAVAE_CHECK_ARG(B >= 1 && B <= v.Bmax, "favae_vae_train_fwdbwd: batch %d outside [1, %d]", B, v.Bmax);
     FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));
     RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, v.xf, v.xt, v.dtype, st));
     RC(encoder_fwd(v, B, true, st));
@@ -340,36 +340,67 @@ extern "C" int favae_vae_adam(favae_vae* h, float lr, float beta1, float beta2, 
 extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const int* perm, long long n, int batch,
                                      const float* eps, const double* prior, float tau, float beta, float var_x, float lr,
                                      long long step0, double* metrics, void* st) {
-    FAVAE_CHECK_ARG(h && perm && metrics && n > 1 && batch > 1, "favae_vae_train_epoch: bad argument");
+    FAVAE_CHECK_ARG(h && perm && metrics && n >= 1 && batch >= 1, "favae_vae_train_epoch: bad argument");
     Vae& v = h->v;
     long long s = 0;
     for (long long o = 0; o < n; o += batch, ++s) {
         const int B = (int)std::min<long long>(batch, n - o);
-        FAVAE_CHECK_ARG(B > 1, "favae_vae_train_epoch: a trailing batch of one sample has no batch statistics");
         RC(favae_vae_train_fwdbwd(h, data_nhwc, perm + o, B, eps + o * v.z, prior, tau, beta, var_x, metrics + 2 * s, st));
         RC(favae_vae_adam(h, lr, 0.9f, 0.999f, 1e-8f, step0 + s + 1, st));
     }
     return FAVAE_OK;
 }
 
-/* Eval-mode encoder over B samples (update_x, :331-358): X.mean / X.cov rows as float64. */
-extern "C" int favae_vae_encode(favae_vae* h, const float* data_nhwc, const int* idx, int B, double* xmean, double* xcov, void* st) {
+/* Encoder over B samples (update_x, :331-358 when train=0; the encoder half of forward() when train=1):
+ * X.mean / X.cov rows as float64. */
+extern "C" int favae_vae_encode(favae_vae* h, const float* data_nhwc, const int* idx, int B, double* xmean, double* xcov,
+                                int train, void* st) {
     FAVAE_CHECK_ARG(h && data_nhwc && xmean && xcov, "favae_vae_encode: null pointer");
     Vae& v = h->v;
     FAVAE_CHECK_ARG(B > 0 && B <= v.Bmax, "favae_vae_encode: batch");
     RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, nullptr, v.xt, v.dtype, st));
-    RC(encoder_fwd(v, B, false, st));
+    RC(encoder_fwd(v, B, train != 0, st));
     return favae_encode_head(v.raw[L_FC], B, v.z, xmean, xcov, st);
 }
 
-/* Eval-mode decoder (reconstruction / decoder(), :94-99, 360-385): zin [B][z] fp32 -> out [B][64][64][ch] fp32 NHWC. */
-extern "C" int favae_vae_decode(favae_vae* h, const float* zin, int B, float* out_nhwc, void* st) {
+/* update_x over a whole resident data set in batches of `batch` (:346-355). */
+extern "C" int favae_vae_encode_all(favae_vae* h, const float* data_nhwc, long long n, int batch, double* xmean, double* xcov,
+                                    void* st) {
+    FAVAE_CHECK_ARG(h && n > 0 && batch > 0, "favae_vae_encode_all: bad argument");
+    Vae& v = h->v;
+    const long long row = (long long)64 * 64 * v.ch;
+    for (long long o = 0; o < n; o += batch) {
+        const int B = (int)std::min<long long>(batch, n - o);
+        RC(favae_vae_encode(h, data_nhwc + o * row, nullptr, B, xmean + o * v.z, xcov + o * v.z, 0, st));
+    }
+    return FAVAE_OK;
+}
+
+/* Decoder (reconstruction / decoder(), :94-99, 360-385): zin [B][z] fp32 -> out [B][64][64][ch] fp32 NHWC. */
+extern "C" int favae_vae_decode(favae_vae* h, const float* zin, int B, float* out_nhwc, int train, void* st) {
     FAVAE_CHECK_ARG(h && zin && out_nhwc, "favae_vae_decode: null pointer");
     Vae& v = h->v;
     FAVAE_CHECK_ARG(B > 0 && B <= v.Bmax, "favae_vae_decode: batch");
     RC(favae_cast(zin, v.zlat, (long long)B * v.z, v.dtype, st));
-    RC(decoder_fwd(v, B, false, st));
+    RC(decoder_fwd(v, B, train != 0, st));
     return favae_sigmoid(v.raw[L_OUT], out_nhwc, (long long)B * 64 * 64 * v.ch, st);
+}
+
+/* Eval decoder over n latent rows + the sums r2_score needs against the resident data (SSHIBA.update diagnostic,
+ * cA/favae.py:839-840): acc3 += (sum (y-yhat)^2, sum y, sum y^2); nothing leaves the device. */
+extern "C" int favae_vae_reconstruct_stats(favae_vae* h, const float* zin, const float* data_nhwc, long long n, int batch,
+                                           double* acc3, void* st) {
+    FAVAE_CHECK_ARG(h && zin && data_nhwc && acc3 && n > 0 && batch > 0, "favae_vae_reconstruct_stats: bad argument");
+    Vae& v = h->v;
+    const long long row = (long long)64 * 64 * v.ch;
+    FAVAE_HIP(hipMemsetAsync(acc3, 0, 3 * sizeof(double), (hipStream_t)st));
+    for (long long o = 0; o < n; o += batch) {
+        const int B = (int)std::min<long long>(batch, n - o);
+        RC(favae_cast(zin + o * v.z, v.zlat, (long long)B * v.z, v.dtype, st));
+        RC(decoder_fwd(v, B, false, st));
+        RC(favae_sigmoid_sse(v.raw[L_OUT], data_nhwc + o * row, (long long)B * row, acc3, v.scratch, v.scratch_doubles, st));
+    }
+    return FAVAE_OK;
 }
 
 /* Debug/parity access to the executor's internal buffers: which = 0 raw, 1 act, 2 dact, 3 draw. */

@@ -210,11 +210,23 @@ class VaeEngine:
 
     def encode(self, data, idx, B, xmean, xcov, train=False):
         L.check(_raw.favae_vae_encode(self.h, L.ptr(data), L.ptr(idx), _i(B), ctypes.c_void_p(xmean.data_ptr()),
-                                      ctypes.c_void_p(xcov.data_ptr()), L.stream_ptr()))
+                                      ctypes.c_void_p(xcov.data_ptr()), _i(int(train)), L.stream_ptr()))
 
-    def decode(self, zin, B, out):
+    def encode_all(self, data, xmean, xcov, batch=64):
+        L.check(_raw.favae_vae_encode_all(self.h, L.ptr(data), _ll(data.shape[0]), _i(batch), L.ptr(xmean), L.ptr(xcov),
+                                          L.stream_ptr()))
+
+    def decode(self, zin, B, out, train=False):
         L.check(_raw.favae_vae_decode(self.h, ctypes.c_void_p(zin.data_ptr()), _i(B), ctypes.c_void_p(out.data_ptr()),
-                                      L.stream_ptr()))
+                                      _i(int(train)), L.stream_ptr()))
+
+    def reconstruct_stats(self, zin, data, acc3, batch=64):
+        L.check(_raw.favae_vae_reconstruct_stats(self.h, L.ptr(zin), L.ptr(data), _ll(zin.shape[0]), _i(batch), L.ptr(acc3),
+                                                 L.stream_ptr()))
+
+    def nhwc_to_nchw_f64(self, x_nhwc, out):
+        n, hh, ww, c = x_nhwc.shape
+        L.check(_raw.favae_nhwc_to_nchw_f64(L.ptr(x_nhwc), L.ptr(out), _ll(n), _i(c), _i(hh * ww), _i(c), L.stream_ptr()))
 
     def debug(self, which, layer, shape, dtype):
         p = ctypes.c_void_p()

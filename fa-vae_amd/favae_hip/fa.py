@@ -134,3 +134,9 @@ def gather_cols(src, sel_dev, out):
     N, K = src.shape
     L.check(_raw.favae_gather_cols(L.ptr(src), _i(K), L.ptr(sel_dev), _i(sel_dev.numel()), L.ptr(out), _ll(N), L.stream_ptr()))
     return out
+
+
+def axpby(a, x, b, y, out=None):
+    out = torch.empty_like(x) if out is None else out
+    L.check(_raw.favae_axpby(_ll(x.numel()), _d(a), L.ptr(x), _d(b), L.ptr(y), L.ptr(out), L.stream_ptr()))
+    return out

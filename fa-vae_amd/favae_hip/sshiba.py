@@ -1,0 +1,603 @@
+"""Host-side mirror of the reference coordinator `favae.SSHIBA` with the factor-analysis state resident on the GPU.
+
+Same constructor / struct_data / fit / fit_iterate / update / update_bound / pruning / predict surface and the same
+public attributes (q_dist.{Z,W,b,alpha,tau}, X, t, L, img_vae, total_elbo, recon_loss, kl_q_p, wandb_metrics) as
+condition_a_VAE/favae.py (variant 'A'), domain_adaptation/favae.py ('B') and transfer_learning/favae.py ('C').
+The coordinator decides *what* runs in which order (reference :743-902) and keeps O(K)-sized bookkeeping; every
+N-sized expression and every K x K factorisation runs in libfavae_hip.so (csrc/fa.hip).  No CPU fallback.
+
+Per-sample arrays (X.mean, X.cov, Z.mean, xi, t) live on the device; the dict entries the result scripts index are
+materialised as float64 NumPy arrays on access.
+"""
+import copy
+import math
+import sys
+
+import numpy as np
+import torch
+
+from . import fa
+from . import lib as L
+
+EPS = sys.float_info.epsilon
+F64 = torch.float64
+
+
+class LazyDict(dict):
+    """dict whose large entries live on the device; host NumPy copies are made on first access after a change."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._dev = {}
+
+    def set_dev(self, key, tensor):
+        self._dev[key] = tensor
+        dict.__setitem__(self, key, None)
+
+    def dev(self, key, device=None):
+        if key not in self._dev:
+            self._dev[key] = torch.from_numpy(np.ascontiguousarray(dict.__getitem__(self, key), dtype=np.float64)).to(device)
+        return self._dev[key]
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        if v is None and key in self._dev:
+            v = self._dev[key].cpu().numpy()
+            dict.__setitem__(self, key, v)
+        return v
+
+    def __setitem__(self, key, value):
+        self._dev.pop(key, None)
+        dict.__setitem__(self, key, value)
+
+    def __getstate__(self):
+        out = {}
+        for k in self.keys():
+            v = self[k]
+            out[k] = [v[i] for i in range(len(v))] if isinstance(v, _PredList) else v
+        return out
+
+    def __setstate__(self, st):
+        self._dev = {}
+        self.update(st)
+
+    def __reduce__(self):
+        return (LazyDict, (), self.__getstate__())
+
+
+class HyperParameters(object):
+    """reference :1856-1881"""
+
+    def __init__(self, m):
+        self.alpha_a, self.alpha_b = [1e-14] * m, [1e-14] * m
+        self.tau_a, self.tau_b = [1e-14] * m, [1e-14] * m
+        self.gamma_a, self.gamma_b = [2] * m, [1] * m
+        self.xi = []
+
+
+class Qdistribution(object):
+    """reference :1883-2063 (non-sparse, no semi-supervision): containers + the two mean helpers."""
+
+    def __init__(self, X, n, n_max, d, Kc, m, hyper):
+        self.n, self.n_max, self.d, self.Kc, self.m, self.X = n, n_max, d, Kc, m, X
+        self.alpha = [dict(a=hyper.alpha_a[i], b=hyper.alpha_b[i] * np.ones(Kc), LH=None, ElogpWalp=None) for i in range(m)]
+        self.tau = [dict(a=hyper.tau_a[i], b=hyper.tau_b[i] * np.ones(1), LH=None, ElogpXtau=None) for i in range(m)]
+        self.gamma = [dict(a=hyper.gamma_a[i], b=hyper.gamma_b[i] * np.ones(d[i]), LH=None) for i in range(m)]
+        blank = lambda: dict(mean=None, cov=None, prodT=None, LH=0, Elogp=0)
+        self.W = [blank() for _ in range(m)]
+        self.b = [blank() for _ in range(m)]
+        self.XS, self.tS = [blank() for _ in range(m)], [blank() for _ in range(m)]
+        self.Z = LazyDict(blank())
+        self.xi = [None] * m
+
+    def alpha_mean(self, m):
+        return self.alpha[m]["a"] / self.alpha[m]["b"]
+
+    def tau_mean(self, m):
+        return self.tau[m]["a"] / self.tau[m]["b"]
+
+    def gamma_mean(self, m):
+        return self.gamma[m]["a"] / self.gamma[m]["b"]
+
+
+class SSHIBA(object):
+    VARIANT = "A"          # set by the thin favae.py modules
+    img_vae_module = None  # the plugin module (`import celeba_deepvanilla_vae as img_vae`, reference :20)
+
+    def __init__(self, Kc=2, prune=0, fs=0, SS_sep=0, hyper=None, X_init=None, b_init=None, Z_init=None, W_init=[None],
+                 alpha_init=None, tau_init=None, gamma_init=None, area_mask=None, latentspace_lr=1):
+        self.Kc, self.prune, self.fs, self.SS_sep = int(Kc), int(prune), int(fs), SS_sep
+        self.hyper, self.X_init, self.b_init, self.Z_init, self.W_init = hyper, X_init, b_init, Z_init, W_init
+        self.alpha_init, self.tau_init, self.gamma_init = alpha_init, tau_init, gamma_init
+        self.latentspace_lr = latentspace_lr
+        for name, v in (("fs", fs), ("X_init", X_init), ("b_init", b_init), ("Z_init", Z_init), ("alpha_init", alpha_init),
+                        ("tau_init", tau_init), ("gamma_init", gamma_init)):
+            if v:
+                raise NotImplementedError("SSHIBA(%s=...) is outside the FA-VAE training hot path (SURVEY.md 2 row 13)" % name)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def struct_data(self, X, method, sparse=0, V=None, kernel=None, sig=0, sparse_fs=0, center=1, mask=None, deg=None,
+                    latent_dim=None, lr=None, epochs=None, dataset=None):
+        """reference :585-621"""
+        if V is not None:
+            kernel = "rbf" if kernel is None else kernel.lower()
+        return dict(data=X, sparse=sparse, sparse_fs=sparse_fs, method=method, mask=mask, SV=V, kernel=kernel, sig=sig,
+                    center=center, deg=deg, latent_dim=latent_dim, lr=lr, epochs=epochs, dataset=dataset)
+
+    # ---- device helpers ------------------------------------------------------------------------------------------
+    def _up(self, a):
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64))).to(self.dev)
+
+    def _tau(self, m):
+        return float(np.ravel(self.q_dist.tau_mean(m))[0])
+
+    def _refresh_xstats(self, m):
+        """X^T [X | 1] and sum_n cov -> X.prodT (:785/818/1213), 1^T X, tr<X^T X>."""
+        X = self.X[m]
+        Xd = X.dev("mean", self.dev)
+        d = self.d[m]
+        xtx1 = fa.atb(Xd, Xd, True, self.sc)
+        prod = xtx1[:, :d].cpu().numpy()
+        if self.method[m] != "reg":
+            csum = fa.atb(X.dev("cov", self.dev), None, True, self.sc).cpu().numpy().ravel()
+            prod = prod + np.diag(csum)
+        dict.__setitem__(X, "prodT", prod)
+        self._xsum[m] = xtx1[:, d].contiguous()
+        self._trxx[m] = float(np.trace(prod))
+
+    def _refresh_zstats(self):
+        q = self.q_dist
+        K = q.Kc
+        ztz1 = fa.atb(q.Z.dev("mean", self.dev), q.Z.dev("mean", self.dev), True, self.sc)
+        self._zsum = ztz1[:, K].contiguous()
+        return ztz1[:, :K].contiguous()
+
+    # ---- fit (:84-379) -------------------------------------------------------------------------------------------
+    def fit(self, *args, **kwargs):
+        if not torch.cuda.is_available():
+            raise L.FavaeHipError("SSHIBA.fit needs a GPU: the HIP path has no CPU fallback")
+        import os
+        self.dev = torch.device("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(self.dev)
+        self.sc = fa.Scratch(self.dev)
+        self.scal = torch.zeros(4, dtype=F64, device=self.dev)
+        n = [int(a["data"].shape[0]) for a in args]
+        self.n_max = int(np.max(n))
+        self.n, self.d, self.sparse, self.sparse_fs, self.center, self.method = [], [], [], [], [], []
+        self.X, self.t, self.SS, self.SS_mask, self.area_mask = [], {}, [], {}, []
+        self.V, self.k, self.sig, self.deg, self.sparse_K, self.kernel = {}, {}, {}, {}, {}, {}
+        self.img_vae = [None] * len(n)
+        self.cat_vae = [None] * len(n)
+        self.wandb_obj = [None] * len(n)
+        self.total_elbo, self.kl_q_p, self.recon_loss, self.kl_q_normal = [], [], [], []
+        self.keep_training, self.test_acc = [], []
+        self._xsum, self._trxx = {}, {}
+        for m, arg in enumerate(args):
+            meth = arg["method"]
+            if arg.get("SV") is not None or arg.get("sparse") or meth not in ("reg", "img", "mult"):
+                raise NotImplementedError("view %d: kernel / sparse / '%s' views are outside the FA-VAE hot path" % (m, meth))
+            self.n.append(int(arg["data"].shape[0]))
+            if self.n[m] != self.n_max:
+                raise NotImplementedError("semi-supervised views (unequal N) are outside the FA-VAE hot path")
+            if meth == "reg":
+                self.d.append(int(arg["data"].shape[1]))
+            elif meth == "img":
+                self.d.append(int(arg["latent_dim"]))
+            else:
+                if len(arg["data"].shape) < 2:
+                    arg["data"] = arg["data"][:, np.newaxis]
+                self.d.append(int(arg["data"].shape[1]))
+            self.sparse.append(arg["sparse"]); self.sparse_fs.append(arg["sparse_fs"]); self.center.append(arg["center"])
+            self.method.append(meth); self.area_mask.append(arg["mask"]); self.SS.append(False)
+            d = self.d[m]
+            mn = np.random.normal(0.0, 1.0, self.n_max * d).reshape(self.n_max, d)                    # :179
+            info = LazyDict(data=np.random.normal(0.0, 1.0, self.n_max * d).reshape(self.n_max, d), mean=mn, cov=mn ** 2,
+                            prodT=np.dot(mn.T, mn), LH=0, Elogp=0, sumlogdet=0, epochs=20)
+            self.X.append(info)
+            data = arg["data"] if meth == "img" else copy.deepcopy(arg["data"])      # images are read-only here
+            if meth == "reg":
+                info["data"] = data
+                info["mean"] = np.copy(data).astype(np.float64)
+                info["cov"] = np.zeros(info["mean"].shape)
+                self.SS_mask[m] = np.isnan(info["mean"])
+            elif meth == "img":
+                self.keep_training.append(True)
+                self.t[m] = dict(data=data, epochs=arg["epochs"], LH=0, Elogp=0, sumlogdet=0)
+                self.img_vae[m] = self.img_vae_module.ImgVAE(dimx=arg["latent_dim"], channels=data.shape[1], lr=arg["lr"],
+                                                             h=data.shape[2], w=data.shape[3], dataset=arg["dataset"],
+                                                             latentspace_lr=self.latentspace_lr)
+            else:
+                self.t[m] = LazyDict(data=data, LH=0, Elogp=0, sumlogdet=0, epochs=20)
+                tt = np.abs(data.astype(float) - 0.05)
+                info["mean"] = np.log(tt / (1 - tt))                                                 # :276
+                info["cov"] = np.zeros(info["mean"].shape)
+                self.t[m]["mean"] = np.copy(data).astype(float)
+                self.t[m]["cov"] = np.zeros(data.shape)
+                self.SS_mask[m] = np.isnan(data.astype(float))
+        self.keep_training = {m: True for m in range(len(n)) if self.method[m] == "img"}
+        self.L, self.mse, self.R2, self.HL, self.AUC, self.AUC_tr, self.ACC, self.ACC_tr = [], [], [], [], [], [], [], []
+        self.wandb_metrics = {}
+        self.m = len(args)
+        if self.hyper is None:
+            self.hyper = HyperParameters(self.m)
+        q = self.q_dist = Qdistribution(self.X, self.n, self.n_max, self.d, self.Kc, self.m, self.hyper)
+        # ---- Qdistribution.init_rnd (:1919-1995), same draw order --------------------------------------------
+        for m in range(self.m):
+            xi = torch.empty(self.n_max, self.d[m], dtype=F64, device=self.dev)
+            fa.xi_init(self.X[m].dev("mean", self.dev), self.X[m].dev("cov", self.dev), xi)
+            q.xi[m] = xi
+        q.Z["mean"] = np.random.normal(0.0, 1.0, self.n_max * self.Kc).reshape(self.n_max, self.Kc)
+        q.Z["cov"] = np.eye(self.Kc)
+        q.Z["prodT"] = q.Z["cov"] + self.n_max * q.Z["cov"]
+        self._refresh_zstats()
+        for m in range(self.m):
+            W = q.W[m]
+            W["mean"] = np.random.normal(np.zeros((self.d[m], self.Kc)),
+                                         1 / (np.repeat(q.alpha_mean(m).reshape(1, self.Kc), self.d[m], axis=0)))
+            W["cov"] = np.dot(W["mean"].T, W["mean"])
+            W["prodT"] = np.dot(W["mean"].T, W["mean"]) + self.Kc * W["cov"]
+            self._refresh_xstats(m)
+            self.update_b(m)                                                                         # :1986-1988
+        if self.VARIANT == "A":
+            if not kwargs["pretrained"]:                                                             # :378 (KeyError if absent)
+                self.fit_iterate(**kwargs)
+        else:
+            self.fit_iterate(**kwargs)
+
+    # ---- fit_iterate (:383-451) ----------------------------------------------------------------------------------
+    def fit_iterate(self, max_iter=int(1e3), pruning_crit=1e-6, tol=1e-5, feat_crit=1e-6, perc=False, verbose=0, Y_tst=[None],
+                    X_tst=[None], X_tr=[None], HL=0, AUC=0, ACC=0, mse=0, R2=0, m_in=[0], m_out=1, steps=50, nnd=None,
+                    pretrained=0, mc_it=1, Y_ss=None, store=False, xga=None, tgx=None, lr=None):
+        q = self.q_dist
+        for i in range(max_iter):
+            self.update(iter_count=i)
+            if self.prune:
+                self.depruning(1e-15)
+                self.L.append(self.update_bound())
+                self.pruning(pruning_crit)
+                if q.Kc == 0:
+                    print("\nThere are no representative latent factors, no structure found in the data.")
+                    return
+            else:
+                self.L.append(self.update_bound())
+            if verbose:
+                text = "Nothing" if len(self.L) < 2 else (" " if self.L[-1] > self.L[-2] else "LOWER!!!!")
+                print("\rIteration %d Lower Bound %.1f K %4d %s" % (len(self.L), self.L[-1], q.Kc, text))
+            if (len(self.L) > 100) and (abs(1 - np.mean(self.L[-101:-1]) / self.L[-1]) < tol):
+                if verbose:
+                    print("\nModel correctly trained. Convergence achieved")
+                return
+            self.wandb_metrics["SSHIBA ELBO"] = float(self.L[-1])
+            self.wandb_metrics["K dimensions"] = q.Kc
+
+    # ---- update (:743-902) ---------------------------------------------------------------------------------------
+    def update(self, Y_tst=[None], X_tst=[None], X_tr=[None], Y_ss=None, HL=0, AUC=0, ACC=0, mse=0, R2=0, m_in=[0], m_out=1,
+               steps=100, mc_it=1, store=True, iter_count=0):
+        for m in range(self.m):
+            self.update_w(m)
+        self.update_Z()
+        for m in range(self.m):
+            meth = self.method[m]
+            if meth == "reg":
+                self.update_tau(m)
+                self.update_b(m)
+            if meth == "img":
+                self._update_img(m, iter_count)
+            elif meth == "mult":
+                for _ in range(2):
+                    self.update_x(m)          # update_x + update_xi fused (:856-857)
+                self._refresh_xstats(m)
+                self.update_tau(m)
+            self.update_b(m)
+            self.update_alpha(m)
+
+    def _schedule(self, m, iter_count):
+        if self.VARIANT == "A":                                                                      # cA :792-800
+            if iter_count == 0:
+                return 50, 1
+            if iter_count < 3:
+                return 5, 1
+            self.keep_training[m] = False
+            return 5, 5
+        if iter_count == 0:                                                                          # DA :808-810
+            return 50, 0.1
+        if iter_count == 1:
+            return 20, 0.5
+        self.keep_training[m] = False
+        return 20, 1
+
+    def _update_img(self, m, iter_count):
+        q, vae = self.q_dist, self.img_vae[m]
+        epochs, beta = self._schedule(m, iter_count)
+        if getattr(self, "epochs_override", None) is not None:
+            epochs = self.epochs_override[min(iter_count, len(self.epochs_override) - 1)]
+        if self.VARIANT == "A":
+            Z_in = {"mean": q.Z.dev("mean_pred%d" % m, self.dev), "cov": q.Z["covs_pred"][m]}         # :802
+        else:
+            Z_in = {"mean": q.Z.dev("mean", self.dev), "cov": q.Z["cov"]}
+        img = self.t[m]["data"]
+        trained = False
+        if self.keep_training[m]:
+            kw = dict(img=img, Z=Z_in, W=q.W[m], b=q.b[m], tau=q.tau_mean(m), epochs=epochs, beta=beta)
+            if self.VARIANT == "A":
+                kw["favae"] = True                                                                   # cA :806
+            # variant C (TL :812) does not pass `favae`, so betaVAE.trainloop falls back to the N(0,I) prior
+            self.keep_training[m] = vae.trainloop(**kw)
+            trained = True
+        elif iter_count % 10 == 0:
+            kw = dict(img=img, Z=Z_in, W=q.W[m], b=q.b[m], tau=q.tau_mean(m), epochs=epochs)          # :821 / DA :827
+            vae.trainloop(**kw)
+            trained = True
+        if trained:
+            ds = str(vae.dataset)
+            self.wandb_metrics[ds + " ELBO"] = float(vae.elbo_training[-1])
+            self.wandb_metrics[ds + " Gaussian LogLikelihood"] = float(-vae.reconstruc_during_training[-1])
+            self.wandb_metrics[ds + " KL(Q||P)"] = float(vae.KL_QandP[-1])
+            self.total_elbo.append(vae.elbo_training)
+            self.recon_loss.append(vae.reconstruc_during_training)
+            self.kl_q_p.append(vae.KL_QandP)
+            vae.update_x(img=img)                                                                    # :817
+            self.X[m].set_dev("mean", vae.x_mean_dev)
+            self.X[m].set_dev("cov", vae.x_cov_dev)
+            self._refresh_xstats(m)
+        self.update_tau(m)
+        self.update_b(m)
+        # diagnostics (:839-851): reconstruction R^2 (one np.random.randn draw) and the zero-input prediction R^2
+        r2 = vae.reconstruction_r2(self.X[m]["mean"], self.X[m]["cov"])
+        self.wandb_metrics[str(vae.dataset) + " R2 reconstruction"] = r2
+        if self.VARIANT == "A" and self.m > 1 and self.method[1] == "mult":
+            self.wandb_metrics[str(vae.dataset) + " r2_acc in the second view"] = self._zero_input_r2()
+
+    def _zero_input_r2(self):
+        """predict([0],[1], struct_data(X['data'],'vae')) of cA :846-848: a 'vae' view contributes nothing to Z_mean
+        (:1402-1414), so the prediction is sigmoid(b (1+pi/8 var)^-1/2) per label (:1469-1477); R^2 from column sums."""
+        q = self.q_dist
+        W0 = self._up(q.W[0]["mean"])
+        aux = fa.small_gemm(W0, W0, transA=True, alpha=self._tau(0))
+        aux = fa.axpby(1.0, aux, 1.0, self._up(np.eye(q.Kc)))
+        Zc, _, _, ok = fa.chol_inv(aux, self.sc)
+        W1 = self._up(q.W[1]["mean"])
+        var = fa.small_gemm(fa.small_gemm(W1, Zc), W1, transB=True).cpu().numpy()
+        var_d = 1.0 / self._tau(1) + np.diag(var)
+        b1 = np.ravel(q.b[1]["mean"])
+        pred = np.exp(-np.log(1 + np.exp(-(b1 * (1 + math.pi / 8 * var_d) ** (-0.5)))))
+        T = self.t[1].dev("mean", self.dev)
+        st = fa.atb(T, T, True, self.sc).cpu().numpy()
+        n, d = self.n_max, self.d[1]
+        sy, syy = st[:, d], np.diag(st[:, :d])
+        num = syy - 2 * pred * sy + n * pred ** 2
+        den = syy - sy ** 2 / n
+        out = np.ones(d)
+        nz = den != 0
+        out[nz] = 1 - num[nz] / den[nz]
+        out[(~nz) & (num != 0)] = 0.0
+        return float(out.mean())
+
+    # ---- mean-field updates ----------------------------------------------------------------------------------------
+    def update_w(self, m):
+        """:1058-1075"""
+        q = self.q_dist
+        tau = self._tau(m)
+        s = self._up(1 / np.sqrt(q.alpha_mean(m)))
+        wcov, _, ld_out, ok = fa.chol_inv(self._up(q.Z["prodT"]), self.sc, s=s, diag_add=1 / tau, out_scale=1 / tau)
+        if not ok:
+            print("Cov W" + str(m) + " is not invertible, not updated")
+            return
+        Xd, Zd = self.X[m].dev("mean", self.dev), q.Z.dev("mean", self.dev)
+        xtz1 = fa.atb(Xd, Zd, True, self.sc)
+        wmean = torch.empty(self.d[m], q.Kc, dtype=F64, device=self.dev)
+        wprod = torch.empty(q.Kc, q.Kc, dtype=F64, device=self.dev)
+        fa.w_update(xtz1, self._zsum, self._up(np.ravel(q.b[m]["mean"])), wcov, tau, wmean, wprod, self.sc)
+        W = q.W[m]
+        W["cov"], W["mean"], W["prodT"] = wcov.cpu().numpy(), wmean.cpu().numpy(), wprod.cpu().numpy()
+        W["_logdet_cov"] = ld_out
+
+    def update_Z(self):
+        """cA :961-1000 (variant A) / DA :980-1009 (variants B, C)"""
+        q = self.q_dist
+        M, K, lr = range(self.m), q.Kc, self.latentspace_lr
+        taus = [self._tau(m) for m in M]
+        wp = [self._up(q.W[m]["prodT"]) for m in M]
+        Zcov, _, ld, ok = fa.chol_inv(fa.z_aux(wp, taus, K, self.dev), self.sc)
+        covs_pred = []
+        if self.VARIANT == "A":
+            q.Z["covs_pred"] = []
+            coef = np.zeros(self.m)
+            for m in M:
+                coef += np.array([0.0 if j == m else 1.0 for j in M])              # `aux` is carried over (:979)
+                cp, _, _, okp = fa.chol_inv(fa.z_aux(wp, list(coef * np.array(taus)), K, self.dev), self.sc)
+                covs_pred.append(cp)
+                q.Z["covs_pred"].append(cp.cpu().numpy() if okp else np.nan)
+        if not ok:
+            print("Cov Z is not invertible, not updated")
+            return
+        q.Z["cov"] = Zcov.cpu().numpy()
+        Wd = [self._up(q.W[m]["mean"]) for m in M]
+        bd = [self._up(np.asarray(q.b[m]["mean"]).reshape(1, -1)) for m in M]
+        Xd = [self.X[m].dev("mean", self.dev) for m in M]
+
+        def combine(views, cov, base, out):
+            # out = lr * (sum_m tau_m (X_m - b_m) W_m) cov + (1 - lr) * base
+            c = None
+            Ps = []
+            for m in views:
+                P = fa.small_gemm(Wd[m], cov, alpha=taus[m])                        # tau_m W_m Sigma  [d_m x K]
+                Ps.append(P)
+                c = fa.small_gemm(bd[m], P, alpha=-1.0, beta=0.0 if c is None else 1.0, out=c)
+            for i, m in enumerate(views):
+                if i == 0:
+                    fa.rows_gemm(Xd[m], Ps[i], c.reshape(-1), lr, base, 1.0 - lr, out)
+                else:
+                    fa.rows_gemm(Xd[m], Ps[i], None, lr, None, 0.0, out, accumulate=True)
+            return out
+
+        Zold = q.Z.dev("mean", self.dev)
+        Znew = combine(list(M), Zcov, Zold, torch.empty_like(Zold))
+        q.Z.set_dev("mean", Znew)
+        ztz = self._refresh_zstats()
+        q.Z["prodT"] = fa.axpby(1.0, ztz, float(self.n_max), Zcov).cpu().numpy()                     # :989
+        if self.VARIANT == "A":
+            q.Z["prodT_pred"] = []
+            for m in M:
+                others = [j for j in M if j != m]
+                if not others:
+                    raise ValueError("variant A needs at least two views (reference :996 stacks the other views)")
+                zp = combine(others, covs_pred[m], Znew, torch.empty_like(Znew))                     # :996-997
+                q.Z.set_dev("mean_pred%d" % m, zp)
+                zz = fa.atb(zp, zp, False, self.sc)
+                q.Z["prodT_pred"].append(fa.axpby(1.0, zz, float(self.n_max), covs_pred[m]).cpu().numpy())
+            q.Z["mean_pred"] = _PredList(q.Z, self.m)
+
+    def update_b(self, m):
+        """:1077-1092"""
+        q = self.q_dist
+        bmean = torch.empty(self.d[m], dtype=F64, device=self.dev)
+        fa.b_update(self._xsum[m], self._zsum, self._up(q.W[m]["mean"]), self._tau(m), self.n_max, bmean, self.scal)
+        sc = self.scal.cpu().numpy()
+        b = q.b[m]
+        b["cov"] = sc[0] * np.eye(self.d[m])
+        b["mean"] = bmean.cpu().numpy()[np.newaxis, :]
+        b["prodT"] = float(sc[1])
+
+    def update_alpha(self, m):
+        """:1094-1112"""
+        q = self.q_dist
+        ab = torch.empty(q.Kc, dtype=F64, device=self.dev)
+        fa.alpha_update(self._up(q.W[m]["prodT"]), self.hyper.alpha_b[m], self.d[m], ab)
+        q.alpha[m]["a"] = (self.hyper.alpha_a[m] + 0.5 * self.d[m]) / (self.d[m])
+        q.alpha[m]["b"] = ab.cpu().numpy()
+
+    def update_tau(self, m):
+        """:1121-1139"""
+        q = self.q_dist
+        xtz1 = fa.atb(self.X[m].dev("mean", self.dev), q.Z.dev("mean", self.dev), True, self.sc)
+        fa.tau_update(self._xsum[m], self._zsum, xtz1, self._trxx[m], self._up(q.Z["prodT"]), self._up(q.W[m]["prodT"]),
+                      self._up(q.W[m]["mean"]), self._up(np.ravel(q.b[m]["mean"])), float(q.b[m]["prodT"]),
+                      self.hyper.tau_a[m], self.hyper.tau_b[m], self.n_max, self.scal)
+        sc = self.scal.cpu().numpy()
+        q.tau[m]["a"] = float(sc[2])
+        q.tau[m]["b"] = np.array([sc[3]])
+
+    def update_x(self, m):
+        """multilabel update_x + update_xi (:1197-1229), one fused pass"""
+        q = self.q_dist
+        X = self.X[m]
+        n, d = self.n_max, self.d[m]
+        zwb = torch.empty(n, d, dtype=F64, device=self.dev)
+        fa.rows_gemm(q.Z.dev("mean", self.dev), self._up(q.W[m]["mean"].T), self._up(np.ravel(q.b[m]["mean"])), 1.0, None, 0.0, zwb)
+        mean = X.dev("mean", self.dev)
+        cov = X.dev("cov", self.dev)
+        sums = fa.mult_update(self.t[m].dev("mean", self.dev), zwb, q.xi[m], mean, cov, self._tau(m), self.sc)
+        X.set_dev("mean", mean)
+        X.set_dev("cov", cov)
+        dict.__setitem__(X, "sumlogdet", float(sums[0]))
+        self._mult_elbo = getattr(self, "_mult_elbo", {})
+        self._mult_elbo[m] = float(sums[1])
+
+    def update_xi(self, m):
+        """fused into update_x (the kernel writes xi = sqrt(cov + mean^2) in the same pass, :1229)"""
+
+    # ---- lower bound (:1572-1688) --------------------------------------------------------------------------------
+    def _hgauss(self, rows, cov, prev):
+        sgn, lad = fa.slogdet(self._up(cov), self.sc)
+        H = 0.5 * rows * (lad if sgn != 0 else -np.inf)
+        return prev if abs(H) == np.inf else H
+
+    def update_bound(self):
+        q = self.q_dist
+        q.Z["LH"] = self._hgauss(self.n_max, q.Z["cov"], q.Z["LH"])
+        ent = q.Z["LH"]
+        for m in range(self.m):
+            q.W[m]["LH"] = self._hgauss(self.d[m], q.W[m]["cov"], q.W[m]["LH"])
+            bc = q.b[m]["cov"][0, 0]
+            Hb = 0.5 * 1 * self.d[m] * math.log(bc) if bc > 0 else -np.inf                            # slogdet(bc * I_d)
+            q.b[m]["LH"] = q.b[m]["LH"] if abs(Hb) == np.inf else Hb
+            q.alpha[m]["LH"] = np.sum(-np.log(q.alpha[m]["b"] + EPS))
+            q.tau[m]["LH"] = np.sum(-np.log(q.tau[m]["b"] + EPS))
+            ent = ent + q.W[m]["LH"] + q.b[m]["LH"] + q.alpha[m]["LH"] + q.tau[m]["LH"]
+            if self.method[m] == "mult":
+                H = 0.5 * self.X[m]["sumlogdet"]
+                dict.__setitem__(self.X[m], "LH", self.X[m]["LH"] if abs(H) == np.inf else H)
+                ent = ent + self.X[m]["LH"]
+        q.Z["Elogp"] = -0.5 * np.trace(q.Z["prodT"])
+        elogp = q.Z["Elogp"]
+        for m in range(self.m):
+            q.b[m]["Elogp"] = -0.5 * q.b[m]["prodT"]
+            e_tau = -(0.5 * self.n_max * self.d[m] + self.hyper.tau_a[m] - 1) * np.log(q.tau[m]["b"] + EPS)
+            if self.method[m] == "mult":
+                e_tau = e_tau + self._mult_elbo[m]                                                    # :1678
+            q.tau[m]["ElogpXtau"] = e_tau
+            q.alpha[m]["ElogpWalp"] = -(0.5 * self.d[m] + self.hyper.alpha_a[m] - 1) * np.sum(np.log(q.alpha[m]["b"]))
+            elogp = elogp + e_tau + q.alpha[m]["ElogpWalp"] + q.b[m]["Elogp"]
+        return float(np.ravel(elogp - ent)[0])
+
+    # ---- pruning (:490-537) ----------------------------------------------------------------------------------------
+    def pruning(self, pruning_crit):
+        q = self.q_dist
+        keep = np.zeros(q.Kc, dtype=bool)
+        for m in range(self.m):
+            keep |= np.any(np.abs(q.W[m]["mean"][:, :q.Kc]) > pruning_crit, axis=0)
+        sel = np.flatnonzero(keep)
+        if len(sel) != q.Z.dev("mean", self.dev).shape[1]:
+            if len(sel):
+                Zd = q.Z.dev("mean", self.dev)
+                out = torch.empty(self.n_max, len(sel), dtype=F64, device=self.dev)
+                fa.gather_cols(Zd, torch.from_numpy(sel.astype(np.int32)).to(self.dev), out)
+                q.Z.set_dev("mean", out)
+            else:
+                q.Z["mean"] = np.zeros((self.n_max, 0))
+        q.Z["cov"] = q.Z["cov"][sel, :][:, sel]
+        q.Z["prodT"] = q.Z["prodT"][sel, :][:, sel]
+        for m in range(self.m):
+            W = q.W[m]
+            W["mean"] = W["mean"][:, sel]
+            W["cov"] = W["cov"][sel, :][:, sel]
+            W["prodT"] = W["prodT"][sel, :][:, sel]
+            q.alpha[m]["b"] = q.alpha[m]["b"][sel]
+        changed = len(sel) != q.Kc
+        q.Kc = len(sel)
+        if changed and q.Kc > 0:
+            self._refresh_zstats()
+
+    def depruning(self, pruning_crit):
+        """Pads the K x K / d x K state back to the original Kc with 1e-15 before the bound (:518-537).  Z.mean is left
+        at its pruned width on the device: the bound only reads its row count (:1603)."""
+        q = self.q_dist
+        Kp = self.Kc - q.Kc
+        if Kp == 0:
+            return
+
+        def pad2(A):
+            top = np.hstack((A, pruning_crit * np.ones((q.Kc, Kp))))
+            return np.vstack((top, pruning_crit * np.ones((Kp, self.Kc))))
+
+        q.Z["cov"], q.Z["prodT"] = pad2(q.Z["cov"]), pad2(q.Z["prodT"])
+        for m in range(self.m):
+            W = q.W[m]
+            W["mean"] = np.hstack((W["mean"], pruning_crit * np.ones((self.d[m], Kp))))
+            W["cov"], W["prodT"] = pad2(W["cov"]), pad2(W["prodT"])
+            q.alpha[m]["b"] = np.hstack((q.alpha[m]["b"], pruning_crit * np.ones((Kp,))))
+
+    # ---- pickling ----------------------------------------------------------------------------------------------------
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        for k in ("sc", "scal", "_zsum", "_xsum", "dev"):
+            st.pop(k, None)
+        if "q_dist" in st:
+            xi = st["q_dist"].xi
+            st["q_dist"] = copy.copy(st["q_dist"])
+            st["q_dist"].xi = [x.cpu().numpy() if isinstance(x, torch.Tensor) else x for x in xi]
+        return st
+
+
+class _PredList(object):
+    """q.Z['mean_pred'][m] of variant A (:992-997): device-resident, materialised on indexing."""
+
+    def __init__(self, zdict, m):
+        self._z, self._m = zdict, m
+
+    def __len__(self):
+        return self._m
+
+    def __getitem__(self, m):
+        return self._z._dev["mean_pred%d" % m].cpu().numpy()

@@ -89,6 +89,9 @@ int favae_encode_head(const float* fc, int B, int z, double* xmean, double* xcov
 int favae_sigmoid_ll(const float* raw, const float* x, int B, long long D, float var_x, void* draw, double* rec_err,
                      double* scratch, size_t scratch_doubles, int dtype, void* stream);
 int favae_sigmoid(const float* raw, float* out, long long n, void* stream);
+/* acc3 += (sum (y - sigmoid(raw))^2, sum y, sum y^2). scratch >= 3*1024 doubles. */
+int favae_sigmoid_sse(const float* raw, const float* y, long long n, double* acc3, double* scratch, size_t scratch_doubles,
+                      void* stream);
 /* torch.optim.Adam step (defaults, no weight decay; :131,250) over a flat fp32 arena of n (multiple of 4) floats. */
 int favae_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                     float eps, long long step, void* stream);
@@ -131,8 +134,15 @@ int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const int* perm,
                           const double* prior, float tau, float beta, float var_x, float lr, long long step0,
                           double* metrics, void* stream);
 /* eval-mode encoder of update_x (:331-358) and eval-mode decoder of reconstruction/decoder (:94-99, 360-385). */
-int favae_vae_encode(favae_vae* h, const float* data_nhwc, const int* idx, int B, double* xmean, double* xcov, void* stream);
-int favae_vae_decode(favae_vae* h, const float* zin, int B, float* out_nhwc, void* stream);
+int favae_vae_encode(favae_vae* h, const float* data_nhwc, const int* idx, int B, double* xmean, double* xcov, int train,
+                     void* stream);
+int favae_vae_encode_all(favae_vae* h, const float* data_nhwc, long long n, int batch, double* xmean, double* xcov,
+                         void* stream);
+int favae_vae_decode(favae_vae* h, const float* zin, int B, float* out_nhwc, int train, void* stream);
+/* reconstruction + r2_score sums of SSHIBA.update (cA/favae.py:839-840) without leaving the device:
+ * acc3 = (sum (y-yhat)^2, sum y, sum y^2) over the n decoded rows against the resident data. */
+int favae_vae_reconstruct_stats(favae_vae* h, const float* zin, const float* data_nhwc, long long n, int batch,
+                                double* acc3, void* stream);
 int favae_vae_debug_ptr(favae_vae* h, int which, int layer, void** out);
 
 /* ---- factor-analysis half (SSHIBA mean-field updates, float64) -------------------------------------------------- */
@@ -179,6 +189,8 @@ int favae_fa_tau_update(const double* xsum, const double* zsum, const double* xt
 int favae_fa_alpha_update(const double* wprodT, double b0, int d, int K, double* alpha_b, void* stream);
 /* aux = I + sum_m coef[m] WprodT_m (cA/favae.py:970-971, 976-980). wprodT: HOST array of m device pointers, m <= 8. */
 int favae_fa_z_aux(const double* const* wprodT, const double* coef, int m, int K, double* aux, void* stream);
+/* out = a x + b y (y may be NULL): Z.prodT = Z^T Z + N Sigma_Z (cA/favae.py:989) and similar small combinations. */
+int favae_axpby(long long n, double a, const double* x, double b, const double* y, double* out, void* stream);
 /* out[N][Kn] = in[N][K][:, sel] (pruning of q.Z['mean'], cA/favae.py:507). */
 int favae_gather_cols(const double* in, int K, const int* sel, int Kn, double* out, long long N, void* stream);
 
