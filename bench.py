@@ -1,0 +1,199 @@
+"""FA-VAE training-iteration benchmark on MI355X (BASELINE.json metric: samples/s per FA-VAE train iteration).
+
+One "step" = one full SSHIBA iteration through the drop-in API (fa-vae_amd/condition_a_VAE/favae.py, variant A):
+update_w, update_Z, ImgVAE.trainloop (E = 5 epochs of batch-64 steps with the FA prior, reference schedule for
+iterations 1-2, condition_a_VAE/favae.py:794-795), update_x over all N, update_tau/b/alpha, the multilabel update,
+the reconstruction diagnostic, update_bound and pruning.  Workload = BASELINE.json configs[1]: N = 202 599 synthetic
+64x64x3 images + 40 labels, latent 20, Kc = 50, bf16 conv path + float64 FA updates.  Inputs are resident in HBM before
+the timed region.  N GPUs: one process per GPU (torchrun), N sharded, weak scaling (202 599 samples per GPU).
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "fa-vae_amd")
+for p in (ROOT, PKG, os.path.join(PKG, "condition_a_VAE")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+E_EPOCHS = 5
+CLASS_NAMES = {0: "igemm_kc gather 128x128", 1: "igemm_kc gather 128x64", 2: "igemm_kc gather 64x64", 3: "igemm_kc gather 128x32",
+               4: "igemm_kc scatter 128x128", 5: "igemm_kc scatter 128x64", 6: "igemm_kc scatter 64x64",
+               8: "igemm_kc gather elementwise-load", 9: "igemm_kc scatter elementwise-load", 10: "igemm_pm wgrad 32x128",
+               11: "igemm_pm wgrad 128x32", 12: "igemm_pm wgrad 64x64", 13: "igemm_pm wgrad 128x128"}
+
+
+def synth(n, seed):
+    rng = np.random.default_rng(seed)
+    img = rng.random((n, 3, 64, 64), dtype=np.float32)
+    rs = np.random.RandomState(seed)
+    zt = rs.randn(n, 5)
+    lab = (zt @ rs.randn(5, 40) > 0).astype(int)
+    return img, lab
+
+
+def cpu_baseline(n, z, kc):
+    """The oracle (CPU restatement, `kind: port`) timed on this box's host cores on a bounded sample of the same
+    workload and extrapolated to one iteration.  Reported next to the GPU number; it is not the target."""
+    from oracle import fa_numpy as fo
+    from oracle import vae_torch as vt
+    torch.manual_seed(0)
+    np.random.seed(0)
+    B = 64
+    vae = vt.OracleImgVAE(dimx=z, channels=3, lr=1e-3, dataset="cpu")
+    img = torch.rand(B, 3, 64, 64)
+    prior = torch.randn(B, z, dtype=torch.float64)
+    tau = torch.Tensor(np.asarray(np.array([1.5])))
+    ts = []
+    for i in range(10):
+        t0 = time.time()
+        vae.optim.zero_grad()
+        loss, *_ = vt.loss_terms(vae.P, vae.B, img, prior, tau, 0.01, 1)
+        loss.backward()
+        vae.optim.step()
+        ts.append(time.time() - t0)
+    t_step = float(np.median(ts[2:]))
+    with torch.no_grad():
+        t0 = time.time()
+        for _ in range(8):
+            vt.encoder(img, vae.P, vae.B, False)
+        t_enc = (time.time() - t0) / 8
+        zin = torch.randn(B, z)
+        t0 = time.time()
+        for _ in range(4):
+            vt.decoder(zin, vae.P, vae.B, False)
+        t_dec = (time.time() - t0) / 4
+    rs = np.random.RandomState(3)
+    zt = rs.randn(n, 5)
+    x0 = zt @ rs.randn(5, z) + 0.1 * rs.randn(n, z)          # stands in for the encoder moments of the image view
+    lab = (zt @ rs.randn(5, 40) > 0).astype(int)
+    fa_model = fo.SSHIBAOracle(kc, 1, variant="A")
+    fa_model.fit(fo.struct_data(x0, "reg"), fo.struct_data(lab, "mult"), iterate=False)
+    t0 = time.time()
+    fa_model.update(iter_count=1)
+    fa_model.depruning(1e-15)
+    fa_model.update_bound()
+    fa_model.pruning(1e-3)
+    t_fa = time.time() - t0
+    nb = (n + B - 1) // B
+    t_iter = E_EPOCHS * nb * t_step + nb * t_enc + nb * t_dec + t_fa
+    return {"value": E_EPOCHS * n / t_iter, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle (torch-CPU fp32 VAE + NumPy fp64 FA): 8 train steps, 8 encoder and 4 decoder batches of 64, "
+                      "one FA update at N=%d; extrapolated to E=%d epochs + update_x + reconstruction over N "
+                      "(t_step %.3fs t_enc %.3fs t_dec %.3fs t_fa %.2fs)" % (n, E_EPOCHS, t_step, t_enc, t_dec, t_fa)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=202599, help="samples per GPU")
+    ap.add_argument("--kc", type=int, default=50)
+    ap.add_argument("--latent", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if ws > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda:%d" % local))
+    os.environ["FAVAE_CONV_DTYPE"] = a.dtype
+
+    import favae
+    from favae_hip import lib
+
+    img, lab = synth(a.n, 1 + rank)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = favae.SSHIBA(a.kc, 1)
+    v_img = model.struct_data(img, "img", latent_dim=a.latent, lr=1e-3, dataset="synthetic")
+    v_lab = model.struct_data(lab, "mult")
+    model.fit(v_img, v_lab, max_iter=0, pruning_crit=1e-3, verbose=0, store=False, pretrained=1)   # initialisation only
+    model.img_vae[0]._resident(img)                      # images resident in HBM before anything is timed
+    model.img_vae[0].img = None
+
+    def one_iteration():
+        model.keep_training[0] = True                    # the FA-prior training iteration (reference iterations 1-2)
+        model.update(iter_count=1)
+        model.depruning(1e-15)
+        model.L.append(model.update_bound())
+        model.pruning(1e-3)
+
+    def fence():
+        torch.cuda.synchronize()
+        if ws > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    raw = lib.raw()
+    for _ in range(a.warmup):
+        one_iteration()
+    raw.favae_prof_enable(1, 16)
+    fence()
+    t0 = time.time()
+    for _ in range(a.steps):
+        one_iteration()
+    fence()
+    dt = time.time() - t0
+    raw.favae_prof_enable(0, 1)
+    prof = (ctypes.c_double * 48)()
+    lib.check(raw.favae_prof_collect(prof))
+    if ws > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        n_global = a.n * ws
+        kern = []
+        for c in range(16):
+            cnt, sec, fl = prof[3 * c], prof[3 * c + 1], prof[3 * c + 2]
+            if cnt > 0:
+                kern.append({"kernel": CLASS_NAMES.get(c, str(c)), "sampled_launches": int(cnt), "avg_us": 1e6 * sec / cnt,
+                             "tflops": fl / sec / 1e12, "share_of_gemm_time": sec})
+        tot = sum(k["share_of_gemm_time"] for k in kern) or 1.0
+        for k in kern:
+            k["share_of_gemm_time"] /= tot
+        dom = max(kern, key=lambda k: k["share_of_gemm_time"]) if kern else None
+        peak = 2500.0 if a.dtype == "bf16" else 157.3
+        out = {
+            "metric": "samples/sec per FA-VAE train iteration (VAE fwd-bwd + FA update)",
+            "value": E_EPOCHS * n_global * a.steps / dt, "unit": "samples/s", "n_gpus": ws, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 conv MFMA (fp32 accumulate) + f64 FA" if a.dtype == "bf16" else "f32 conv MFMA + f64 FA",
+            "data": "synthetic",
+            "config": {"workload": "condition_a_VAE full CelebA scale: N=%d synthetic 64x64x3 images per GPU + 40-label view, "
+                                   "latent %d, Kc=%d, E=%d epochs of batch 64 per iteration" % (a.n, a.latent, a.kc, E_EPOCHS),
+                       "samples_per_gpu": a.n, "global_samples": n_global, "epochs_per_iteration": E_EPOCHS, "batch": 64,
+                       "parallelism": "dp%d (N-sharded, RCCL all-reduce of VAE gradients and FA statistics)" % ws,
+                       "bound_last": float(model.L[-1])},
+            "roofline": None if dom is None else {
+                "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
+                "frac": dom["tflops"] / peak, "traffic": None,
+                "note": "HIP events on the launch stream around every 16th launch inside the timed region; algorithmic flops, "
+                        "dense-tap convention"},
+            "kernels": kern,
+        }
+        if ws == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.n, a.latent, a.kc)
+        print(json.dumps(out))
+    if ws > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

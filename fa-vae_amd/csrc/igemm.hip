@@ -18,9 +18,41 @@
 #include "common.h"
 #include "favae_hip.h"
 
+#include <mutex>
+#include <vector>
+
 namespace {
 
 constexpr int BK = 32;  // reduction elements per LDS stage
+
+// ---- optional live timing of the GEMM launches (bench.py roofline): every `stride`-th launch of each kernel class is
+// bracketed by HIP events on the launch stream; favae_prof_collect() resolves them after a synchronise. -----------
+struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+struct Prof {
+    int enabled = 0, stride = 1;
+    long long counter[16] = {0};
+    std::vector<ProfRec> recs;
+    std::mutex mu;
+} g_prof;
+
+struct ProfScope {
+    hipStream_t st; int idx = -1;
+    ProfScope(int cls, double flops, hipStream_t s) : st(s) {
+        if (!g_prof.enabled) return;
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        if ((g_prof.counter[cls]++ % g_prof.stride) != 0) return;
+        ProfRec r; r.cls = cls; r.flops = flops;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        (void)hipEventRecord(r.a, st);
+        g_prof.recs.push_back(r);
+        idx = (int)g_prof.recs.size() - 1;
+    }
+    ~ProfScope() {
+        if (idx < 0) return;
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        (void)hipEventRecord(g_prof.recs[idx].b, st);
+    }
+};
 
 template <class T> struct Frag;
 template <> struct Frag<float> { float v[8]; };
@@ -385,6 +417,11 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
 template <class T, bool TR, bool SLOW, int BM, int BN, int WM, int WN>
 int launch_kc(const KcParams& p, int classes, hipStream_t st) {
     dim3 grid(cdiv(p.M, BM) * p.ntn, p.splitk, classes);
+    const int tile = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64) ? 2 : 3;
+    const int cls = SLOW ? (TR ? 9 : 8) : (TR ? 4 : 0) + tile;
+    // algorithmic work, dense-tap convention: gather form ks*ks taps per output pixel, stride-2 scatter form 9/4
+    const double taps = (TR && p.stride == 2) ? 2.25 : (double)(p.ks * p.ks);
+    ProfScope prof(cls, 2.0 * p.Nb * p.Ho * p.Wo * (double)p.Cout * taps * p.Cin, st);
     hipLaunchKernelGGL((igemm_kc<T, BM, BN, WM, WN, TR, SLOW>), grid, dim3(256), 0, st, p);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
@@ -431,6 +468,7 @@ int dispatch_pm(PmParams p, hipStream_t st) {
     int sk = p.splitk > 0 ? p.splitk : std::min(std::max(1, nchunk / 4), cdiv(1024, blocks));
     p.splitk = std::max(1, std::min(sk, nchunk));
     dim3 grid(cdiv(p.Rc, BM) * p.ntn, p.splitk, p.ks * p.ks);
+    ProfScope prof(BM == 32 ? 10 : BN == 32 ? 11 : BM == 64 ? 12 : 13, 2.0 * p.Rc * (double)p.Cc * p.K * p.ks * p.ks, st);
     if (BM == 32) hipLaunchKernelGGL((igemm_pm<T, 32, 128, 1, 4>), grid, dim3(256), 0, st, p);
     else if (BN == 32) hipLaunchKernelGGL((igemm_pm<T, 128, 32, 4, 1>), grid, dim3(256), 0, st, p);
     else if (BM == 64) hipLaunchKernelGGL((igemm_pm<T, 64, 64, 2, 2>), grid, dim3(256), 0, st, p);
@@ -491,4 +529,33 @@ extern "C" int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const 
     p.splitk = splitk; p.ntn = 1; p.K = Nb * Hs * Ws;
     hipStream_t st = (hipStream_t)stream;
     return dtype == FAVAE_F32 ? dispatch_pm<float>(p, st) : dispatch_pm<bf16_t>(p, st);
+}
+
+/* Live kernel timing for bench.py: enable with a sampling stride, run, then collect per-class (launches, seconds, flops).
+ * Classes: 0-3 gather form tiles 128x128/128x64/64x64/128x32, 4-6 scatter form, 8/9 element-wise loaders, 10-13 weight
+ * gradient tiles 32x128/128x32/64x64/128x128. */
+extern "C" int favae_prof_enable(int enabled, int stride) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.enabled = enabled;
+    g_prof.stride = stride > 0 ? stride : 1;
+    for (auto& c : g_prof.counter) c = 0;
+    return FAVAE_OK;
+}
+extern "C" int favae_prof_collect(double* out /* [16][3] */) {
+    FAVAE_CHECK_ARG(out, "favae_prof_collect: null");
+    FAVAE_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    for (int i = 0; i < 48; ++i) out[i] = 0.0;
+    for (auto& r : g_prof.recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            out[r.cls * 3 + 0] += 1.0;
+            out[r.cls * 3 + 1] += ms * 1e-3;
+            out[r.cls * 3 + 2] += r.flops;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof.recs.clear();
+    return FAVAE_OK;
 }

@@ -1,0 +1,65 @@
+"""Multi-GPU glue: one process per GPU, torch.distributed over RCCL (backend "nccl").  The path shards along N
+(SURVEY.md 8e): per-sample state stays on its rank; only reduced statistics, VAE gradients, epoch metrics and BN running
+statistics are exchanged.  All helpers are no-ops in a single process."""
+import torch
+import torch.distributed as td
+
+
+def active():
+    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+
+
+def world_size():
+    return td.get_world_size() if active() else 1
+
+
+def rank():
+    return td.get_rank() if active() else 0
+
+
+def sum_(t):
+    """In-place sum over ranks of a device (or, under gloo, host) tensor."""
+    if active():
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+    return t
+
+
+def mean_(t):
+    """In-place mean over ranks.  RCCL has a native AVG; gloo (CPU tests) does not."""
+    if active():
+        if td.get_backend() == "nccl":
+            td.all_reduce(t, op=td.ReduceOp.AVG)
+        else:
+            td.all_reduce(t, op=td.ReduceOp.SUM)
+            t /= td.get_world_size()
+    return t
+
+
+def broadcast_(t, src=0):
+    if active():
+        td.broadcast(t, src)
+    return t
+
+
+def sum_scalar(x, device=None):
+    """Sum of a Python int/float over ranks."""
+    if not active():
+        return x
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device if td.get_backend() == "nccl" else "cpu")
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return t.item()
+
+
+def all_equal(x, device=None):
+    if not active():
+        return True
+    return sum_scalar(x, device) == x * world_size()
+
+
+def shard_bounds(n, ws=None, rk=None):
+    """Contiguous equal-as-possible shard [lo, hi) of n rows for this rank (np.array_split convention)."""
+    ws = world_size() if ws is None else ws
+    rk = rank() if rk is None else rk
+    base, rem = divmod(n, ws)
+    lo = rk * base + min(rk, rem)
+    return lo, lo + base + (1 if rk < rem else 0)

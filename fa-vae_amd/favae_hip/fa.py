@@ -3,6 +3,7 @@ import ctypes
 
 import torch
 
+from . import dist
 from . import lib as L
 
 _raw = L.raw()
@@ -59,6 +60,7 @@ def mult_update(t, zwb, xi, mean, cov, tau, sc):
     s = sc.need(4096)
     L.check(_raw.favae_fa_mult_update(L.ptr(t), L.ptr(zwb), L.ptr(xi), L.ptr(mean), L.ptr(cov), _d(tau), _ll(t.numel()),
                                       L.ptr(sc.pair), L.ptr(s), _sz(s.numel()), L.stream_ptr()))
+    dist.sum_(sc.pair)                          # the two sums run over all shards
     return sc.pair[:2].cpu().numpy().copy()     # (sum log cov, bound term)
 
 

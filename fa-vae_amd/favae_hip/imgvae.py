@@ -13,6 +13,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from . import dist
 from . import lib as L
 
 _WIDTHS = (64, 128, 256, 512, 1024)
@@ -81,7 +82,7 @@ class ImgVAE(VAE):
     def __getstate__(self):
         self._pull()
         st = self.__dict__.copy()
-        for k in ("_eng", "_data_dev", "x_mean_dev", "x_cov_dev", "_ckp"):
+        for k in ("_eng", "_data_dev", "x_mean_dev", "x_cov_dev", "_ckp", "_img_src"):
             st[k] = None
         st["_synced_version"], st["_img_key"] = None, None
         return st
@@ -241,6 +242,8 @@ class ImgVAE(VAE):
             prior, tau_f = None, 1.0
         n = data.shape[0]
         nb = (n + self.BATCH - 1) // self.BATCH
+        if not dist.all_equal(nb, self.device):
+            raise ValueError("data-parallel trainloop needs the same number of mini-batches on every rank (got %d here)" % nb)
         metrics = torch.zeros(nb, 2, dtype=torch.float64, device=self.device)
         elbo_checker = -1e20
         for ep in range(int(epochs)):
@@ -250,8 +253,20 @@ class ImgVAE(VAE):
             g.manual_seed(seed)
             perm = torch.randperm(n, generator=g)
             eps = torch.cat([torch.randn(min(self.BATCH, n - s), self.dimx) for s in range(0, n, self.BATCH)], 0)
-            e.train_epoch(data, perm.to(torch.int32).to(self.device), eps.to(self.device), prior, tau_f, float(beta),
-                          float(self.var_x), float(self.lr), self.BATCH, metrics)
+            perm_d, eps_d = perm.to(torch.int32).to(self.device), eps.to(self.device)
+            if not dist.active():
+                e.train_epoch(data, perm_d, eps_d, prior, tau_f, float(beta), float(self.var_x), float(self.lr), self.BATCH, metrics)
+            else:
+                # data parallel over the N shards: every rank runs its own mini-batch of 64, gradients are averaged over
+                # RCCL before the (replicated) Adam step; BN batch statistics stay per rank (group size 64, as :218)
+                for si, s in enumerate(range(0, n, self.BATCH)):
+                    bsz = min(self.BATCH, n - s)
+                    e.train_fwdbwd(data, perm_d[s:s + bsz], bsz, eps_d[s:s + bsz], prior, tau_f, float(beta), float(self.var_x),
+                                   metrics[si])
+                    dist.mean_(e.G)
+                    e.adam(float(self.lr))
+                dist.mean_(metrics)
+                dist.mean_(e.BUF)
             m = metrics.cpu().numpy()
             rec, kl = m[:, 0], m[:, 1]
             loss = rec + beta * kl
@@ -286,6 +301,9 @@ class ImgVAE(VAE):
     def update_x(self, img=None):
         e = self._engine()
         torch.empty((), dtype=torch.int64).random_()        # the sequential DataLoader still draws its base seed
+        if img is not None and getattr(self, "_img_src", None) is None:
+            self._img_src = img
+            self.img = torch.from_numpy(img) if isinstance(img, np.ndarray) else torch.as_tensor(img)
         if img is None or self.UPDATE_X_USES_SELF_IMG:
             data = self._resident(self._img_src)
         elif img is getattr(self, "_img_src", None):
@@ -327,8 +345,9 @@ class ImgVAE(VAE):
         torch.empty((), dtype=torch.int64).random_()
         acc = torch.zeros(3, dtype=torch.float64, device=self.device)
         e.reconstruct_stats(sample, self._resident(self._img_src), acc, self.BATCH)
+        dist.sum_(acc)
         sse, sy, syy = acc.cpu().numpy()
-        cnt = float(sample.shape[0]) * 64 * 64 * self.channels
+        cnt = dist.sum_scalar(float(sample.shape[0]), self.device) * 64 * 64 * self.channels
         self.training = False
         return 1.0 - sse / (syy - sy * sy / cnt)
 

@@ -16,6 +16,7 @@ import sys
 import numpy as np
 import torch
 
+from . import dist
 from . import fa
 from . import lib as L
 
@@ -136,10 +137,10 @@ class SSHIBA(object):
         X = self.X[m]
         Xd = X.dev("mean", self.dev)
         d = self.d[m]
-        xtx1 = fa.atb(Xd, Xd, True, self.sc)
+        xtx1 = dist.sum_(fa.atb(Xd, Xd, True, self.sc))
         prod = xtx1[:, :d].cpu().numpy()
         if self.method[m] != "reg":
-            csum = fa.atb(X.dev("cov", self.dev), None, True, self.sc).cpu().numpy().ravel()
+            csum = dist.sum_(fa.atb(X.dev("cov", self.dev), None, True, self.sc)).cpu().numpy().ravel()
             prod = prod + np.diag(csum)
         dict.__setitem__(X, "prodT", prod)
         self._xsum[m] = xtx1[:, d].contiguous()
@@ -148,7 +149,7 @@ class SSHIBA(object):
     def _refresh_zstats(self):
         q = self.q_dist
         K = q.Kc
-        ztz1 = fa.atb(q.Z.dev("mean", self.dev), q.Z.dev("mean", self.dev), True, self.sc)
+        ztz1 = dist.sum_(fa.atb(q.Z.dev("mean", self.dev), q.Z.dev("mean", self.dev), True, self.sc))
         self._zsum = ztz1[:, K].contiguous()
         return ztz1[:, :K].contiguous()
 
@@ -162,7 +163,8 @@ class SSHIBA(object):
         self.sc = fa.Scratch(self.dev)
         self.scal = torch.zeros(4, dtype=F64, device=self.dev)
         n = [int(a["data"].shape[0]) for a in args]
-        self.n_max = int(np.max(n))
+        self.n_loc = int(np.max(n))                       # rows held by this rank (the views passed in are this rank's shard)
+        self.n_max = int(round(dist.sum_scalar(self.n_loc, self.dev)))      # global N of the formulas
         self.n, self.d, self.sparse, self.sparse_fs, self.center, self.method = [], [], [], [], [], []
         self.X, self.t, self.SS, self.SS_mask, self.area_mask = [], {}, [], {}, []
         self.V, self.k, self.sig, self.deg, self.sparse_K, self.kernel = {}, {}, {}, {}, {}, {}
@@ -177,7 +179,7 @@ class SSHIBA(object):
             if arg.get("SV") is not None or arg.get("sparse") or meth not in ("reg", "img", "mult"):
                 raise NotImplementedError("view %d: kernel / sparse / '%s' views are outside the FA-VAE hot path" % (m, meth))
             self.n.append(int(arg["data"].shape[0]))
-            if self.n[m] != self.n_max:
+            if self.n[m] != self.n_loc:
                 raise NotImplementedError("semi-supervised views (unequal N) are outside the FA-VAE hot path")
             if meth == "reg":
                 self.d.append(int(arg["data"].shape[1]))
@@ -190,8 +192,8 @@ class SSHIBA(object):
             self.sparse.append(arg["sparse"]); self.sparse_fs.append(arg["sparse_fs"]); self.center.append(arg["center"])
             self.method.append(meth); self.area_mask.append(arg["mask"]); self.SS.append(False)
             d = self.d[m]
-            mn = np.random.normal(0.0, 1.0, self.n_max * d).reshape(self.n_max, d)                    # :179
-            info = LazyDict(data=np.random.normal(0.0, 1.0, self.n_max * d).reshape(self.n_max, d), mean=mn, cov=mn ** 2,
+            mn = np.random.normal(0.0, 1.0, self.n_loc * d).reshape(self.n_loc, d)                    # :179
+            info = LazyDict(data=np.random.normal(0.0, 1.0, self.n_loc * d).reshape(self.n_loc, d), mean=mn, cov=mn ** 2,
                             prodT=np.dot(mn.T, mn), LH=0, Elogp=0, sumlogdet=0, epochs=20)
             self.X.append(info)
             data = arg["data"] if meth == "img" else copy.deepcopy(arg["data"])      # images are read-only here
@@ -223,10 +225,10 @@ class SSHIBA(object):
         q = self.q_dist = Qdistribution(self.X, self.n, self.n_max, self.d, self.Kc, self.m, self.hyper)
         # ---- Qdistribution.init_rnd (:1919-1995), same draw order --------------------------------------------
         for m in range(self.m):
-            xi = torch.empty(self.n_max, self.d[m], dtype=F64, device=self.dev)
+            xi = torch.empty(self.n_loc, self.d[m], dtype=F64, device=self.dev)
             fa.xi_init(self.X[m].dev("mean", self.dev), self.X[m].dev("cov", self.dev), xi)
             q.xi[m] = xi
-        q.Z["mean"] = np.random.normal(0.0, 1.0, self.n_max * self.Kc).reshape(self.n_max, self.Kc)
+        q.Z["mean"] = np.random.normal(0.0, 1.0, self.n_loc * self.Kc).reshape(self.n_loc, self.Kc)
         q.Z["cov"] = np.eye(self.Kc)
         q.Z["prodT"] = q.Z["cov"] + self.n_max * q.Z["cov"]
         self._refresh_zstats()
@@ -234,6 +236,8 @@ class SSHIBA(object):
             W = q.W[m]
             W["mean"] = np.random.normal(np.zeros((self.d[m], self.Kc)),
                                          1 / (np.repeat(q.alpha_mean(m).reshape(1, self.Kc), self.d[m], axis=0)))
+            if dist.active():                              # replicated state must start identical on every rank
+                W["mean"] = dist.broadcast_(self._up(W["mean"])).cpu().numpy()
             W["cov"] = np.dot(W["mean"].T, W["mean"])
             W["prodT"] = np.dot(W["mean"].T, W["mean"]) + self.Kc * W["cov"]
             self._refresh_xstats(m)
@@ -362,7 +366,7 @@ class SSHIBA(object):
         b1 = np.ravel(q.b[1]["mean"])
         pred = np.exp(-np.log(1 + np.exp(-(b1 * (1 + math.pi / 8 * var_d) ** (-0.5)))))
         T = self.t[1].dev("mean", self.dev)
-        st = fa.atb(T, T, True, self.sc).cpu().numpy()
+        st = dist.sum_(fa.atb(T, T, True, self.sc)).cpu().numpy()
         n, d = self.n_max, self.d[1]
         sy, syy = st[:, d], np.diag(st[:, :d])
         num = syy - 2 * pred * sy + n * pred ** 2
@@ -384,7 +388,7 @@ class SSHIBA(object):
             print("Cov W" + str(m) + " is not invertible, not updated")
             return
         Xd, Zd = self.X[m].dev("mean", self.dev), q.Z.dev("mean", self.dev)
-        xtz1 = fa.atb(Xd, Zd, True, self.sc)
+        xtz1 = dist.sum_(fa.atb(Xd, Zd, True, self.sc))
         wmean = torch.empty(self.d[m], q.Kc, dtype=F64, device=self.dev)
         wprod = torch.empty(q.Kc, q.Kc, dtype=F64, device=self.dev)
         fa.w_update(xtz1, self._zsum, self._up(np.ravel(q.b[m]["mean"])), wcov, tau, wmean, wprod, self.sc)
@@ -444,7 +448,7 @@ class SSHIBA(object):
                     raise ValueError("variant A needs at least two views (reference :996 stacks the other views)")
                 zp = combine(others, covs_pred[m], Znew, torch.empty_like(Znew))                     # :996-997
                 q.Z.set_dev("mean_pred%d" % m, zp)
-                zz = fa.atb(zp, zp, False, self.sc)
+                zz = dist.sum_(fa.atb(zp, zp, False, self.sc))
                 q.Z["prodT_pred"].append(fa.axpby(1.0, zz, float(self.n_max), covs_pred[m]).cpu().numpy())
             q.Z["mean_pred"] = _PredList(q.Z, self.m)
 
@@ -470,7 +474,7 @@ class SSHIBA(object):
     def update_tau(self, m):
         """:1121-1139"""
         q = self.q_dist
-        xtz1 = fa.atb(self.X[m].dev("mean", self.dev), q.Z.dev("mean", self.dev), True, self.sc)
+        xtz1 = dist.sum_(fa.atb(self.X[m].dev("mean", self.dev), q.Z.dev("mean", self.dev), True, self.sc))
         fa.tau_update(self._xsum[m], self._zsum, xtz1, self._trxx[m], self._up(q.Z["prodT"]), self._up(q.W[m]["prodT"]),
                       self._up(q.W[m]["mean"]), self._up(np.ravel(q.b[m]["mean"])), float(q.b[m]["prodT"]),
                       self.hyper.tau_a[m], self.hyper.tau_b[m], self.n_max, self.scal)
@@ -482,7 +486,7 @@ class SSHIBA(object):
         """multilabel update_x + update_xi (:1197-1229), one fused pass"""
         q = self.q_dist
         X = self.X[m]
-        n, d = self.n_max, self.d[m]
+        n, d = self.n_loc, self.d[m]
         zwb = torch.empty(n, d, dtype=F64, device=self.dev)
         fa.rows_gemm(q.Z.dev("mean", self.dev), self._up(q.W[m]["mean"].T), self._up(np.ravel(q.b[m]["mean"])), 1.0, None, 0.0, zwb)
         mean = X.dev("mean", self.dev)
@@ -541,11 +545,11 @@ class SSHIBA(object):
         if len(sel) != q.Z.dev("mean", self.dev).shape[1]:
             if len(sel):
                 Zd = q.Z.dev("mean", self.dev)
-                out = torch.empty(self.n_max, len(sel), dtype=F64, device=self.dev)
+                out = torch.empty(self.n_loc, len(sel), dtype=F64, device=self.dev)
                 fa.gather_cols(Zd, torch.from_numpy(sel.astype(np.int32)).to(self.dev), out)
                 q.Z.set_dev("mean", out)
             else:
-                q.Z["mean"] = np.zeros((self.n_max, 0))
+                q.Z["mean"] = np.zeros((self.n_loc, 0))
         q.Z["cov"] = q.Z["cov"][sel, :][:, sel]
         q.Z["prodT"] = q.Z["prodT"][sel, :][:, sel]
         for m in range(self.m):

@@ -51,6 +51,12 @@ int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const void* cols,
                      int Nb, int Hs, int Ws, int Hl, int Wl, int ks, int stride, int pad, int splitk, int dtype,
                      void* stream);
 
+/* Live HIP-event timing of the GEMM launches (measurement only; no reference counterpart). Every stride-th launch of
+ * each kernel class is timed on its launch stream; collect() synchronises and returns [16][3] = launches, seconds,
+ * algorithmic flops per class (classes: see csrc/igemm.hip). */
+int favae_prof_enable(int enabled, int stride);
+int favae_prof_collect(double* out48);
+
 /* ---- conv VAE: HBM-bound kernels ----------------------------------------------------------------------------- */
 
 /* nn.BatchNorm2d training statistics over the rows of raw [R][C] (cA/celeba_deepvanilla_vae.py:34,58,72): batch mean
