@@ -97,20 +97,29 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=202599, help="samples per GPU")
+    ap.add_argument("--samples", dest="n", type=int, default=202599, help="samples per GPU")
     ap.add_argument("--kc", type=int, default=50)
     ap.add_argument("--latent", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
+    if os.environ.get("FAVAE_HANG_DUMP"):                # debugging aid: dump all Python stacks after N seconds and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["FAVAE_HANG_DUMP"]), exit=True)
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FAVAE_DIST_BACKEND", "nccl") != "nccl":     # rehearsal of the N>1 path on a one-GPU box (gloo)
+        local = 0
+        os.environ["LOCAL_RANK"] = "0"
     torch.cuda.set_device(local)
     if ws > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda:%d" % local))
+        if os.environ.get("FAVAE_DIST_BACKEND", "nccl") == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda:%d" % local))
+        else:
+            torch.distributed.init_process_group(os.environ["FAVAE_DIST_BACKEND"])
     os.environ["FAVAE_CONV_DTYPE"] = a.dtype
 
     import favae

@@ -17,27 +17,37 @@ def rank():
     return td.get_rank() if active() else 0
 
 
+def _staged(t, fn):
+    """gloo (CPU tests / one-GPU rehearsal of the N>1 path) works on host memory: stage device tensors through it."""
+    if t.is_cuda and td.get_backend() != "nccl":
+        h = t.cpu()
+        fn(h)
+        t.copy_(h)
+    else:
+        fn(t)
+    return t
+
+
 def sum_(t):
-    """In-place sum over ranks of a device (or, under gloo, host) tensor."""
+    """In-place sum over ranks (RCCL all-reduce on the device buffer)."""
     if active():
-        td.all_reduce(t, op=td.ReduceOp.SUM)
+        _staged(t, lambda x: td.all_reduce(x, op=td.ReduceOp.SUM))
     return t
 
 
 def mean_(t):
-    """In-place mean over ranks.  RCCL has a native AVG; gloo (CPU tests) does not."""
+    """In-place mean over ranks.  RCCL has a native AVG; gloo does not."""
     if active():
         if td.get_backend() == "nccl":
             td.all_reduce(t, op=td.ReduceOp.AVG)
         else:
-            td.all_reduce(t, op=td.ReduceOp.SUM)
-            t /= td.get_world_size()
+            _staged(t, lambda x: (td.all_reduce(x, op=td.ReduceOp.SUM), x.div_(td.get_world_size())))
     return t
 
 
 def broadcast_(t, src=0):
     if active():
-        td.broadcast(t, src)
+        _staged(t, lambda x: td.broadcast(x, src))
     return t
 
 

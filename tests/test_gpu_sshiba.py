@@ -132,3 +132,60 @@ def test_full_variant_A_short_horizon_matches_oracle():
     _close(back.q_dist.Z["mean"], model.q_dist.Z["mean"], 0, 0)
     sd0, sd1 = model.img_vae[0].state_dict(), back.img_vae[0].state_dict()
     assert all(torch.equal(sd0[k], sd1[k]) for k in sd0)
+
+
+def _sharded_worker(rank, ws, port, q):
+    """One rank of the N-sharded FA-only fit (both ranks share the one GPU of the test box; gloo stands in for RCCL)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK="0")
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=ws)
+    for p in (os.path.dirname(PKG), PKG, os.path.join(os.path.dirname(PKG), "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from favae_hip import dist
+    fav = load_variant("condition_a_VAE")
+    X0, lab = fa_inputs(n=1001)
+    N = X0.shape[0]
+    lo, hi = dist.shard_bounds(N)
+    # make the sharded initialisation identical to the un-sharded one: every N-sized normal draw is made at full
+    # size on every rank (keeps the global stream in step) and sliced to the rank's rows
+    real = np.random.normal
+
+    def sliced(loc=0.0, scale=1.0, size=None):
+        if isinstance(size, (int, np.integer)) and size % (hi - lo) == 0 and np.ndim(loc) == 0:
+            d = size // (hi - lo)
+            return real(loc, scale, N * d).reshape(N, d)[lo:hi].reshape(-1)
+        return real(loc, scale, size)
+
+    np.random.normal = sliced
+    np.random.seed(0)
+    model = fav.SSHIBA(10, 1)
+    model.fit(model.struct_data(X0[lo:hi], "reg"), model.struct_data(lab[lo:hi], "mult"), max_iter=4, pruning_crit=1e-3,
+              verbose=0, store=False, pretrained=0)
+    q.put((rank, list(model.L), model.q_dist.W[1]["mean"], model.q_dist.Z["mean"], lo, hi))
+    td.destroy_process_group()
+
+
+def test_two_rank_sharded_fit_equals_single_rank_fit(golden):
+    """N-sharding: two ranks, each holding half of the rows and exchanging only reduced statistics,
+    reproduce the single-process fit -- and therefore the reference golden -- to fp64 re-association accuracy."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+    fav = load_variant("condition_a_VAE")
+    X0, lab = fa_inputs(n=1001)
+    np.random.seed(0)
+    ref = fav.SSHIBA(10, 1)
+    ref.fit(ref.struct_data(X0, "reg"), ref.struct_data(lab, "mult"), max_iter=4, pruning_crit=1e-3, verbose=0, store=False,
+            pretrained=0)
+    for rank, Ls, W1, Z, lo, hi in res:
+        _close(Ls, ref.L, 1e-10)
+        _close(W1, ref.q_dist.W[1]["mean"], 1e-9, 1e-12)
+        _close(Z, ref.q_dist.Z["mean"][lo:hi], 1e-9, 1e-11)
