@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int BK = 32;  // reduction elements per LDS stage
+constexpr int BK = 64;  // reduction elements per LDS stage
 
 // ---- optional live timing of the GEMM launches (bench.py roofline): every `stride`-th launch of each kernel class is
 // bracketed by HIP events on the launch stream; favae_prof_collect() resolves them after a synchronise. -----------
@@ -53,6 +53,8 @@ struct ProfScope {
         (void)hipEventRecord(g_prof.recs[idx].b, st);
     }
 };
+
+int g_force_kc_tile = -1, g_force_pm_tile = -1;  // developer override (favae_debug_force_tile), -1 = heuristic
 
 template <class T> struct Frag;
 template <> struct Frag<float> { float v[8]; };
@@ -430,21 +432,27 @@ int launch_kc(const KcParams& p, int classes, hipStream_t st) {
 template <class T, bool TR>
 int dispatch_kc(KcParams p, int classes, int target_blocks, hipStream_t st) {
     const bool slow = (p.Cin % BK) != 0;
-    int BM, BN;
-    if (slow) { BM = 64; BN = 64; }
-    else if (p.Cout <= 32 && !TR) { BM = 128; BN = 32; }
-    else if (p.Cout <= 64) { BN = 64; BM = p.M >= 4096 ? 128 : 64; }
-    else { BN = 128; BM = 128; if (p.M < 128 * 4) { BM = 64; BN = 64; } }
+    // Batch-64 layers are 2-5 GFLOP each: a 64x64 tile grid of 256-1024 blocks beats larger tiles with deeper split-K
+    // on every layer of the step (tools/tune_gemm.py sweep on MI355X), because the fp32 atomic traffic of split-K grows
+    // with the tile area while these grids already cover the 256 CUs.
+    int BM = 64, BN = 64;
+    if (!slow && p.Cout <= 32 && !TR) { BM = 128; BN = 32; }
+    if (!slow && g_force_kc_tile >= 0) {
+        static const int tb[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
+        BM = tb[g_force_kc_tile & 3][0]; BN = tb[g_force_kc_tile & 3][1];
+        if (TR && BN == 32) { BM = 64; BN = 64; }
+    }
     p.ntn = cdiv(p.Cout, BN);
     // split the reduction when the tile grid alone cannot fill 256 CUs
     const int ntap_max = p.ks * p.ks;
     const int nchunk = slow ? cdiv(ntap_max * p.Cin, BK) : ntap_max * (p.Cin / BK);
     const int blocks = cdiv(p.M, BM) * p.ntn * classes;
+    const bool prezeroed = p.splitk < 0;   // caller guarantees out == 0 (one pooled memset per step, vae_model.hip)
     int sk = 1;
     if (p.splitk > 0) sk = p.splitk;
-    else if (blocks < target_blocks) sk = std::min(std::max(1, nchunk / 4), cdiv(target_blocks, blocks));
+    else if (2 * blocks < target_blocks) sk = std::min(std::max(1, nchunk / 4), (target_blocks + blocks / 2) / blocks);
     p.splitk = std::max(1, std::min(sk, nchunk));
-    if (p.splitk > 1)
+    if (p.splitk > 1 && !prezeroed)
         FAVAE_HIP(hipMemsetAsync(p.out, 0, (size_t)p.Nb * p.Ho * p.Wo * p.Cout * sizeof(float), st));
     if (slow) return launch_kc<T, TR, true, 64, 64, 2, 2>(p, classes, st);
     if (BM == 128 && BN == 32) {
@@ -457,15 +465,17 @@ int dispatch_kc(KcParams p, int classes, int target_blocks, hipStream_t st) {
 
 template <class T>
 int dispatch_pm(PmParams p, hipStream_t st) {
-    int BM, BN;
+    int BM = 64, BN = 64;
     if (p.Rc <= 32) { BM = 32; BN = 128; }
     else if (p.Cc <= 32) { BM = 128; BN = 32; }
-    else if (p.Rc <= 64 || p.Cc <= 64) { BM = 64; BN = 64; }
-    else { BM = 128; BN = 128; }
+    if (g_force_pm_tile >= 0) {
+        static const int tb[4][2] = {{32, 128}, {128, 32}, {64, 64}, {128, 128}};
+        BM = tb[g_force_pm_tile & 3][0]; BN = tb[g_force_pm_tile & 3][1];
+    }
     p.ntn = cdiv(p.Cc, BN);
     const int nchunk = cdiv(p.K, BK);
     const int blocks = cdiv(p.Rc, BM) * p.ntn * p.ks * p.ks;
-    int sk = p.splitk > 0 ? p.splitk : std::min(std::max(1, nchunk / 4), cdiv(1024, blocks));
+    int sk = p.splitk > 0 ? p.splitk : std::min(std::max(1, nchunk / 8), std::max(1, (512 + blocks / 2) / blocks));
     p.splitk = std::max(1, std::min(sk, nchunk));
     dim3 grid(cdiv(p.Rc, BM) * p.ntn, p.splitk, p.ks * p.ks);
     ProfScope prof(BM == 32 ? 10 : BN == 32 ? 11 : BM == 64 ? 12 : 13, 2.0 * p.Rc * (double)p.Cc * p.K * p.ks * p.ks, st);
@@ -505,7 +515,7 @@ extern "C" int favae_conv_igemm(const void* in, const void* w, const float* bias
     p.M = Nb * p.HoC * p.WoC;
     p.ntn = 1;
     hipStream_t st = (hipStream_t)stream;
-    const int target = 512;
+    const int target = scatter ? 1024 : 512;
     if (dtype == FAVAE_F32) return scatter ? dispatch_kc<float, true>(p, classes, target, st) : dispatch_kc<float, false>(p, classes, target, st);
     return scatter ? dispatch_kc<bf16_t, true>(p, classes, target, st) : dispatch_kc<bf16_t, false>(p, classes, target, st);
 }
@@ -529,6 +539,12 @@ extern "C" int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const 
     p.splitk = splitk; p.ntn = 1; p.K = Nb * Hs * Ws;
     hipStream_t st = (hipStream_t)stream;
     return dtype == FAVAE_F32 ? dispatch_pm<float>(p, st) : dispatch_pm<bf16_t>(p, st);
+}
+
+extern "C" int favae_debug_force_tile(int kc_tile, int pm_tile) {
+    g_force_kc_tile = kc_tile;
+    g_force_pm_tile = pm_tile;
+    return FAVAE_OK;
 }
 
 /* Live kernel timing for bench.py: enable with a sampling stride, run, then collect per-class (launches, seconds, flops).

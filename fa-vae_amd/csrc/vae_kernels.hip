@@ -3,107 +3,215 @@
 // re-layout, batch gather.  All of them are HBM-bound column reductions or element-wise passes over NHWC
 // [rows][C] matrices.  Reference: condition_a_VAE/celeba_deepvanilla_vae.py (line numbers cited per kernel).
 #include <algorithm>
+#include <atomic>
 #include "common.h"
 #include "favae_hip.h"
 
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------
-// deterministic two-pass column reduction over a row-major [R][C] matrix
-//   pass 1: block (slab, channel tile) -> partial[slab][v][c]   (fp64)
-//   pass 2: a per-use "finish" kernel sums the slabs in a fixed order
+// deterministic column reduction over a row-major [R][C] matrix, one launch:
+//   every block (slab of rows, tile of channels) writes fp64 partial sums partial[slab][v][c]; the block that takes
+//   the last ticket of its channel tile adds the slabs in a fixed order and runs the per-channel finish functor.
+//   The result does not depend on which block happens to be last, so it is bit-reproducible.
+// Threads hold VW consecutive channels (16-byte loads for VW = 4).
 // ---------------------------------------------------------------------------------------------------------
-struct RedGeom { int CL, RG, ctiles, nslab, rps; };
+constexpr int TICKET_SLOTS = 4096;
+__device__ unsigned g_tickets[TICKET_SLOTS];   // zero at load; every launch leaves the slots it used at zero
+std::atomic<unsigned> g_ticket_next{0};        // host: rotating slot base, so launches on different streams do not share
+
+int ticket_base(int nslots, unsigned** out) {
+    static unsigned* per_device[64] = {nullptr};
+    int dev = 0;
+    FAVAE_HIP(hipGetDevice(&dev));
+    FAVAE_CHECK_ARG(dev >= 0 && dev < 64, "column reduction: device index %d", dev);
+    if (!per_device[dev]) FAVAE_HIP(hipGetSymbolAddress((void**)&per_device[dev], HIP_SYMBOL(g_tickets)));
+    const unsigned base = g_ticket_next.fetch_add((unsigned)nslots) % (unsigned)(TICKET_SLOTS - 256);
+    *out = per_device[dev] + base;
+    return FAVAE_OK;
+}
+
+struct RedGeom { int VW, TPR, RG, ctiles, nslab, rps; };
+
+constexpr int RED_THREADS = 1024;   // 16 waves: few, fat blocks keep the slab count (and the last block's tail) small
 
 RedGeom red_geom(long long R, int C) {
     RedGeom g;
-    g.CL = std::min(C, 64);
-    g.RG = 256 / g.CL;
-    g.ctiles = cdiv(C, g.CL);
-    int target = std::max(1, 1024 / g.ctiles);
-    long long min_rows = (long long)g.RG * 8;
+    g.VW = (C % 4 == 0) ? 4 : 1;
+    const int cv = C / g.VW, cap = g.VW == 4 ? 16 : 64;
+    g.TPR = 1;
+    while (g.TPR < cv && g.TPR < cap) g.TPR *= 2;
+    g.RG = RED_THREADS / g.TPR;
+    g.ctiles = cdiv(cv, g.TPR);
+    const int target = std::max(1, std::min(128, 512 / g.ctiles));
+    const long long min_rows = (long long)g.RG * 4;
     long long ns = std::max(1LL, std::min((long long)target, cdivll(R, min_rows)));
+    if (R <= (long long)g.RG * 4) ns = 1;    // a single slab needs no cross-block hand-over at all
     g.rps = (int)cdivll(R, ns);
     g.nslab = (int)cdivll(R, g.rps);
     return g;
 }
 
-template <int NV, class F>
-__global__ __launch_bounds__(256) void colreduce(int R, int C, int CL, int RG, int rps, double* partial, F f) {
-    __shared__ double sm[256 * NV];
-    const int tid = threadIdx.x, cl = tid % CL, rg = tid / CL;
-    const int c = blockIdx.y * CL + cl;
-    double acc[NV];
+template <int NV, int VW, class F>
+__global__ __launch_bounds__(RED_THREADS) void colreduce(int R, int C, int TPR, int rps, int nslab, double* partial,
+                                                         unsigned* tickets, F f) {
+    __shared__ double sm[NV * RED_THREADS];
+    __shared__ int is_last;
+    const int tid = threadIdx.x, tl = tid % TPR, rg = tid / TPR, RG = RED_THREADS / TPR;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int c0 = (blockIdx.y * TPR + tl) * VW;
+    const bool live = c0 < C;
+    double acc[NV][VW];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
-    if (rg < RG && c < C) {
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int j = 0; j < VW; ++j) acc[v][j] = 0.0;
+    if (live) {
+        typename F::Ctx ctx;
+        f.init(ctx, c0);
         const int r0 = blockIdx.x * rps, r1 = min(R, r0 + rps);
-        for (int r = r0 + rg; r < r1; r += RG) f(r, c, acc);
+#pragma unroll 4
+        for (int r = r0 + rg; r < r1; r += RG) f.row(ctx, r, c0, acc);
     }
+    // row groups of one wave (lanes tl, tl+TPR, ...) by a fixed xor tree, then the 16 waves in order
 #pragma unroll
-    for (int v = 0; v < NV; ++v) sm[v * 256 + tid] = acc[v];
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+            double t = acc[v][j];
+            for (int o = TPR; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+            if (lane < TPR) sm[((v * VW + j) * 16 + wave) * TPR + lane] = t;
+        }
     __syncthreads();
-    if (rg == 0 && c < C) {
+    if (nslab == 1) {
+        if (tid < TPR && live) {
+#pragma unroll
+            for (int j = 0; j < VW; ++j) {
+                double tot[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int w = 0; w < 16; ++w) t += sm[((v * VW + j) * 16 + w) * TPR + tid];
+                    tot[v] = 0.0 + t;   // same association as the multi-slab tail with one slab
+                }
+                f.finish(c0 + j, tot);
+            }
+        }
+        return;
+    }
+    if (tid < TPR && live) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int j = 0; j < VW; ++j) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) t += sm[((v * VW + j) * 16 + w) * TPR + tid];
+                __hip_atomic_store(&partial[((size_t)blockIdx.x * NV + v) * C + c0 + j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+    }
+    // The partial sums travel between blocks as agent-scope (write-through / cache-bypassing) atomic stores and loads, so
+    // only their completion has to be awaited before the ticket is taken: no L2 write-back fence per block.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) is_last = __hip_atomic_fetch_add(&tickets[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nslab - 1);
+    __syncthreads();
+    if (!is_last) return;
+    // last block of this channel tile: CT channels x (1024 / CT) slab parts, at most 8 loads per thread and value
+    const int CT = TPR * VW, ch = tid % CT, part = tid / CT, parts = RED_THREADS / CT;
+    const int c = blockIdx.y * CT + ch;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = part + q * parts;
+            x[q] = (c < C && i < nslab) ? __hip_atomic_load(&partial[((size_t)i * NV + v) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += x[q];
+        sm[v * RED_THREADS + tid] = t;
+    }
+    __syncthreads();
+    if (tid < CT && c < C) {
+        double tot[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            double s = 0.0;
-            for (int g = 0; g < RG; ++g) s += sm[v * 256 + g * CL + cl];
-            partial[((size_t)blockIdx.x * NV + v) * C + c] = s;
+            double t = 0.0;
+            for (int q = 0; q < parts; ++q) t += sm[v * RED_THREADS + q * CT + tid];
+            tot[v] = t;
         }
+        f.finish(c, tot);
     }
+    if (tid == 0) __hip_atomic_store(&tickets[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int NV, class F>
-int run_colreduce(long long R, int C, double* partial, size_t partial_cap, RedGeom& g, F f, hipStream_t st) {
-    g = red_geom(R, C);
+int run_colreduce(long long R, int C, double* partial, size_t partial_cap, F f, hipStream_t st) {
+    const RedGeom g = red_geom(R, C);
     FAVAE_CHECK_ARG((size_t)g.nslab * NV * C <= partial_cap, "column reduction: scratch too small (%zu < %zu doubles)",
                     partial_cap, (size_t)g.nslab * NV * C);
-    hipLaunchKernelGGL((colreduce<NV, F>), dim3(g.nslab, g.ctiles), dim3(256), 0, st, (int)R, C, g.CL, g.RG, g.rps, partial, f);
+    FAVAE_CHECK_ARG(g.ctiles <= 256, "column reduction: too many channels (%d)", C);
+    unsigned* tickets = nullptr;
+    int trc = ticket_base(g.ctiles, &tickets);
+    if (trc) return trc;
+    if (g.VW == 4)
+        hipLaunchKernelGGL((colreduce<NV, 4, F>), dim3(g.nslab, g.ctiles), dim3(RED_THREADS), 0, st, (int)R, C, g.TPR, g.rps, g.nslab, partial, tickets, f);
+    else
+        hipLaunchKernelGGL((colreduce<NV, 1, F>), dim3(g.nslab, g.ctiles), dim3(RED_THREADS), 0, st, (int)R, C, g.TPR, g.rps, g.nslab, partial, tickets, f);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }
 
-// finish kernels: 256 threads = 8 channels x 32 slab-parts; every part sums a strided subset of the slabs, the 32
-// parts are combined by a fixed xor tree (deterministic).  FIN_GRID(C) blocks.
-#define FIN_GRID(C) dim3(cdiv((C), 8))
-#define FIN_BLOCK dim3(256)
-__device__ __forceinline__ double slab_sum(const double* partial, int nslab, int nv, int v, int C, int c) {
-    const int part = threadIdx.x & 31;
-    double s = 0.0;
-    if (c < C)
-        for (int i = part; i < nslab; i += 32) s += partial[((size_t)i * nv + v) * C + c];
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    return s;
-}
-#define FIN_CHANNEL() (blockIdx.x * 8 + (threadIdx.x >> 5))
-#define FIN_LEADER() ((threadIdx.x & 31) == 0)
+template <class T, int VW> struct VecLoad;
+template <> struct VecLoad<float, 4> {
+    static __device__ __forceinline__ void ld(const float* p, float* o) { const float4 v = *(const float4*)p; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    static __device__ __forceinline__ void st(float* p, const float* o) { *(float4*)p = make_float4(o[0], o[1], o[2], o[3]); }
+};
+template <> struct VecLoad<bf16_t, 4> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float* o) {
+        const uint2 u = *(const uint2*)p;
+        o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+        o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float* o) {
+        uint2 u;
+        u.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+        u.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+        *(uint2*)p = u;
+    }
+};
+template <class T> struct VecLoad<T, 1> {
+    static __device__ __forceinline__ void ld(const T* p, float* o) { o[0] = to_f32<T>(*p); }
+    static __device__ __forceinline__ void st(T* p, const float* o) { *p = from_f32<T>(o[0]); }
+};
 
 // ---- BatchNorm2d (train) statistics: nn.BatchNorm2d(h_dim), celeba_deepvanilla_vae.py:34,58,72 -------------
 struct StatsF {
-    const float* x; int C;
-    __device__ void operator()(int r, int c, double* acc) const {
-        const double v = x[(size_t)r * C + c];
-        acc[0] += v; acc[1] += v * v;
+    const float* x; int C; double R; float eps, mom; float *mean, *invstd, *run_mean, *run_var;
+    struct Ctx {};
+    __device__ void init(Ctx&, int) const {}
+    template <int VW> __device__ void row(const Ctx&, int r, int c0, double (*acc)[VW]) const {
+        float v[VW];
+        VecLoad<float, VW>::ld(x + (size_t)r * C + c0, v);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) { acc[0][j] += v[j]; acc[1][j] += (double)v[j] * v[j]; }
+    }
+    __device__ void finish(int c, const double* tot) const {
+        const double m = tot[0] / R;
+        double var = tot[1] / R - m * m;
+        if (var < 0) var = 0;
+        mean[c] = (float)m;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (run_mean) {
+            const double unb = R > 1 ? var * R / (R - 1) : var;
+            run_mean[c] = (1.f - mom) * run_mean[c] + mom * (float)m;
+            run_var[c] = (1.f - mom) * run_var[c] + mom * (float)unb;
+        }
     }
 };
-
-__global__ void bn_stats_finish(const double* partial, int nslab, int C, double R, float eps, float mom, float* mean,
-                                float* invstd, float* run_mean, float* run_var) {
-    const int c = FIN_CHANNEL();
-    const double s = slab_sum(partial, nslab, 2, 0, C, c), s2 = slab_sum(partial, nslab, 2, 1, C, c);
-    if (c >= C || !FIN_LEADER()) return;
-    const double m = s / R;
-    double var = s2 / R - m * m;
-    if (var < 0) var = 0;
-    mean[c] = (float)m;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (run_mean) {
-        const double unb = R > 1 ? var * R / (R - 1) : var;
-        run_mean[c] = (1.f - mom) * run_mean[c] + mom * (float)m;
-        run_var[c] = (1.f - mom) * run_var[c] + mom * (float)unb;
-    }
-}
 
 __global__ void bn_eval_prep(const float* run_mean, const float* run_var, int C, float eps, float* mean, float* invstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -156,51 +264,74 @@ __global__ __launch_bounds__(256) void bn_lrelu_fwd(const float* __restrict__ ra
 template <class T>
 struct BnBwdRedF {
     const float* dact; const T* act; const float* raw; const float* mean; const float* invstd; int C;
-    __device__ void operator()(int r, int c, double* acc) const {
-        const size_t i = (size_t)r * C + c;
-        const float a = to_f32<T>(act[i]);
-        const float d = dact[i] * (a > 0.f ? 1.f : 0.01f);
-        const float xh = (raw[i] - mean[c]) * invstd[c];
-        acc[0] += d; acc[1] += (double)d * xh;
+    float *dgamma, *dbeta, *s1s2;
+    struct Ctx { float mu[4], is[4]; };
+    __device__ void init(Ctx& k, int c0) const {
+        for (int j = 0; j < 4 && c0 + j < C; ++j) { k.mu[j] = mean[c0 + j]; k.is[j] = invstd[c0 + j]; }
+    }
+    template <int VW> __device__ void row(const Ctx& k, int r, int c0, double (*acc)[VW]) const {
+        const size_t i = (size_t)r * C + c0;
+        float a[VW], d[VW], x[VW];
+        VecLoad<T, VW>::ld(act + i, a);
+        VecLoad<float, VW>::ld(dact + i, d);
+        VecLoad<float, VW>::ld(raw + i, x);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+            const float dd = d[j] * (a[j] > 0.f ? 1.f : 0.01f);
+            const float xh = (x[j] - k.mu[j]) * k.is[j];
+            acc[0][j] += dd; acc[1][j] += (double)dd * xh;
+        }
+    }
+    __device__ void finish(int c, const double* tot) const {
+        dbeta[c] = (float)tot[0];
+        dgamma[c] = (float)tot[1];
+        s1s2[c] = (float)tot[0];
+        s1s2[C + c] = (float)tot[1];
     }
 };
-
-__global__ void bn_bwd_finish(const double* partial, int nslab, int C, float* dgamma, float* dbeta, float* s1s2) {
-    const int c = FIN_CHANNEL();
-    const double s1 = slab_sum(partial, nslab, 2, 0, C, c), s2 = slab_sum(partial, nslab, 2, 1, C, c);
-    if (c >= C || !FIN_LEADER()) return;
-    dbeta[c] = (float)s1;
-    dgamma[c] = (float)s2;
-    s1s2[c] = (float)s1;
-    s1s2[C + c] = (float)s2;
-}
 
 template <class T>
 struct BnBwdApplyF {
     const float* dact; const T* act; const float* raw; const float* mean; const float* invstd; const float* gamma;
-    const float* s1s2; T* draw; int C; float invR;
-    __device__ void operator()(int r, int c, double* acc) const {
-        const size_t i = (size_t)r * C + c;
-        const float a = to_f32<T>(act[i]);
-        const float d = dact[i] * (a > 0.f ? 1.f : 0.01f);
-        const float xh = (raw[i] - mean[c]) * invstd[c];
-        const float g = gamma[c] * invstd[c] * (d - s1s2[c] * invR - xh * s1s2[C + c] * invR);
-        draw[i] = from_f32<T>(g);
-        acc[0] += g;
+    const float* s1s2; T* draw; int C; float invR; float* dbias;
+    struct Ctx { float mu[4], is[4], gi[4], k1[4], k2[4]; };
+    __device__ void init(Ctx& k, int c0) const {
+        for (int j = 0; j < 4 && c0 + j < C; ++j) {
+            k.mu[j] = mean[c0 + j]; k.is[j] = invstd[c0 + j]; k.gi[j] = gamma[c0 + j] * invstd[c0 + j];
+            k.k1[j] = s1s2[c0 + j] * invR; k.k2[j] = s1s2[C + c0 + j] * invR;
+        }
     }
+    template <int VW> __device__ void row(const Ctx& k, int r, int c0, double (*acc)[VW]) const {
+        const size_t i = (size_t)r * C + c0;
+        float a[VW], d[VW], x[VW], g[VW];
+        VecLoad<T, VW>::ld(act + i, a);
+        VecLoad<float, VW>::ld(dact + i, d);
+        VecLoad<float, VW>::ld(raw + i, x);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+            const float dd = d[j] * (a[j] > 0.f ? 1.f : 0.01f);
+            const float xh = (x[j] - k.mu[j]) * k.is[j];
+            g[j] = k.gi[j] * (dd - k.k1[j] - xh * k.k2[j]);
+            acc[0][j] += g[j];
+        }
+        VecLoad<T, VW>::st(draw + i, g);
+    }
+    __device__ void finish(int c, const double* tot) const { if (dbias) dbias[c] = (float)tot[0]; }
 };
 
 template <class T>
 struct ColsumF {
-    const T* x; int C;
-    __device__ void operator()(int r, int c, double* acc) const { acc[0] += to_f32<T>(x[(size_t)r * C + c]); }
+    const T* x; int C; float* out;
+    struct Ctx {};
+    __device__ void init(Ctx&, int) const {}
+    template <int VW> __device__ void row(const Ctx&, int r, int c0, double (*acc)[VW]) const {
+        float v[VW];
+        VecLoad<T, VW>::ld(x + (size_t)r * C + c0, v);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) acc[0][j] += v[j];
+    }
+    __device__ void finish(int c, const double* tot) const { out[c] = (float)tot[0]; }
 };
-
-__global__ void colsum_finish(const double* partial, int nslab, int C, float* out) {
-    const int c = FIN_CHANNEL();
-    const double v = slab_sum(partial, nslab, 1, 0, C, c);
-    if (c < C && FIN_LEADER()) out[c] = (float)v;
-}
 
 // ---- reparameterise + KL(q || N(mu_P, 1/tau)) : celeba_deepvanilla_vae.py:86-92,137-150,231-232 --------------
 // one block; B*z is at most a few tens of thousands of elements
@@ -369,6 +500,44 @@ __global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w,
     }
 }
 
+struct WprepTable {
+    const float* w[16]; void* wc[16]; void* wt[16];
+    int Co[16], taps[16], Ci[16], start[17];
+};
+template <class T>
+__global__ __launch_bounds__(256) void wprep_batch_kernel(const WprepTable tb, int n) {
+    __shared__ float tile[32][33];
+    int l = 0;
+    while (l + 1 < n && (int)blockIdx.x >= tb.start[l + 1]) ++l;
+    const int Co = tb.Co[l], taps = tb.taps[l], Ci = tb.Ci[l];
+    const float* __restrict__ w = tb.w[l];
+    T* __restrict__ wc = (T*)tb.wc[l];
+    T* __restrict__ wt = (T*)tb.wt[l];
+    int b = blockIdx.x - tb.start[l];
+    const int nci = (Ci + 31) / 32, nco = (Co + 31) / 32;
+    const int ci0 = (b % nci) * 32; b /= nci;
+    const int co0 = (b % nco) * 32;
+    const int tap = b / nco;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int co = co0 + i, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < Co && ci < Ci) {
+            const size_t o = ((size_t)co * taps + tap) * Ci + ci;
+            v = w[o];
+            if (wc) wc[o] = from_f32<T>(v);
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    if (wt) {
+        for (int i = ty; i < 32; i += 8) {
+            const int ci = ci0 + i, co = co0 + tx;
+            if (co < Co && ci < Ci) wt[((size_t)ci * taps + tap) * Co + co] = from_f32<T>(tile[tx][i]);
+        }
+    }
+}
+
 // ---- batch gather: rows of the resident fp32 NHWC dataset -> fp32 batch (LL target) + T batch (conv input) ----
 template <class T>
 __global__ __launch_bounds__(256) void gather_batch(const float* __restrict__ data, const int* __restrict__ idx, int B,
@@ -414,13 +583,7 @@ inline int ew_grid(size_t n) { return (int)std::min<size_t>(4096, std::max<size_
 extern "C" int favae_bn_stats(const float* raw, long long R, int C, float eps, float momentum, float* mean, float* invstd,
                               float* run_mean, float* run_var, double* scratch, size_t scratch_doubles, void* stream) {
     FAVAE_CHECK_ARG(raw && mean && invstd && scratch && R > 0 && C > 0 && R < (1LL << 31), "favae_bn_stats: bad argument");
-    RedGeom g;
-    int rc = run_colreduce<2>(R, C, scratch, scratch_doubles, g, StatsF{raw, C}, ST);
-    if (rc) return rc;
-    hipLaunchKernelGGL(bn_stats_finish, FIN_GRID(C), FIN_BLOCK, 0, ST, scratch, g.nslab, C, (double)R, eps, momentum, mean,
-                       invstd, run_mean, run_var);
-    FAVAE_LAUNCH_CHECK();
-    return FAVAE_OK;
+    return run_colreduce<2>(R, C, scratch, scratch_doubles, StatsF{raw, C, (double)R, eps, momentum, mean, invstd, run_mean, run_var}, ST);
 }
 
 extern "C" int favae_bn_eval_prep(const float* run_mean, const float* run_var, int C, float eps, float* mean, float* invstd,
@@ -447,19 +610,10 @@ template <class T>
 static int bn_bwd_impl(const float* dact, const T* act, const float* raw, const float* mean, const float* invstd,
                        const float* gamma, T* draw, float* dgamma, float* dbeta, float* dbias, long long R, int C,
                        double* scratch, size_t cap, float* s1s2, hipStream_t st) {
-    RedGeom g;
-    int rc = run_colreduce<2>(R, C, scratch, cap, g, BnBwdRedF<T>{dact, act, raw, mean, invstd, C}, st);
+    int rc = run_colreduce<2>(R, C, scratch, cap, BnBwdRedF<T>{dact, act, raw, mean, invstd, C, dgamma, dbeta, s1s2}, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finish, FIN_GRID(C), FIN_BLOCK, 0, st, scratch, g.nslab, C, dgamma, dbeta, s1s2);
-    FAVAE_LAUNCH_CHECK();
-    rc = run_colreduce<1>(R, C, scratch, cap, g,
-                          BnBwdApplyF<T>{dact, act, raw, mean, invstd, gamma, s1s2, draw, C, (float)(1.0 / (double)R)}, st);
-    if (rc) return rc;
-    if (dbias) {
-        hipLaunchKernelGGL(colsum_finish, FIN_GRID(C), FIN_BLOCK, 0, st, scratch, g.nslab, C, dbias);
-        FAVAE_LAUNCH_CHECK();
-    }
-    return FAVAE_OK;
+    return run_colreduce<1>(R, C, scratch, cap,
+                            BnBwdApplyF<T>{dact, act, raw, mean, invstd, gamma, s1s2, draw, C, (float)(1.0 / (double)R), dbias}, st);
 }
 
 extern "C" int favae_bn_lrelu_bwd(const float* dact, const void* act, const float* raw, const float* mean,
@@ -477,13 +631,8 @@ extern "C" int favae_bn_lrelu_bwd(const float* dact, const void* act, const floa
 extern "C" int favae_colsum(const void* x, long long R, int C, float* out, double* scratch, size_t scratch_doubles, int dtype,
                             void* stream) {
     FAVAE_CHECK_ARG(x && out && scratch && R > 0 && R < (1LL << 31) && C > 0, "favae_colsum: bad argument");
-    RedGeom g;
-    int rc = dtype == FAVAE_F32 ? run_colreduce<1>(R, C, scratch, scratch_doubles, g, ColsumF<float>{(const float*)x, C}, ST)
-                                : run_colreduce<1>(R, C, scratch, scratch_doubles, g, ColsumF<bf16_t>{(const bf16_t*)x, C}, ST);
-    if (rc) return rc;
-    hipLaunchKernelGGL(colsum_finish, FIN_GRID(C), FIN_BLOCK, 0, ST, scratch, g.nslab, C, out);
-    FAVAE_LAUNCH_CHECK();
-    return FAVAE_OK;
+    return dtype == FAVAE_F32 ? run_colreduce<1>(R, C, scratch, scratch_doubles, ColsumF<float>{(const float*)x, C, out}, ST)
+                              : run_colreduce<1>(R, C, scratch, scratch_doubles, ColsumF<bf16_t>{(const bf16_t*)x, C, out}, ST);
 }
 
 extern "C" int favae_reparam_kl_fwd(const float* fc, const float* eps, const double* prior, const int* idx, float tau, int B,
@@ -570,6 +719,27 @@ extern "C" int favae_weight_prep(const float* w, void* w_copy, void* w_transpose
         hipLaunchKernelGGL(wprep_kernel<float>, grid, dim3(256), 0, ST, w, (float*)w_copy, (float*)w_transposed, Co, taps, Ci);
     else
         hipLaunchKernelGGL(wprep_kernel<bf16_t>, grid, dim3(256), 0, ST, w, (bf16_t*)w_copy, (bf16_t*)w_transposed, Co, taps, Ci);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_weight_prep_batch(int n, const float* const* w, void* const* w_copy, void* const* w_transposed,
+                                       const int* Co, const int* taps, const int* Ci, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(n >= 1 && n <= 16 && w && w_copy && w_transposed && Co && taps && Ci, "favae_weight_prep_batch: bad argument");
+    WprepTable tb;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        FAVAE_CHECK_ARG(w[i] && Co[i] > 0 && taps[i] > 0 && Ci[i] > 0 && (w_copy[i] || w_transposed[i]), "favae_weight_prep_batch: tensor %d", i);
+        tb.w[i] = w[i]; tb.wc[i] = w_copy[i]; tb.wt[i] = w_transposed[i];
+        tb.Co[i] = Co[i]; tb.taps[i] = taps[i]; tb.Ci[i] = Ci[i];
+        tb.start[i] = total;
+        total += cdiv(Ci[i], 32) * cdiv(Co[i], 32) * taps[i];
+    }
+    tb.start[n] = total;
+    if (dtype == FAVAE_F32)
+        hipLaunchKernelGGL(wprep_batch_kernel<float>, dim3(total), dim3(256), 0, ST, tb, n);
+    else
+        hipLaunchKernelGGL(wprep_batch_kernel<bf16_t>, dim3(total), dim3(256), 0, ST, tb, n);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

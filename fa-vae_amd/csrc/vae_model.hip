@@ -3,6 +3,7 @@
 // igemm.hip and vae_kernels.hip.  The host passes device buffers (PyTorch tensors used as memory); this file owns
 // the layer table, the carve-up of the workspace and the launch order.  Nothing here allocates device memory.
 #include <algorithm>
+#include <cstdlib>
 #include <new>
 #include <vector>
 #include "common.h"
@@ -77,6 +78,11 @@ struct Vae {
     char *xt, *zlat;
     double *scratch, *metrics2;
     size_t scratch_doubles;
+    // split-K targets small enough to be zeroed by one memset per training step
+    bool raw_pooled[NL], dact_pooled[NL];
+    char* zero_lo; size_t zero_bytes;
+    // weight gradients run on a second stream next to the dgrad -> BN-backward chain of the main stream
+    hipStream_t side; hipEvent_t ev_fork[NL]; hipEvent_t ev_join; bool overlap;
     const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(SH + L[l].wc_off * esz); }
     const void* Wt(int l) const { return (const void*)(SH + L[l].wt_off * esz); }
     long long rows(int l, int B) const { return (long long)B * L[l].Hout * L[l].Hout; }
@@ -95,11 +101,30 @@ struct Carver {
 void carve(Vae& v, char* base, size_t cap, size_t* need) {
     Carver c{base, 0, cap};
     const int B = v.Bmax;
+    // zero pool first: the fp32 conv outputs (raw) and input gradients (dact) of the layers whose GEMMs may split the
+    // reduction, i.e. the small ones; everything in [zero_lo, zero_lo + zero_bytes) is cleared once per training step
+    const size_t pool_max = (size_t)1 << 20;   // elements
+    v.zero_lo = (char*)c.take(0);
     for (int l = 0; l < NL; ++l) {
         const size_t n = (size_t)v.rows(l, B) * v.L[l].Cout;
-        v.raw[l] = (float*)c.take(n * 4);
+        v.raw_pooled[l] = v.dact_pooled[l] = n <= pool_max;
+        if (n <= pool_max) {
+            v.raw[l] = (float*)c.take(n * 4);
+            v.dact[l] = (float*)c.take(n * 4);
+        }
+    }
+    v.dz = (float*)c.take((size_t)B * v.z * 4);
+    {
+        char* end = (char*)c.take(0);
+        v.zero_bytes = (size_t)(end - v.zero_lo);
+    }
+    for (int l = 0; l < NL; ++l) {
+        const size_t n = (size_t)v.rows(l, B) * v.L[l].Cout;
+        if (n > pool_max) {
+            v.raw[l] = (float*)c.take(n * 4);
+            v.dact[l] = (float*)c.take(n * 4);
+        }
         v.act[l] = (char*)c.take(n * v.esz);
-        v.dact[l] = (float*)c.take(n * 4);
         v.draw[l] = (char*)c.take(n * v.esz);
         v.mean[l] = (float*)c.take((size_t)v.L[l].Cout * 4);
         v.invstd[l] = (float*)c.take((size_t)v.L[l].Cout * 4);
@@ -109,7 +134,6 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
     v.xt = (char*)c.take(img * v.esz);
     v.zlat = (char*)c.take((size_t)B * v.z * v.esz);
     v.stdq = (float*)c.take((size_t)B * v.z * 4);
-    v.dz = (float*)c.take((size_t)B * v.z * 4);
     v.s1s2 = (float*)c.take(2 * 1024 * 4);
     v.scratch_doubles = 2 * 1024 * 64 + 4096;
     v.scratch = (double*)c.take(v.scratch_doubles * 8);
@@ -119,18 +143,19 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
 
 #define RC(x) do { int rc_ = (x); if (rc_ != FAVAE_OK) return rc_; } while (0)
 
-int conv_fwd(Vae& v, int l, const void* in, int B, void* st) {
+int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false) {
     const Layer& L = v.L[l];
     const float* bias = v.P + L.b_off;
+    const int sk = (pooled && v.raw_pooled[l]) ? -1 : 0;
     switch (L.kind) {
     case CONV_S2:
-        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 2, 1, 0, 0, v.dtype, st);
+        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 2, 1, 0, sk, v.dtype, st);
     case CONV_S1:
-        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 1, 1, 0, 0, v.dtype, st);
+        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 1, 1, 0, sk, v.dtype, st);
     case CONVT_S2:
-        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 2, 1, 1, 0, v.dtype, st);
+        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 2, 1, 1, sk, v.dtype, st);
     default:
-        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, 1, 1, L.Cin, 1, 1, L.Cout, 1, 1, 0, 0, 0, v.dtype, st);
+        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, 1, 1, L.Cin, 1, 1, L.Cout, 1, 1, 0, 0, sk, v.dtype, st);
     }
 }
 
@@ -144,26 +169,26 @@ int bn_fwd(Vae& v, int l, int B, bool train, void* st) {
     return favae_bn_lrelu_fwd(v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.P + L.be_off, v.act[l], R, L.Cout, 1, v.dtype, st);
 }
 
-int encoder_fwd(Vae& v, int B, bool train, void* st) {
+int encoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false) {
     const void* in = v.xt;
     for (int l = 0; l < 5; ++l) {
-        RC(conv_fwd(v, l, in, B, st));
+        RC(conv_fwd(v, l, in, B, st, pooled));
         RC(bn_fwd(v, l, B, train, st));
         in = v.act[l];
     }
-    return conv_fwd(v, L_FC, in, B, st);
+    return conv_fwd(v, L_FC, in, B, st, pooled);
 }
 
-int decoder_fwd(Vae& v, int B, bool train, void* st) {
-    RC(conv_fwd(v, L_DI, v.zlat, B, st));
+int decoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false) {
+    RC(conv_fwd(v, L_DI, v.zlat, B, st, pooled));
     RC(favae_cast(v.raw[L_DI], v.act[L_DI], (long long)B * 4096, v.dtype, st));
     const void* in = v.act[L_DI];
     for (int l = 7; l <= 11; ++l) {
-        RC(conv_fwd(v, l, in, B, st));
+        RC(conv_fwd(v, l, in, B, st, pooled));
         RC(bn_fwd(v, l, B, train, st));
         in = v.act[l];
     }
-    return conv_fwd(v, L_OUT, in, B, st);
+    return conv_fwd(v, L_OUT, in, B, st, pooled);
 }
 
 int bn_bwd(Vae& v, int l, int B, void* st) {
@@ -172,8 +197,18 @@ int bn_bwd(Vae& v, int l, int B, void* st) {
                               v.G + L.be_off, v.G + L.b_off, v.rows(l, B), L.Cout, v.scratch, v.scratch_doubles, v.s1s2, v.dtype, st);
 }
 
-// weight gradient of layer l given draw[l] and the layer input
+int wgrad_launch(Vae& v, int l, const void* in, int B, void* st);
+
+// weight gradient of layer l given draw[l] (just produced on the main stream) and the layer input; with overlap on it
+// is queued on the side stream behind an event, so the main stream continues with the input gradient at once
 int wgrad(Vae& v, int l, const void* in, int B, void* st) {
+    if (!v.overlap) return wgrad_launch(v, l, in, B, st);
+    FAVAE_HIP(hipEventRecord(v.ev_fork[l], (hipStream_t)st));
+    FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_fork[l], 0));
+    return wgrad_launch(v, l, in, B, (void*)v.side);
+}
+
+int wgrad_launch(Vae& v, int l, const void* in, int B, void* st) {
     const Layer& L = v.L[l];
     float* dw = v.G + L.w_off;
     switch (L.kind) {
@@ -189,17 +224,18 @@ int wgrad(Vae& v, int l, const void* in, int B, void* st) {
 }
 
 // input gradient of layer l: draw[l] -> out (fp32, shaped like the layer input)
-int dgrad(Vae& v, int l, float* out, int B, void* st) {
+int dgrad(Vae& v, int l, float* out, int B, void* st, bool out_zeroed) {
     const Layer& L = v.L[l];
+    const int sk = out_zeroed ? -1 : 0;
     switch (L.kind) {
     case CONV_S2:   // scatter form with [Cin][tap][Cout]
-        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, 2, 1, 1, 0, v.dtype, st);
+        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, 2, 1, 1, sk, v.dtype, st);
     case CONV_S1:
-        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, 1, 1, 1, 0, v.dtype, st);
+        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, 1, 1, 1, sk, v.dtype, st);
     case CONVT_S2:  // gather form
-        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, 2, 1, 0, 0, v.dtype, st);
+        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, 2, 1, 0, sk, v.dtype, st);
     default:
-        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, 1, 1, L.Cout, 1, 1, L.Cin, 1, 1, 0, 0, 0, v.dtype, st);
+        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, 1, 1, L.Cout, 1, 1, L.Cin, 1, 1, 0, 0, sk, v.dtype, st);
     }
 }
 
@@ -264,11 +300,30 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
         favae_set_error("favae_vae_create: workspace %zu < %zu or shadow %zu < %zu", workspace_bytes, need, shadow_bytes, (size_t)v.nshadow * v.esz);
         return FAVAE_ERR_ARG;
     }
+    const char* e = getenv("FAVAE_SINGLE_STREAM");
+    v.overlap = !(e && e[0] == '1');
+    v.side = nullptr;
+    if (v.overlap) {
+        bool ok = hipStreamCreateWithFlags(&v.side, hipStreamNonBlocking) == hipSuccess;
+        for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_fork[l], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&v.ev_join, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            delete h;
+            favae_set_error("favae_vae_create: could not create the side stream / events");
+            return FAVAE_ERR_HIP;
+        }
+    }
     *out = h;
     return FAVAE_OK;
 }
 
 extern "C" int favae_vae_destroy(favae_vae* h) {
+    if (h && h->v.overlap && h->v.side) {
+        (void)hipStreamSynchronize(h->v.side);
+        for (int l = 0; l < NL; ++l) (void)hipEventDestroy(h->v.ev_fork[l]);
+        (void)hipEventDestroy(h->v.ev_join);
+        (void)hipStreamDestroy(h->v.side);
+    }
     delete h;
     return FAVAE_OK;
 }
@@ -277,13 +332,17 @@ extern "C" int favae_vae_destroy(favae_vae* h) {
 extern "C" int favae_vae_refresh_weights(favae_vae* h, void* st) {
     FAVAE_CHECK_ARG(h, "favae_vae_refresh_weights: null handle");
     Vae& v = h->v;
+    const float* w[16]; void* wc[16]; void* wt[16]; int Co[16], taps[16], Ci[16];
+    int n = 0;
     for (int l = 0; l < NL; ++l) {
         const Layer& L = v.L[l];
-        void* wc = L.wc_off >= 0 ? v.SH + L.wc_off * v.esz : nullptr;
-        void* wt = L.wt_off >= 0 ? v.SH + L.wt_off * v.esz : nullptr;
-        if (wc || wt) RC(favae_weight_prep(v.P + L.w_off, wc, wt, L.Cout, L.taps, L.Cin, v.dtype, st));
+        void* c = L.wc_off >= 0 ? v.SH + L.wc_off * v.esz : nullptr;
+        void* t = L.wt_off >= 0 ? v.SH + L.wt_off * v.esz : nullptr;
+        if (!c && !t) continue;
+        w[n] = v.P + L.w_off; wc[n] = c; wt[n] = t; Co[n] = L.Cout; taps[n] = L.taps; Ci[n] = L.Cin;
+        ++n;
     }
-    return FAVAE_OK;
+    return n ? favae_weight_prep_batch(n, w, wc, wt, Co, taps, Ci, v.dtype, st) : FAVAE_OK;
 }
 
 /* One forward + backward of the training step (cA/celeba_deepvanilla_vae.py:229-249): gradients land in the grads
@@ -294,36 +353,41 @@ extern "C" int favae_vae_train_fwdbwd(favae_vae* h, const float* data_nhwc, cons
     Vae& v = h->v;
     FAVAE_CHECK_ARG(B >= 1 && B <= v.Bmax, "favae_vae_train_fwdbwd: batch %d outside [1, %d]", B, v.Bmax);
     FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));
+    FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, (hipStream_t)st));
     RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, v.xf, v.xt, v.dtype, st));
-    RC(encoder_fwd(v, B, true, st));
+    RC(encoder_fwd(v, B, true, st, true));
     RC(favae_reparam_kl_fwd(v.raw[L_FC], eps, prior, idx, tau, B, v.z, v.zlat, v.stdq, metrics2_out + 1, v.dtype, st));
-    RC(decoder_fwd(v, B, true, st));
+    RC(decoder_fwd(v, B, true, st, true));
     const long long D = (long long)64 * 64 * v.ch;
     RC(favae_sigmoid_ll(v.raw[L_OUT], v.xf, B, D, var_x, v.draw[L_OUT], metrics2_out, v.scratch, v.scratch_doubles, v.dtype, st));
     // ---- backward ----
     RC(favae_colsum(v.draw[L_OUT], v.rows(L_OUT, B), v.ch, v.G + v.L[L_OUT].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
     RC(wgrad(v, L_OUT, v.act[11], B, st));
-    RC(dgrad(v, L_OUT, v.dact[11], B, st));
+    RC(dgrad(v, L_OUT, v.dact[11], B, st, v.dact_pooled[11]));
     for (int l = 11; l >= 7; --l) {
         RC(bn_bwd(v, l, B, st));
         RC(wgrad(v, l, v.act[l - 1], B, st));
-        RC(dgrad(v, l, v.dact[l - 1], B, st));
+        RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1]));
     }
     RC(favae_cast(v.dact[L_DI], v.draw[L_DI], (long long)B * 4096, v.dtype, st));
     RC(favae_colsum(v.draw[L_DI], B, 4096, v.G + v.L[L_DI].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
     RC(wgrad(v, L_DI, v.zlat, B, st));
-    RC(dgrad(v, L_DI, v.dz, B, st));
+    RC(dgrad(v, L_DI, v.dz, B, st, true));
     RC(favae_reparam_kl_bwd(v.raw[L_FC], eps, prior, idx, v.stdq, v.dz, tau, beta, B, v.z, v.draw[L_FC], v.dtype, st));
     RC(favae_colsum(v.draw[L_FC], B, 2 * v.z, v.G + v.L[L_FC].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
     RC(wgrad(v, L_FC, v.act[4], B, st));
-    RC(dgrad(v, L_FC, v.dact[4], B, st));
+    RC(dgrad(v, L_FC, v.dact[4], B, st, v.dact_pooled[4]));
     for (int l = 4; l >= 1; --l) {
         RC(bn_bwd(v, l, B, st));
         RC(wgrad(v, l, v.act[l - 1], B, st));
-        RC(dgrad(v, l, v.dact[l - 1], B, st));
+        RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1]));
     }
     RC(bn_bwd(v, 0, B, st));
     RC(wgrad(v, 0, v.xt, B, st));
+    if (v.overlap) {
+        FAVAE_HIP(hipEventRecord(v.ev_join, v.side));
+        FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_join, 0));
+    }
     return FAVAE_OK;
 }
 

@@ -37,7 +37,8 @@ int favae_version(void);
  *              nn.ConvTranspose2d and nn.Linear forward / input gradient (:41-45) with ks=1 on a 1x1 grid.
  *   scatter=1: nn.ConvTranspose2d forward (:50-57, 64-71) and the input gradient of nn.Conv2d (loss.backward() :249).
  * in [Nb,Hi,Wi,Cin] dtype, w [Cout][ks*ks][Cin] dtype, bias [Cout] fp32 or NULL, out [Nb,Ho,Wo,Cout] fp32.
- * splitk: 0 = choose; >1 splits the reduction and accumulates with fp32 atomics (out is zeroed first). */
+ * splitk: 0 = choose; >1 splits the reduction and accumulates with fp32 atomics (out is zeroed first); <0 = choose, and
+ * the caller guarantees that out is already all zero (lets one memset serve many launches). */
 int favae_conv_igemm(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cin,
                      int Ho, int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk, int dtype,
                      void* stream);
@@ -56,6 +57,10 @@ int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const void* cols,
  * algorithmic flops per class (classes: see csrc/igemm.hip). */
 int favae_prof_enable(int enabled, int stride);
 int favae_prof_collect(double* out48);
+/* Developer hook for tile tuning (tools/tune_gemm.py; no reference counterpart): force the tile of the gather/scatter
+ * kernels (0..3 = 128x128, 128x64, 64x64, 128x32) and of the weight-gradient kernels (0..3 = 32x128, 128x32, 64x64,
+ * 128x128); -1 restores the built-in choice.  Process-wide, not thread-safe. */
+int favae_debug_force_tile(int kc_tile, int pm_tile);
 
 /* ---- conv VAE: HBM-bound kernels ----------------------------------------------------------------------------- */
 
@@ -102,6 +107,9 @@ int favae_sigmoid_sse(const float* raw, const float* y, long long n, double* acc
 int favae_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                     float eps, long long step, void* stream);
 /* master fp32 [Co][taps][Ci] -> dtype copy (same layout, may be NULL) and dtype transpose [Ci][taps][Co] (may be NULL). */
+/* The same for n weight tensors in one launch (host arrays of device pointers / shapes; n <= 16). */
+int favae_weight_prep_batch(int n, const float* const* w, void* const* w_copy, void* const* w_transposed, const int* Co,
+                            const int* taps, const int* Ci, int dtype, void* stream);
 int favae_weight_prep(const float* w, void* w_copy, void* w_transposed, int Co, int taps, int Ci, int dtype, void* stream);
 /* rows idx[b] of the resident fp32 NHWC dataset -> fp32 batch and/or dtype batch (DataLoader batch, :227-229). */
 int favae_gather_batch(const float* data, const int* idx, int B, long long row_floats, float* x_f32, void* x_t, int dtype,
