@@ -26,10 +26,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 E_EPOCHS = 5
-CLASS_NAMES = {0: "igemm_kc gather 128x128", 1: "igemm_kc gather 128x64", 2: "igemm_kc gather 64x64", 3: "igemm_kc gather 128x32",
-               4: "igemm_kc scatter 128x128", 5: "igemm_kc scatter 128x64", 6: "igemm_kc scatter 64x64",
+CLASS_NAMES = {2: "igemm_kc gather 64x64", 3: "igemm_kc gather 128x32", 6: "igemm_kc scatter 64x64",
                8: "igemm_kc gather elementwise-load", 9: "igemm_kc scatter elementwise-load", 10: "igemm_pm wgrad 32x128",
-               11: "igemm_pm wgrad 128x32", 12: "igemm_pm wgrad 64x64", 13: "igemm_pm wgrad 128x128"}
+               11: "igemm_pm wgrad 128x32", 12: "igemm_pm wgrad 64x64", 15: "wgrad narrow-channel (VALU)"}
 
 
 def synth(n, seed):

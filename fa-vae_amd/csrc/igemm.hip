@@ -17,6 +17,7 @@
 #include <algorithm>
 #include "common.h"
 #include "favae_hip.h"
+#include "smallconv.h"
 
 #include <mutex>
 #include <vector>
@@ -98,6 +99,12 @@ __device__ __forceinline__ void frag_pm(Frag<bf16_t>& f, const char* lds, int RS
     f.v = c.b;
 }
 
+// value select (a ?: on two uint4 lvalues would be an lvalue select and force the register arrays into memory)
+__device__ __forceinline__ uint4 keep_if(bool ok, uint4 v) {
+    v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+    return v;
+}
+
 template <class T> __device__ __forceinline__ void put_elem(uint4& v, int e, T x);
 template <> __device__ __forceinline__ void put_elem<float>(uint4& v, int e, float x) {
     unsigned u = __float_as_uint(x);
@@ -130,9 +137,13 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
     constexpr int VA = (NVA + 255) / 256, VB = (NVB + 255) / 256;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "wave layout");
-    __shared__ __attribute__((aligned(16))) char lds[(BM + BN) * RS];
-    char* ldsA = lds;
-    char* ldsB = lds + BM * RS;
+    // Pipeline: D chunks of both operands are in flight in registers (the layers are short reductions on small grids,
+    // so the exposed global-load latency per chunk, not MFMA issue, sets the kernel time), LDS is double-buffered
+    // where two stages fit in 64 KB so that one barrier per chunk is enough.
+    constexpr int D = SLOW ? 1 : ((VA + VB) * 4 <= 16 ? 4 : (VA + VB) * 4 <= 32 ? 3 : 2);
+    constexpr int STAGE = (BM + BN) * RS;
+    constexpr int NBUF = 2 * STAGE <= 65536 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) char lds[NBUF * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -165,6 +176,14 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
         a_x[i] = rem - a_y[i] * p.WoC;
     }
     const int vecA = tid % VPR;  // same for every i because 256 % VPR == 0
+    int b_row[VB];
+    bool b_ok[VB];
+#pragma unroll
+    for (int j = 0; j < VB; ++j) {
+        const int n = n0 + (tid + j * 256) / VPR;
+        b_ok[j] = n < p.Cout && (tid + j * 256) < NVB;
+        b_row[j] = b_ok[j] ? n : 0;
+    }
 
     auto in_coord = [&](int yy, int xx, int kh, int kw, int& iy, int& ix) -> bool {
         if (TR) {
@@ -177,9 +196,12 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
         return iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
     };
 
-    uint4 va[VA], vb[VB];
-    auto load_chunk = [&](int c) {
+    // returns the validity bits of the A vectors (bit i); the zeroing select is applied when the registers are written
+    // to LDS, D chunks later, so that nothing waits on a load at issue time
+    auto load_chunk = [&](int c, uint4 (&va)[VA], uint4 (&vb)[VB]) -> unsigned {
+        unsigned mask = 0;
         if (!SLOW) {
+            // branch-free: out-of-image taps and tail rows read a clamped (valid) address
             const int t = c / cpt, ci0 = (c - t * cpt) * BK;
             const int kh = tap_kh(t / nkw), kw = tap_kw(t % nkw);
             const int kg = (kh * p.ks + kw) * p.Cin + ci0 + vecA * VE;
@@ -187,19 +209,16 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
             for (int i = 0; i < VA; ++i) {
                 int iy, ix;
                 const bool ok = in_coord(a_y[i], a_x[i], kh, kw, iy, ix) && a_ok[i];
-                va[i] = make_uint4(0, 0, 0, 0);
-                if (ok) {
-                    const size_t off = ((size_t)(a_n[i] * p.Hi + iy) * p.Wi + ix) * p.Cin + ci0 + vecA * VE;
-                    va[i] = *(const uint4*)((const T*)p.in + off);
-                }
+                iy = min(max(iy, 0), p.Hi - 1);
+                ix = min(max(ix, 0), p.Wi - 1);
+                const size_t off = ((size_t)(a_n[i] * p.Hi + iy) * p.Wi + ix) * p.Cin + ci0 + vecA * VE;
+                va[i] = *(const uint4*)((const T*)p.in + off);
+                mask |= ok ? (1u << i) : 0u;
             }
 #pragma unroll
-            for (int j = 0; j < VB; ++j) {
-                const int r = (tid + j * 256) / VPR, n = n0 + r;
-                vb[j] = make_uint4(0, 0, 0, 0);
-                if (n < p.Cout && (tid + j * 256) < NVB) vb[j] = *(const uint4*)((const T*)p.w + (size_t)n * p.ldw + kg);
-            }
+            for (int j = 0; j < VB; ++j) vb[j] = *(const uint4*)((const T*)p.w + (size_t)b_row[j] * p.ldw + kg);
         } else {
+            mask = ~0u;
             const int ktot = ntap * p.Cin;
 #pragma unroll
             for (int i = 0; i < VA; ++i) {
@@ -220,21 +239,21 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
             }
 #pragma unroll
             for (int j = 0; j < VB; ++j) {
-                const int r = (tid + j * 256) / VPR, n = n0 + r;
                 vb[j] = make_uint4(0, 0, 0, 0);
 #pragma unroll
                 for (int e = 0; e < VE; ++e) {
                     const int k = c * BK + vecA * VE + e;
                     T x = (T)0;
-                    if (k < ktot && n < p.Cout && (tid + j * 256) < NVB) {
+                    if (k < ktot && b_ok[j]) {
                         const int t = k / p.Cin, ci = k - t * p.Cin;
                         const int kh = tap_kh(t / nkw), kw = tap_kw(t % nkw);
-                        x = ((const T*)p.w)[(size_t)n * p.ldw + (kh * p.ks + kw) * p.Cin + ci];
+                        x = ((const T*)p.w)[(size_t)b_row[j] * p.ldw + (kh * p.ks + kw) * p.Cin + ci];
                     }
                     put_elem<T>(vb[j], e, x);
                 }
             }
         }
+        return mask;
     };
 
     f32x16 acc[TM][TN];
@@ -245,30 +264,44 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    if (c_begin < c_end) load_chunk(c_begin);
-    for (int c = c_begin; c < c_end; ++c) {
+    uint4 va[D][VA], vb[D][VB];
+    unsigned am[D];
 #pragma unroll
-        for (int i = 0; i < VA; ++i)
-            if ((tid + i * 256) < NVA) *(uint4*)(ldsA + ((tid + i * 256) / VPR) * RS + vecA * 16) = va[i];
+    for (int d = 0; d < D; ++d)
+        if (c_begin + d < c_end) am[d] = load_chunk(c_begin + d, va[d], vb[d]);
+    int buf = 0;
+    for (int c = c_begin; c < c_end; c += D) {
 #pragma unroll
-        for (int j = 0; j < VB; ++j)
-            if ((tid + j * 256) < NVB) *(uint4*)(ldsB + ((tid + j * 256) / VPR) * RS + vecA * 16) = vb[j];
-        __syncthreads();
-        if (c + 1 < c_end) load_chunk(c + 1);  // in flight while the MFMAs below run
+        for (int d = 0; d < D; ++d) {
+            const int cc = c + d;
+            if (cc < c_end) {   // block-uniform
+                char* ldsA = lds + buf * STAGE;
+                char* ldsB = ldsA + BM * RS;
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            Frag<T> fa[TM], fb[TN];
-            const int koff = (kk * 16 + 8 * (lane >> 5)) * (int)sizeof(T);
+                for (int i = 0; i < VA; ++i)
+                    if (NVA % 256 == 0 || (tid + i * 256) < NVA)
+                        *(uint4*)(ldsA + ((tid + i * 256) / VPR) * RS + vecA * 16) = keep_if((am[d] >> i) & 1u, va[d][i]);
 #pragma unroll
-            for (int a = 0; a < TM; ++a) frag_kc(fa[a], ldsA + (wm * WTM + a * 32 + (lane & 31)) * RS + koff);
+                for (int j = 0; j < VB; ++j)
+                    if (NVB % 256 == 0 || (tid + j * 256) < NVB) *(uint4*)(ldsB + ((tid + j * 256) / VPR) * RS + vecA * 16) = keep_if(b_ok[j], vb[d][j]);
+                __syncthreads();
+                if (cc + D < c_end) am[d] = load_chunk(cc + D, va[d], vb[d]);  // D chunks ahead of the MFMAs below
 #pragma unroll
-            for (int b = 0; b < TN; ++b) frag_kc(fb[b], ldsB + (wn * WTN + b * 32 + (lane & 31)) * RS + koff);
+                for (int kk = 0; kk < BK / 16; ++kk) {
+                    Frag<T> fa[TM], fb[TN];
+                    const int koff = (kk * 16 + 8 * (lane >> 5)) * (int)sizeof(T);
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+                    for (int a = 0; a < TM; ++a) frag_kc(fa[a], ldsA + (wm * WTM + a * 32 + (lane & 31)) * RS + koff);
 #pragma unroll
-                for (int b = 0; b < TN; ++b) mma32(acc[a][b], fa[a], fb[b]);
+                    for (int b = 0; b < TN; ++b) frag_kc(fb[b], ldsB + (wn * WTN + b * 32 + (lane & 31)) * RS + koff);
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) mma32(acc[a][b], fa[a], fb[b]);
+                }
+                if (NBUF == 1) __syncthreads(); else buf ^= 1;
+            }
         }
-        __syncthreads();
     }
     if (c_begin >= c_end && !(blockIdx.y == 0)) return;
 
@@ -319,9 +352,10 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
     constexpr int VR = (NVR + 255) / 256, VC = (NVC + 255) / 256;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "wave layout");
-    __shared__ __attribute__((aligned(16))) char lds[BK * (RSR + RSC)];
-    char* ldsR = lds;
-    char* ldsC = lds + BK * RSR;
+    constexpr int D = (VR + VC) * 4 <= 16 ? 4 : (VR + VC) * 4 <= 32 ? 3 : 2;   // chunks in flight (see igemm_kc)
+    constexpr int STAGE = BK * (RSR + RSC);
+    constexpr int NBUF = 2 * STAGE <= 65536 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) char lds[NBUF * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -332,36 +366,55 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
     const int c_begin = blockIdx.y * per, c_end = min(nchunk, c_begin + per);
     if (c_begin >= c_end) return;
 
-    auto load_vec = [&](const void* base, int C, bool large, int ch0, int v, int vpr, int chunk) -> uint4 {
+    // branch-free for whole-vector channel counts: clamped address, validity returned separately and applied when the
+    // registers go to LDS (tail pixels, halo, tail channels)
+    auto load_vec = [&](const void* base, int C, bool large, int ch0, int v, int vpr, int chunk, bool& valid) -> uint4 {
         const int prow = v / vpr, cv = v - prow * vpr;
         const int pix = chunk * BK + prow;
-        uint4 out = make_uint4(0, 0, 0, 0);
-        if (pix >= p.K || prow >= BK) return out;
-        size_t spix = (size_t)pix;
+        bool ok = pix < p.K && prow < BK;
+        const int pc = min(pix, p.K - 1);
+        size_t spix = (size_t)pc;
         if (large) {
             const int hw = p.Hs * p.Ws;
-            const int n = pix / hw, rem = pix - n * hw, h = rem / p.Ws, w = rem - h * p.Ws;
-            const int y = h * p.stride - p.pad + kh, x = w * p.stride - p.pad + kw;
-            if (y < 0 || y >= p.Hl || x < 0 || x >= p.Wl) return out;
+            const int n = pc / hw, rem = pc - n * hw, h = rem / p.Ws, w = rem - h * p.Ws;
+            int y = h * p.stride - p.pad + kh, x = w * p.stride - p.pad + kw;
+            ok = ok && y >= 0 && y < p.Hl && x >= 0 && x < p.Wl;
+            y = min(max(y, 0), p.Hl - 1);
+            x = min(max(x, 0), p.Wl - 1);
             spix = ((size_t)n * p.Hl + y) * p.Wl + x;
         }
         const int ch = ch0 + cv * VE;
+        uint4 out = make_uint4(0, 0, 0, 0);
         if (C % VE == 0) {
-            if (ch < C) out = *(const uint4*)((const T*)base + spix * C + ch);
+            const int chc = min(ch, C - VE);
+            out = *(const uint4*)((const T*)base + spix * C + chc);
+            valid = ok && ch < C;
         } else {
+            valid = true;
+            if (ok) {
 #pragma unroll
-            for (int e = 0; e < VE; ++e)
-                if (ch + e < C) put_elem<T>(out, e, ((const T*)base)[spix * C + ch + e]);
+                for (int e = 0; e < VE; ++e)
+                    if (ch + e < C) put_elem<T>(out, e, ((const T*)base)[spix * C + ch + e]);
+            }
         }
         return out;
     };
 
-    uint4 vr[VR], vc[VC];
-    auto load_chunk = [&](int chunk) {
+    auto load_chunk = [&](int chunk, uint4 (&vr)[VR], uint4 (&vc)[VC]) -> unsigned {
+        unsigned mask = 0;
 #pragma unroll
-        for (int i = 0; i < VR; ++i) vr[i] = load_vec(p.rp, p.Rc, p.r_large, r0, tid + i * 256, VPR_R, chunk);
+        for (int i = 0; i < VR; ++i) {
+            bool ok;
+            vr[i] = load_vec(p.rp, p.Rc, p.r_large, r0, tid + i * 256, VPR_R, chunk, ok);
+            mask |= ok ? (1u << i) : 0u;
+        }
 #pragma unroll
-        for (int i = 0; i < VC; ++i) vc[i] = load_vec(p.cp, p.Cc, p.c_large, c0, tid + i * 256, VPR_C, chunk);
+        for (int i = 0; i < VC; ++i) {
+            bool ok;
+            vc[i] = load_vec(p.cp, p.Cc, p.c_large, c0, tid + i * 256, VPR_C, chunk, ok);
+            mask |= ok ? (1u << (16 + i)) : 0u;
+        }
+        return mask;
     };
 
     f32x16 acc[TM][TN];
@@ -372,33 +425,46 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    load_chunk(c_begin);
-    for (int c = c_begin; c < c_end; ++c) {
+    uint4 vr[D][VR], vc[D][VC];
+    unsigned vm[D];
 #pragma unroll
-        for (int i = 0; i < VR; ++i) {
-            const int v = tid + i * 256;
-            if (v < NVR) *(uint4*)(ldsR + (v / VPR_R) * RSR + (v % VPR_R) * 16) = vr[i];
+    for (int d = 0; d < D; ++d)
+        if (c_begin + d < c_end) vm[d] = load_chunk(c_begin + d, vr[d], vc[d]);
+    int buf = 0;
+    for (int c = c_begin; c < c_end; c += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int cc = c + d;
+            if (cc < c_end) {   // block-uniform
+                char* ldsR = lds + buf * STAGE;
+                char* ldsC = ldsR + BK * RSR;
+#pragma unroll
+                for (int i = 0; i < VR; ++i) {
+                    const int v = tid + i * 256;
+                    if (NVR % 256 == 0 || v < NVR) *(uint4*)(ldsR + (v / VPR_R) * RSR + (v % VPR_R) * 16) = keep_if((vm[d] >> i) & 1u, vr[d][i]);
+                }
+#pragma unroll
+                for (int i = 0; i < VC; ++i) {
+                    const int v = tid + i * 256;
+                    if (NVC % 256 == 0 || v < NVC) *(uint4*)(ldsC + (v / VPR_C) * RSC + (v % VPR_C) * 16) = keep_if((vm[d] >> (16 + i)) & 1u, vc[d][i]);
+                }
+                __syncthreads();
+                if (cc + D < c_end) vm[d] = load_chunk(cc + D, vr[d], vc[d]);
+#pragma unroll
+                for (int kk = 0; kk < BK / 16; ++kk) {
+                    Frag<T> fa[TM], fb[TN];
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) frag_pm(fa[a], ldsR, RSR, kk * 16, wm * WTM + a * 32, lane);
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) frag_pm(fb[b], ldsC, RSC, kk * 16, wn * WTN + b * 32, lane);
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) mma32(acc[a][b], fa[a], fb[b]);
+                }
+                if (NBUF == 1) __syncthreads(); else buf ^= 1;
+            }
         }
-#pragma unroll
-        for (int i = 0; i < VC; ++i) {
-            const int v = tid + i * 256;
-            if (v < NVC) *(uint4*)(ldsC + (v / VPR_C) * RSC + (v % VPR_C) * 16) = vc[i];
-        }
-        __syncthreads();
-        if (c + 1 < c_end) load_chunk(c + 1);
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            Frag<T> fa[TM], fb[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) frag_pm(fa[a], ldsR, RSR, kk * 16, wm * WTM + a * 32, lane);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) frag_pm(fb[b], ldsC, RSC, kk * 16, wn * WTN + b * 32, lane);
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) mma32(acc[a][b], fa[a], fb[b]);
-        }
-        __syncthreads();
     }
 
     const int ntaps = p.ks * p.ks;
@@ -419,8 +485,7 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
 template <class T, bool TR, bool SLOW, int BM, int BN, int WM, int WN>
 int launch_kc(const KcParams& p, int classes, hipStream_t st) {
     dim3 grid(cdiv(p.M, BM) * p.ntn, p.splitk, classes);
-    const int tile = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64) ? 2 : 3;
-    const int cls = SLOW ? (TR ? 9 : 8) : (TR ? 4 : 0) + tile;
+    const int cls = SLOW ? (TR ? 9 : 8) : (TR ? 4 : 0) + (BM == 64 ? 2 : 3);
     // algorithmic work, dense-tap convention: gather form ks*ks taps per output pixel, stride-2 scatter form 9/4
     const double taps = (TR && p.stride == 2) ? 2.25 : (double)(p.ks * p.ks);
     ProfScope prof(cls, 2.0 * p.Nb * p.Ho * p.Wo * (double)p.Cout * taps * p.Cin, st);
@@ -432,16 +497,12 @@ int launch_kc(const KcParams& p, int classes, hipStream_t st) {
 template <class T, bool TR>
 int dispatch_kc(KcParams p, int classes, int target_blocks, hipStream_t st) {
     const bool slow = (p.Cin % BK) != 0;
-    // Batch-64 layers are 2-5 GFLOP each: a 64x64 tile grid of 256-1024 blocks beats larger tiles with deeper split-K
-    // on every layer of the step (tools/tune_gemm.py sweep on MI355X), because the fp32 atomic traffic of split-K grows
-    // with the tile area while these grids already cover the 256 CUs.
-    int BM = 64, BN = 64;
-    if (!slow && p.Cout <= 32 && !TR) { BM = 128; BN = 32; }
-    if (!slow && g_force_kc_tile >= 0) {
-        static const int tb[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
-        BM = tb[g_force_kc_tile & 3][0]; BN = tb[g_force_kc_tile & 3][1];
-        if (TR && BN == 32) { BM = 64; BN = 64; }
-    }
+    // Batch-64 layers are 2-5 GFLOP each: a 64x64 tile grid of 256-1024 blocks beat 128-wide tiles with deeper split-K
+    // on every layer of the step (sweep on MI355X), because the fp32 atomic traffic of split-K grows with the tile
+    // area while these grids already cover the 256 CUs.  128x32 serves the few-output-channel gather layers.
+    bool narrow_n = !slow && p.Cout <= 32 && !TR;
+    if (!slow && !TR && g_force_kc_tile >= 0) narrow_n = g_force_kc_tile == 1;
+    const int BM = narrow_n ? 128 : 64, BN = narrow_n ? 32 : 64;
     p.ntn = cdiv(p.Cout, BN);
     // split the reduction when the tile grid alone cannot fill 256 CUs
     const int ntap_max = p.ks * p.ks;
@@ -455,34 +516,27 @@ int dispatch_kc(KcParams p, int classes, int target_blocks, hipStream_t st) {
     if (p.splitk > 1 && !prezeroed)
         FAVAE_HIP(hipMemsetAsync(p.out, 0, (size_t)p.Nb * p.Ho * p.Wo * p.Cout * sizeof(float), st));
     if (slow) return launch_kc<T, TR, true, 64, 64, 2, 2>(p, classes, st);
-    if (BM == 128 && BN == 32) {
-        if constexpr (!TR) return launch_kc<T, TR, false, 128, 32, 4, 1>(p, classes, st);
+    if constexpr (!TR) {
+        if (narrow_n) return launch_kc<T, TR, false, 128, 32, 4, 1>(p, classes, st);
     }
-    if (BM == 128 && BN == 64) return launch_kc<T, TR, false, 128, 64, 2, 2>(p, classes, st);
-    if (BM == 64 && BN == 64) return launch_kc<T, TR, false, 64, 64, 2, 2>(p, classes, st);
-    return launch_kc<T, TR, false, 128, 128, 2, 2>(p, classes, st);
+    return launch_kc<T, TR, false, 64, 64, 2, 2>(p, classes, st);
 }
 
 template <class T>
 int dispatch_pm(PmParams p, hipStream_t st) {
-    int BM = 64, BN = 64;
-    if (p.Rc <= 32) { BM = 32; BN = 128; }
-    else if (p.Cc <= 32) { BM = 128; BN = 32; }
-    if (g_force_pm_tile >= 0) {
-        static const int tb[4][2] = {{32, 128}, {128, 32}, {64, 64}, {128, 128}};
-        BM = tb[g_force_pm_tile & 3][0]; BN = tb[g_force_pm_tile & 3][1];
-    }
+    int tile = p.Rc <= 32 ? 0 : p.Cc <= 32 ? 1 : 2;   // 32x128, 128x32, 64x64
+    if (g_force_pm_tile >= 0 && g_force_pm_tile <= 2) tile = g_force_pm_tile;
+    const int BM = tile == 0 ? 32 : tile == 1 ? 128 : 64, BN = tile == 0 ? 128 : tile == 1 ? 32 : 64;
     p.ntn = cdiv(p.Cc, BN);
     const int nchunk = cdiv(p.K, BK);
     const int blocks = cdiv(p.Rc, BM) * p.ntn * p.ks * p.ks;
     int sk = p.splitk > 0 ? p.splitk : std::min(std::max(1, nchunk / 8), std::max(1, (512 + blocks / 2) / blocks));
     p.splitk = std::max(1, std::min(sk, nchunk));
     dim3 grid(cdiv(p.Rc, BM) * p.ntn, p.splitk, p.ks * p.ks);
-    ProfScope prof(BM == 32 ? 10 : BN == 32 ? 11 : BM == 64 ? 12 : 13, 2.0 * p.Rc * (double)p.Cc * p.K * p.ks * p.ks, st);
-    if (BM == 32) hipLaunchKernelGGL((igemm_pm<T, 32, 128, 1, 4>), grid, dim3(256), 0, st, p);
-    else if (BN == 32) hipLaunchKernelGGL((igemm_pm<T, 128, 32, 4, 1>), grid, dim3(256), 0, st, p);
-    else if (BM == 64) hipLaunchKernelGGL((igemm_pm<T, 64, 64, 2, 2>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((igemm_pm<T, 128, 128, 2, 2>), grid, dim3(256), 0, st, p);
+    ProfScope prof(10 + tile, 2.0 * p.Rc * (double)p.Cc * p.K * p.ks * p.ks, st);
+    if (tile == 0) hipLaunchKernelGGL((igemm_pm<T, 32, 128, 1, 4>), grid, dim3(256), 0, st, p);
+    else if (tile == 1) hipLaunchKernelGGL((igemm_pm<T, 128, 32, 4, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_pm<T, 64, 64, 2, 2>), grid, dim3(256), 0, st, p);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }
@@ -505,6 +559,12 @@ extern "C" int favae_conv_igemm(const void* in, const void* w, const float* bias
     const int esz = dtype == FAVAE_F32 ? 4 : 2;
     if (Cin % BK == 0) FAVAE_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)w % 16) == 0, "favae_conv_igemm: 16-byte alignment");
     (void)esz;
+    hipStream_t st = (hipStream_t)stream;
+    // one thread per output pixel pays off once the pixel count fills the chip several times over (the decoder side)
+    if (g_force_kc_tile < 0 && (long long)Nb * Ho * Wo >= 131072 && thin_in_applicable(Cin, Cout, ks, stride, scatter)) {
+        ProfScope prof(14, 2.0 * Nb * Ho * Wo * (double)Cout * 9 * Cin, (hipStream_t)stream);
+        return thin_in_launch(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, stride, scatter, dtype, (hipStream_t)stream);
+    }
     KcParams p;
     p.in = in; p.w = w; p.bias = bias; p.out = out;
     p.Nb = Nb; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
@@ -514,7 +574,6 @@ extern "C" int favae_conv_igemm(const void* in, const void* w, const float* bias
     else { p.HoC = Ho; p.WoC = Wo; }
     p.M = Nb * p.HoC * p.WoC;
     p.ntn = 1;
-    hipStream_t st = (hipStream_t)stream;
     const int target = scatter ? 1024 : 512;
     if (dtype == FAVAE_F32) return scatter ? dispatch_kc<float, true>(p, classes, target, st) : dispatch_kc<float, false>(p, classes, target, st);
     return scatter ? dispatch_kc<bf16_t, true>(p, classes, target, st) : dispatch_kc<bf16_t, false>(p, classes, target, st);
@@ -533,11 +592,15 @@ extern "C" int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const 
                     "favae_conv_wgrad: small/large size mismatch");
     FAVAE_CHECK_ARG((size_t)Nb * Hl * Wl < (1u << 31), "favae_conv_wgrad: too many pixels");
     FAVAE_CHECK_ARG(((uintptr_t)rows % 16) == 0 && ((uintptr_t)cols % 16) == 0, "favae_conv_wgrad: 16-byte alignment");
+    hipStream_t st = (hipStream_t)stream;
+    if (g_force_pm_tile < 0 && cols_large && Rc <= 4 && stride == 1 && wgrad_nw_applicable(Cc, Rc, ks, stride, 0)) {
+        ProfScope prof(15, 2.0 * Rc * (double)Cc * Nb * Hs * Ws * 9, st);   // wide = cols (large grid), narrow = rows
+        return wgrad_nw_launch(cols, rows, dw, Nb, Hl, Wl, Cc, Hs, Ws, Rc, stride, 0, 1, Cc, 9 * Cc, dtype, st);
+    }
     PmParams p;
     p.rp = rows; p.cp = cols; p.dw = dw; p.Rc = Rc; p.Cc = Cc; p.r_large = rows_large; p.c_large = cols_large;
     p.Nb = Nb; p.Hs = Hs; p.Ws = Ws; p.Hl = Hl; p.Wl = Wl; p.ks = ks; p.stride = stride; p.pad = pad;
     p.splitk = splitk; p.ntn = 1; p.K = Nb * Hs * Ws;
-    hipStream_t st = (hipStream_t)stream;
     return dtype == FAVAE_F32 ? dispatch_pm<float>(p, st) : dispatch_pm<bf16_t>(p, st);
 }
 
@@ -548,8 +611,8 @@ extern "C" int favae_debug_force_tile(int kc_tile, int pm_tile) {
 }
 
 /* Live kernel timing for bench.py: enable with a sampling stride, run, then collect per-class (launches, seconds, flops).
- * Classes: 0-3 gather form tiles 128x128/128x64/64x64/128x32, 4-6 scatter form, 8/9 element-wise loaders, 10-13 weight
- * gradient tiles 32x128/128x32/64x64/128x128. */
+ * Classes: 2/3 gather form tiles 64x64/128x32, 6 scatter form 64x64, 8/9 element-wise loaders (gather/scatter),
+ * 10-12 weight gradient tiles 32x128/128x32/64x64, 15 narrow-channel weight gradient (smallconv.hip). */
 extern "C" int favae_prof_enable(int enabled, int stride) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.enabled = enabled;

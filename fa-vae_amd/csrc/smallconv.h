@@ -1,0 +1,11 @@
+// Internal interface of smallconv.hip (weight gradient with an image-sized channel count on one side).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "favae_hip.h"
+
+bool wgrad_nw_applicable(int Cw, int Cs, int ks, int stride, int narrow_is_large);
+int wgrad_nw_launch(const void* wide, const void* narrow, float* dw, int Nb, int Hq, int Wq, int Cw, int Hn, int Wn, int Cs,
+                    int stride, int narrow_is_large, int s_ch, int s_tap, int s_c, int dtype, hipStream_t st);
+bool thin_in_applicable(int Cs, int Co, int ks, int stride, int scatter);
+int thin_in_launch(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cs, int Ho, int Wo,
+                   int Co, int stride, int scatter, int dtype, hipStream_t st);

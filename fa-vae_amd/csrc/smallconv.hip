@@ -1,0 +1,205 @@
+// Weight gradient of a 3x3 convolution whose output (or input) has an image-sized channel count (<= 4), e.g.
+// final_layer.3 = Conv2d(64 -> 3, k3 s1 p1) of the FA-VAE decoder (celeba_deepvanilla_vae.py:74-76).  With 3 channels
+// on one side the GEMM is 27 x 64 with a reduction over every pixel of the batch: far below an MFMA tile and bound by
+// streaming the wide operand once, so it runs on the vector ALUs:
+//   dw[..] += sum_q wide[q][ch] * narrow[coord(q, tap)][c]      c < Cs <= 4, 4 wide channels per lane
+// coord(q, tap) = q*stride - 1 + k (narrow on the large grid) or q + 1 - k (narrow on the small grid, stride 1).
+// Border taps use a clamped coordinate and a 0/1 mask, so all loads of a pixel are issued together.
+#include <algorithm>
+#include <atomic>
+#include "common.h"
+#include "smallconv.h"
+
+namespace {
+
+template <class T> __device__ __forceinline__ void load4(const T* p, float* o);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float* o) {
+    const float4 v = *(const float4*)p; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float* o) {
+    const uint2 u = *(const uint2*)p;
+    o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+    o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+
+__device__ __forceinline__ int coord(int q, int k, int stride, int flip) { return flip ? q + 1 - k : q * stride - 1 + k; }
+
+// Border taps are handled without control flow: the coordinate is clamped into the image and the value multiplied by
+// a 0/1 mask, so that all loads of one pixel are issued back to back and waited for once.
+__device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi - 1); }
+
+// ---------------------------------------------------------------------------------------------------------
+template <class T, int CS>
+__global__ __launch_bounds__(256) void wgrad_nw(const T* __restrict__ wide, const T* __restrict__ narrow, float* __restrict__ dw,
+                                                int Hq, int Wq, int Cw, int Hn, int Wn, int stride, int flip, int total, int ppb,
+                                                int s_ch, int s_tap, int s_c) {
+    __shared__ float red[256 * 4];
+    const int tid = threadIdx.x;
+    const int L = Cw >> 2, PP = 256 / L, l = tid % L, pl = tid / L;
+    float acc[9 * CS][4];
+#pragma unroll
+    for (int i = 0; i < 9 * CS; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
+    const int q0 = blockIdx.x * ppb, q1 = min(total, q0 + ppb);
+    for (int q = q0 + pl; q < q1; q += PP) {
+        const int n = q / (Hq * Wq), rem = q - n * Hq * Wq, y = rem / Wq, x = rem - y * Wq;
+        float wv[4], v[9 * CS];
+        load4<T>(wide + (size_t)q * Cw + l * 4, wv);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = coord(y, kh, stride, flip);
+            const bool oky = iy >= 0 && iy < Hn;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = coord(x, kw, stride, flip);
+                const float m = (oky && ix >= 0 && ix < Wn) ? 1.f : 0.f;
+                const T* src = narrow + ((size_t)(n * Hn + clampi(iy, Hn)) * Wn + clampi(ix, Wn)) * CS;
+#pragma unroll
+                for (int c = 0; c < CS; ++c) v[(kh * 3 + kw) * CS + c] = to_f32<T>(src[c]) * m;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9 * CS; ++k) {
+            acc[k][0] += v[k] * wv[0]; acc[k][1] += v[k] * wv[1]; acc[k][2] += v[k] * wv[2]; acc[k][3] += v[k] * wv[3];
+        }
+    }
+    // block reduction over the PP pixel lanes, one (tap, c) at a time, then one atomic per output element
+#pragma unroll
+    for (int i = 0; i < 9 * CS; ++i) {
+        *(float4*)(red + tid * 4) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+        __syncthreads();
+        if (tid < Cw) {
+            float s = 0.f;
+            for (int p = 0; p < PP; ++p) s += red[(p * L + (tid >> 2)) * 4 + (tid & 3)];
+            const int tap = i / CS, c = i - tap * CS;
+            atomicAdd(dw + (size_t)tid * s_ch + (size_t)tap * s_tap + (size_t)c * s_c, s);
+        }
+        __syncthreads();
+    }
+}
+
+inline bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+}  // namespace
+
+bool wgrad_nw_applicable(int Cw, int Cs, int ks, int stride, int narrow_is_large) {
+    return ks == 3 && Cs >= 1 && Cs <= 4 && Cw % 4 == 0 && pow2(Cw / 4) && Cw >= 16 && Cw <= 256 && (narrow_is_large || stride == 1);
+}
+
+template <class T>
+static int wgrad_nw_dispatch(const void* wide, const void* narrow, float* dw, int Hq, int Wq, int Cw, int Hn, int Wn, int Cs,
+                             int stride, int flip, int total, int ppb, int grid, int s_ch, int s_tap, int s_c, hipStream_t st) {
+#define NW_CASE(CS_)                                                                                                        \
+    case CS_:                                                                                                               \
+        hipLaunchKernelGGL((wgrad_nw<T, CS_>), dim3(grid), dim3(256), 0, st, (const T*)wide, (const T*)narrow, dw, Hq, Wq, Cw, \
+                           Hn, Wn, stride, flip, total, ppb, s_ch, s_tap, s_c);                                             \
+        break;
+    switch (Cs) { NW_CASE(1) NW_CASE(2) NW_CASE(3) NW_CASE(4) }
+#undef NW_CASE
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+int wgrad_nw_launch(const void* wide, const void* narrow, float* dw, int Nb, int Hq, int Wq, int Cw, int Hn, int Wn, int Cs,
+                    int stride, int narrow_is_large, int s_ch, int s_tap, int s_c, int dtype, hipStream_t st) {
+    const int total = Nb * Hq * Wq;
+    const int PP = 256 / (Cw / 4);
+    int ppb = std::max(PP, cdiv(cdiv(total, 1024), PP) * PP);
+    const int grid = cdiv(total, ppb);
+    const int flip = narrow_is_large ? 0 : 1;
+    return dtype == FAVAE_F32
+               ? wgrad_nw_dispatch<float>(wide, narrow, dw, Hq, Wq, Cw, Hn, Wn, Cs, stride, flip, total, ppb, grid, s_ch, s_tap, s_c, st)
+               : wgrad_nw_dispatch<bf16_t>(wide, narrow, dw, Hq, Wq, Cw, Hn, Wn, Cs, stride, flip, total, ppb, grid, s_ch, s_tap, s_c, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Convolution with an image-sized INPUT channel count (Cs <= 4) and a wide output (Co = 64): encoder.0 forward
+// (k3 s2 p1, celeba_deepvanilla_vae.py:31-33) and the input gradient of final_layer.3 (k3 s1 p1 with the transposed
+// weights, loss.backward() :249).  The reduction is only 9*Cs <= 36 long, so one thread owns one output pixel and all
+// Co channels: its 9*Cs inputs sit in registers, the weights are wave-uniform (scalar loads, SGPR operands of the
+// FMAs), and nothing is shared between threads.  VALU-bound at 9*Cs*Co FMAs per pixel.
+//   out[pix][co] = bias[co] + sum_{tap, c} in[coord(pix, tap)][c] * w[co][tap][c]
+namespace {
+
+template <class T, int CS, int CO>
+__global__ __launch_bounds__(256) void conv_thin_in(const T* __restrict__ in, const float* __restrict__ wk /* [9*CS][CO] fp32 */,
+                                                    const float* __restrict__ bias, float* __restrict__ out, int Hi, int Wi,
+                                                    int Ho, int Wo, int stride, int flip, int total) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= total) return;
+    const int n = pix / (Ho * Wo), rem = pix - n * Ho * Wo, y = rem / Wo, x = rem - y * Wo;
+    float v[9 * CS];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int iy = coord(y, kh, stride, flip);
+        const bool oky = iy >= 0 && iy < Hi;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ix = coord(x, kw, stride, flip);
+            const float m = (oky && ix >= 0 && ix < Wi) ? 1.f : 0.f;
+            const T* src = in + ((size_t)(n * Hi + clampi(iy, Hi)) * Wi + clampi(ix, Wi)) * CS;
+#pragma unroll
+            for (int c = 0; c < CS; ++c) v[(kh * 3 + kw) * CS + c] = to_f32<T>(src[c]) * m;
+        }
+    }
+    float* dst = out + (size_t)pix * CO;
+#pragma unroll
+    for (int cb = 0; cb < CO; cb += 16) {   // 16 output channels at a time keeps the accumulators at 16 registers
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = bias ? bias[cb + j] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 9 * CS; ++k)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] += v[k] * wk[k * CO + cb + j];
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) *(float4*)(dst + cb + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+    }
+}
+
+// w [CO][9][CS] (dtype) -> wk [9*CS][CO] fp32
+template <class T>
+__global__ void thin_in_wprep(const T* __restrict__ w, float* __restrict__ wk, int K, int CO) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= K * CO) return;
+    const int k = i / CO, co = i - k * CO;
+    wk[i] = to_f32<T>(w[(size_t)co * K + k]);
+}
+
+}  // namespace
+
+bool thin_in_applicable(int Cs, int Co, int ks, int stride, int scatter) {
+    return ks == 3 && Cs >= 1 && Cs <= 4 && Co == 64 && (scatter ? stride == 1 : true);
+}
+
+namespace {
+constexpr int WK_SLOTS = 16, WK_FLOATS = 36 * 64;
+__device__ float g_thin_wk[WK_SLOTS * WK_FLOATS];   // re-laid-out weights of the launches in flight (ring of slots)
+std::atomic<unsigned> g_wk_next{0};
+}  // namespace
+
+int thin_in_launch(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cs, int Ho, int Wo,
+                   int Co, int stride, int scatter, int dtype, hipStream_t st) {
+    static float* per_device[64] = {nullptr};
+    int dev = 0;
+    FAVAE_HIP(hipGetDevice(&dev));
+    FAVAE_CHECK_ARG(dev >= 0 && dev < 64, "thin_in_launch: device index %d", dev);
+    if (!per_device[dev]) FAVAE_HIP(hipGetSymbolAddress((void**)&per_device[dev], HIP_SYMBOL(g_thin_wk)));
+    float* wk_scratch = per_device[dev] + (size_t)(g_wk_next.fetch_add(1u) % WK_SLOTS) * WK_FLOATS;
+    const int total = Nb * Ho * Wo, K = 9 * Cs;
+    const int grid = cdiv(total, 256);
+    if (dtype == FAVAE_F32)
+        hipLaunchKernelGGL(thin_in_wprep<float>, dim3(cdiv(K * Co, 256)), dim3(256), 0, st, (const float*)w, wk_scratch, K, Co);
+    else
+        hipLaunchKernelGGL(thin_in_wprep<bf16_t>, dim3(cdiv(K * Co, 256)), dim3(256), 0, st, (const bf16_t*)w, wk_scratch, K, Co);
+#define TI_CASE(T_, CS_)                                                                                                   \
+    hipLaunchKernelGGL((conv_thin_in<T_, CS_, 64>), dim3(grid), dim3(256), 0, st, (const T_*)in, wk_scratch, bias, out, Hi, Wi, \
+                       Ho, Wo, stride, scatter, total)
+    if (dtype == FAVAE_F32) {
+        switch (Cs) { case 1: TI_CASE(float, 1); break; case 2: TI_CASE(float, 2); break; case 3: TI_CASE(float, 3); break; default: TI_CASE(float, 4); }
+    } else {
+        switch (Cs) { case 1: TI_CASE(bf16_t, 1); break; case 2: TI_CASE(bf16_t, 2); break; case 3: TI_CASE(bf16_t, 3); break; default: TI_CASE(bf16_t, 4); }
+    }
+#undef TI_CASE
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}

@@ -241,20 +241,28 @@ template <> __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
 
 __device__ __forceinline__ float lrelu(float y) { return y > 0.f ? y : 0.01f * y; }
 
+// The grid stride is a multiple of C (host picks it), so a thread keeps its 4 channels for the whole loop and the
+// affine form y = x * a + b is set up once.
 template <class T>
 __global__ __launch_bounds__(256) void bn_lrelu_fwd(const float* __restrict__ raw, const float* __restrict__ mean,
                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, T* __restrict__ act, size_t nvec, int C,
                                                     int apply_act) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
-        const int c = (int)((i * 4) % C);
-        const float4 x = *(const float4*)(raw + i * 4);
-        float y[4] = {x.x, x.y, x.z, x.w};
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    const int c = (int)((i0 * 4) % C);
+    float a[4], b[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float a = invstd[c + j] * gamma[c + j];
-            y[j] = y[j] * a + (beta[c + j] - mean[c + j] * a);
-            if (apply_act) y[j] = lrelu(y[j]);
+    for (int j = 0; j < 4; ++j) {
+        a[j] = invstd[c + j] * gamma[c + j];
+        b[j] = beta[c + j] - mean[c + j] * a[j];
+    }
+#pragma unroll 4
+    for (size_t i = i0; i < nvec; i += stride) {
+        const float4 x = *(const float4*)(raw + i * 4);
+        float y[4] = {x.x * a[0] + b[0], x.y * a[1] + b[1], x.z * a[2] + b[2], x.w * a[3] + b[3]};
+        if (apply_act) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = lrelu(y[j]);
         }
         store4<T>(act + i * 4, y[0], y[1], y[2], y[3]);
     }
@@ -598,10 +606,16 @@ extern "C" int favae_bn_lrelu_fwd(const float* raw, const float* mean, const flo
                                   const float* beta, void* act, long long R, int C, int apply_act, int dtype, void* stream) {
     FAVAE_CHECK_ARG(raw && mean && invstd && gamma && beta && act && R > 0 && C > 0 && C % 4 == 0, "favae_bn_lrelu_fwd: bad argument");
     const size_t nvec = (size_t)R * C / 4;
+    // grid stride (vectors) must be a multiple of C/4: blocks of 256 vectors, grid a multiple of C/4 / gcd(C/4, 256)
+    int c4 = C / 4, gg = c4, t = 256;
+    while (t) { const int r = gg % t; gg = t; t = r; }
+    const int mult = c4 / gg;
+    long long grid = (long long)std::min<size_t>(2048, (nvec + 255) / 256);
+    grid = std::max<long long>(mult, grid / mult * mult);
     if (dtype == FAVAE_F32)
-        hipLaunchKernelGGL(bn_lrelu_fwd<float>, dim3(ew_grid(nvec)), dim3(256), 0, ST, raw, mean, invstd, gamma, beta, (float*)act, nvec, C, apply_act);
+        hipLaunchKernelGGL(bn_lrelu_fwd<float>, dim3((unsigned)grid), dim3(256), 0, ST, raw, mean, invstd, gamma, beta, (float*)act, nvec, C, apply_act);
     else
-        hipLaunchKernelGGL(bn_lrelu_fwd<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, ST, raw, mean, invstd, gamma, beta, (bf16_t*)act, nvec, C, apply_act);
+        hipLaunchKernelGGL(bn_lrelu_fwd<bf16_t>, dim3((unsigned)grid), dim3(256), 0, ST, raw, mean, invstd, gamma, beta, (bf16_t*)act, nvec, C, apply_act);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

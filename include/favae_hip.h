@@ -57,9 +57,9 @@ int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const void* cols,
  * algorithmic flops per class (classes: see csrc/igemm.hip). */
 int favae_prof_enable(int enabled, int stride);
 int favae_prof_collect(double* out48);
-/* Developer hook for tile tuning (tools/tune_gemm.py; no reference counterpart): force the tile of the gather/scatter
- * kernels (0..3 = 128x128, 128x64, 64x64, 128x32) and of the weight-gradient kernels (0..3 = 32x128, 128x32, 64x64,
- * 128x128); -1 restores the built-in choice.  Process-wide, not thread-safe. */
+/* Developer hook for tile tuning (tools/tune_gemm.py; no reference counterpart): force the tile of the gather-form
+ * kernels (0 = 64x64, 1 = 128x32) and of the weight-gradient kernels (0..2 = 32x128, 128x32, 64x64); -1 restores the
+ * built-in choice.  Process-wide, not thread-safe. */
 int favae_debug_force_tile(int kc_tile, int pm_tile);
 
 /* ---- conv VAE: HBM-bound kernels ----------------------------------------------------------------------------- */

@@ -16,8 +16,8 @@ def timeit(fn, reps=20):
     for _ in range(reps): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
-KC = ['128x128', '128x64', '64x64', '128x32']
-PM = ['32x128', '128x32', '64x64', '128x128']
+KC = ['64x64', '128x32']
+PM = ['32x128', '128x32', '64x64']
 SK = [1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 64]
 def sweep(name, fn, tiles, kc):
     raw.favae_debug_force_tile(-1, -1)
