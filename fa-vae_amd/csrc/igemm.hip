@@ -477,7 +477,12 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
                 const int col = c0 + wn * WTN + b * 32 + (lane & 31);
-                if (col < p.Cc) atomicAdd(p.dw + ((size_t)row * ntaps + tap) * p.Cc + col, acc[a][b][r]);
+                if (col < p.Cc) {
+                    // one block per output element when the reduction is not split: add without an atomic (the
+                    // gradient arena is zeroed per step; chip-wide float atomics run at ~1.3 TB/s, plain stores at 6)
+                    float* dst = p.dw + ((size_t)row * ntaps + tap) * p.Cc + col;
+                    if (p.splitk > 1) atomicAdd(dst, acc[a][b][r]); else *dst += acc[a][b][r];
+                }
             }
         }
 }

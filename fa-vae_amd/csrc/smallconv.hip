@@ -124,8 +124,7 @@ template <class T, int CS, int CO>
 __global__ __launch_bounds__(256) void conv_thin_in(const T* __restrict__ in, const float* __restrict__ wk /* [9*CS][CO] fp32 */,
                                                     const float* __restrict__ bias, float* __restrict__ out, int Hi, int Wi,
                                                     int Ho, int Wo, int stride, int flip, int total) {
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= total) return;
+    const int pix = min(blockIdx.x * 256 + (int)threadIdx.x, total - 1);   // tail threads redo the last pixel, store nothing
     const int n = pix / (Ho * Wo), rem = pix - n * Ho * Wo, y = rem / Wo, x = rem - y * Wo;
     float v[9 * CS];
 #pragma unroll
@@ -141,18 +140,39 @@ __global__ __launch_bounds__(256) void conv_thin_in(const T* __restrict__ in, co
             for (int c = 0; c < CS; ++c) v[(kh * 3 + kw) * CS + c] = to_f32<T>(src[c]) * m;
         }
     }
-    float* dst = out + (size_t)pix * CO;
+    // results go through a per-wave LDS tile [64 pixels][32 channels] so that every global store instruction writes
+    // whole 128-B segments of the pixel rows (a thread storing its own row 16 B at a time costs 3x the HBM write
+    // traffic: partial lines)
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    constexpr int HC = 32, RSF = HC + 4;   // channels per pass, floats per LDS row (+16 B against bank conflicts)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* wt = tile + wave * 64 * RSF;
+    const int pix_w0 = blockIdx.x * 256 + wave * 64;   // first pixel of this wave
+    constexpr int LPR = HC / 4;                        // lanes per pixel row (float4 each)
+    constexpr int PPI = 64 / LPR;                      // pixel rows per store instruction
+    for (int hb = 0; hb < CO; hb += HC) {
 #pragma unroll
-    for (int cb = 0; cb < CO; cb += 16) {   // 16 output channels at a time keeps the accumulators at 16 registers
-        float acc[16];
+        for (int cb = 0; cb < HC; cb += 16) {   // 16 output channels at a time keeps the accumulators at 16 registers
+            float acc[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = bias ? bias[cb + j] : 0.f;
+            for (int j = 0; j < 16; ++j) acc[j] = bias ? bias[hb + cb + j] : 0.f;
 #pragma unroll
-        for (int k = 0; k < 9 * CS; ++k)
+            for (int k = 0; k < 9 * CS; ++k)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] += v[k] * wk[k * CO + cb + j];
+                for (int j = 0; j < 16; ++j) acc[j] += v[k] * wk[k * CO + hb + cb + j];
 #pragma unroll
-        for (int j = 0; j < 16; j += 4) *(float4*)(dst + cb + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+            for (int j = 0; j < 16; j += 4) *(float4*)(wt + lane * RSF + cb + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+        }
+        // wave-local hand-over: the tile is written and read by the same wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 64 / PPI; ++i) {
+            const int pr = i * PPI + lane / LPR, c4 = (lane % LPR) * 4;
+            if (pix_w0 + pr < total) *(float4*)(out + (size_t)(pix_w0 + pr) * CO + hb + c4) = *(const float4*)(wt + pr * RSF + c4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -192,7 +212,7 @@ int thin_in_launch(const void* in, const void* w, const float* bias, float* out,
     else
         hipLaunchKernelGGL(thin_in_wprep<bf16_t>, dim3(cdiv(K * Co, 256)), dim3(256), 0, st, (const bf16_t*)w, wk_scratch, K, Co);
 #define TI_CASE(T_, CS_)                                                                                                   \
-    hipLaunchKernelGGL((conv_thin_in<T_, CS_, 64>), dim3(grid), dim3(256), 0, st, (const T_*)in, wk_scratch, bias, out, Hi, Wi, \
+    hipLaunchKernelGGL((conv_thin_in<T_, CS_, 64>), dim3(grid), dim3(256), 4 * 64 * (32 + 4) * sizeof(float), st, (const T_*)in, wk_scratch, bias, out, Hi, Wi, \
                        Ho, Wo, stride, scatter, total)
     if (dtype == FAVAE_F32) {
         switch (Cs) { case 1: TI_CASE(float, 1); break; case 2: TI_CASE(float, 2); break; case 3: TI_CASE(float, 3); break; default: TI_CASE(float, 4); }
