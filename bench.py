@@ -26,9 +26,28 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 E_EPOCHS = 5
-CLASS_NAMES = {2: "igemm_kc gather 64x64", 3: "igemm_kc gather 128x32", 6: "igemm_kc scatter 64x64",
+CLASS_NAMES = {14: "conv thin-input (VALU, one thread per pixel)", 2: "igemm_kc gather 64x64", 3: "igemm_kc gather 128x32", 6: "igemm_kc scatter 64x64",
                8: "igemm_kc gather elementwise-load", 9: "igemm_kc scatter elementwise-load", 10: "igemm_pm wgrad 32x128",
                11: "igemm_pm wgrad 128x32", 12: "igemm_pm wgrad 64x64", 15: "wgrad narrow-channel (VALU)"}
+
+
+# kernel class -> name in the rocprofv3 traces (profiles/r1_pmc_traffic_per_launch.json, tools/pmc_traffic.py)
+CLASS_KERNEL = {2: "void igemm_kc<unsigned short, 64, 64, 2, 2, false, false>(KcParams)",
+                3: "void igemm_kc<unsigned short, 128, 32, 4, 1, false, false>(KcParams)",
+                6: "void igemm_kc<unsigned short, 64, 64, 2, 2, true, false>(KcParams)",
+                8: "void igemm_kc<unsigned short, 64, 64, 2, 2, false, true>(KcParams)",
+                11: "void igemm_pm<unsigned short, 128, 32, 4, 1>(PmParams)",
+                12: "void igemm_pm<unsigned short, 64, 64, 2, 2>(PmParams)"}
+
+
+def pmc_traffic(cls, dtype):
+    """HBM-side bytes per launch of a kernel class from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE runs of tools/prof_step.py, gfx950 corrections applied); None when there is no such record."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic_per_launch.json")
+    if dtype != "bf16" or cls not in CLASS_KERNEL or not os.path.exists(path):
+        return None
+    rec = json.load(open(path)).get(CLASS_KERNEL[cls])
+    return None if rec is None else rec["hbm_bytes"]
 
 
 def synth(n, seed):
@@ -171,7 +190,7 @@ def main():
         for c in range(16):
             cnt, sec, fl = prof[3 * c], prof[3 * c + 1], prof[3 * c + 2]
             if cnt > 0:
-                kern.append({"kernel": CLASS_NAMES.get(c, str(c)), "sampled_launches": int(cnt), "avg_us": 1e6 * sec / cnt,
+                kern.append({"cls": c, "kernel": CLASS_NAMES.get(c, str(c)), "sampled_launches": int(cnt), "avg_us": 1e6 * sec / cnt,
                              "tflops": fl / sec / 1e12, "share_of_gemm_time": sec})
         tot = sum(k["share_of_gemm_time"] for k in kern) or 1.0
         for k in kern:
@@ -191,9 +210,11 @@ def main():
                        "bound_last": float(model.L[-1])},
             "roofline": None if dom is None else {
                 "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
-                "frac": dom["tflops"] / peak, "traffic": None,
-                "note": "HIP events on the launch stream around every 16th launch inside the timed region; algorithmic flops, "
-                        "dense-tap convention"},
+                "frac": dom["tflops"] / peak, "traffic": pmc_traffic(dom["cls"], a.dtype),
+                "note": "HIP events on the launch stream around every 16th launch inside the timed region (weight gradients "
+                        "run on a side stream next to the main chain, so their durations include that overlap); algorithmic "
+                        "flops, dense-tap convention; traffic = mean HBM-side bytes per launch of this kernel from the "
+                        "committed rocprofv3 --pmc passes (profiles/r1_pmc_traffic_per_launch.json)"},
             "kernels": kern,
         }
         if ws == 1 and not a.no_cpu_baseline:

@@ -307,6 +307,38 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
+    if constexpr (BM == 64 && BN == 64 && !SLOW) {
+        // unsplit reduction: the tile goes through LDS and leaves as 16 B per lane, 256 contiguous bytes per output
+        // row (4 B per lane straight from the accumulators writes the same bytes in 4x the store instructions)
+        if (p.splitk == 1 && (p.Cout & 3) == 0) {
+            constexpr int TS = BN + 4;   // floats per LDS row
+            static_assert(BM * TS * 4 <= STAGE, "output tile must fit the staging buffer");
+            float* tile = (float*)lds;
+            __syncthreads();             // every wave is done with the operand stages
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tile[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TS + wn * 32 + (lane & 31)] = acc[0][0][r];
+            __syncthreads();
+            const int c4 = (tid & 15) * 4, n = n0 + c4;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (add_bias && n < p.Cout) bv = *(const float4*)(p.bias + n);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (tid >> 4) + 16 * i, m = m0 + row;
+                if (m >= p.M || n >= p.Cout) continue;
+                size_t opix = (size_t)m;
+                if (TR) {
+                    const int hw = p.HoC * p.WoC;
+                    const int nb = m / hw, rem = m - nb * hw, yy = rem / p.WoC, xx = rem - yy * p.WoC;
+                    opix = ((size_t)nb * p.Ho + (yy * p.stride + py)) * p.Wo + (xx * p.stride + px);
+                }
+                float4 v = *(const float4*)(tile + row * TS + c4);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                *(float4*)(p.out + opix * p.Cout + n) = v;
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
 #pragma unroll

@@ -33,7 +33,8 @@ int ticket_base(int nslots, unsigned** out) {
 
 struct RedGeom { int VW, TPR, RG, ctiles, nslab, rps; };
 
-constexpr int RED_THREADS = 1024;   // 16 waves: few, fat blocks keep the slab count (and the last block's tail) small
+constexpr int RED_THREADS = 512;    // 8 waves: few, fat blocks keep the slab count (and the last block's tail) small
+constexpr int RED_WAVES = RED_THREADS / 64;
 
 RedGeom red_geom(long long R, int C) {
     RedGeom g;
@@ -43,7 +44,7 @@ RedGeom red_geom(long long R, int C) {
     while (g.TPR < cv && g.TPR < cap) g.TPR *= 2;
     g.RG = RED_THREADS / g.TPR;
     g.ctiles = cdiv(cv, g.TPR);
-    const int target = std::max(1, std::min(128, 512 / g.ctiles));
+    const int target = std::max(1, std::min(8 * (RED_THREADS / 64), 512 / g.ctiles));   // tail: <= 8 loads per thread
     const long long min_rows = (long long)g.RG * 4;
     long long ns = std::max(1LL, std::min((long long)target, cdivll(R, min_rows)));
     if (R <= (long long)g.RG * 4) ns = 1;    // a single slab needs no cross-block hand-over at all
@@ -73,14 +74,14 @@ __global__ __launch_bounds__(RED_THREADS) void colreduce(int R, int C, int TPR, 
 #pragma unroll 4
         for (int r = r0 + rg; r < r1; r += RG) f.row(ctx, r, c0, acc);
     }
-    // row groups of one wave (lanes tl, tl+TPR, ...) by a fixed xor tree, then the 16 waves in order
+    // row groups of one wave (lanes tl, tl+TPR, ...) by a fixed xor tree, then the waves in order
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int j = 0; j < VW; ++j) {
             double t = acc[v][j];
             for (int o = TPR; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
-            if (lane < TPR) sm[((v * VW + j) * 16 + wave) * TPR + lane] = t;
+            if (lane < TPR) sm[((v * VW + j) * RED_WAVES + wave) * TPR + lane] = t;
         }
     __syncthreads();
     if (nslab == 1) {
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(RED_THREADS) void colreduce(int R, int C, int TPR, 
                 for (int v = 0; v < NV; ++v) {
                     double t = 0.0;
 #pragma unroll
-                    for (int w = 0; w < 16; ++w) t += sm[((v * VW + j) * 16 + w) * TPR + tid];
+                    for (int w = 0; w < RED_WAVES; ++w) t += sm[((v * VW + j) * RED_WAVES + w) * TPR + tid];
                     tot[v] = 0.0 + t;   // same association as the multi-slab tail with one slab
                 }
                 f.finish(c0 + j, tot);
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(RED_THREADS) void colreduce(int R, int C, int TPR, 
             for (int j = 0; j < VW; ++j) {
                 double t = 0.0;
 #pragma unroll
-                for (int w = 0; w < 16; ++w) t += sm[((v * VW + j) * 16 + w) * TPR + tid];
+                for (int w = 0; w < RED_WAVES; ++w) t += sm[((v * VW + j) * RED_WAVES + w) * TPR + tid];
                 __hip_atomic_store(&partial[((size_t)blockIdx.x * NV + v) * C + c0 + j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
     }
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(RED_THREADS) void colreduce(int R, int C, int TPR, 
     if (tid == 0) is_last = __hip_atomic_fetch_add(&tickets[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nslab - 1);
     __syncthreads();
     if (!is_last) return;
-    // last block of this channel tile: CT channels x (1024 / CT) slab parts, at most 8 loads per thread and value
+    // last block of this channel tile: CT channels x (RED_THREADS / CT) slab parts, at most 8 loads per thread and value
     const int CT = TPR * VW, ch = tid % CT, part = tid / CT, parts = RED_THREADS / CT;
     const int c = blockIdx.y * CT + ch;
 #pragma unroll
