@@ -486,6 +486,28 @@ extern "C" int favae_fa_mult_update(const double* t, const double* zwb, double* 
     return FAVAE_OK;
 }
 
+// SSHIBA.predict, multilabel output (cA/favae.py:1476-1479): s = m_x * scale[d]; mean_t = sigmoid(s) written the
+// reference's way exp(-log(1+exp(-s))) (:924-935), var_t = exp(s) / (1 + exp(s)^2) as written at :1479.
+__global__ __launch_bounds__(256) void mult_predict_kernel(const double* __restrict__ mx, const double* __restrict__ scale,
+                                                           double* __restrict__ mean_t, double* __restrict__ var_t, size_t n, int d) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double s = mx[i] * scale[i % d];
+        mean_t[i] = exp(-log(1.0 + exp(-s)));
+        const double e = exp(s);
+        var_t[i] = e / (1.0 + e * e);
+    }
+}
+
+extern "C" int favae_fa_mult_predict(const double* m_x, const double* scale, double* mean_t, double* var_t, long long N, int d,
+                                     void* stream) {
+    FAVAE_CHECK_ARG(m_x && scale && mean_t && var_t && N > 0 && d > 0, "favae_fa_mult_predict: bad argument");
+    const size_t n = (size_t)N * d;
+    const int grid = (int)std::min<size_t>(4096, (n + 255) / 256);
+    hipLaunchKernelGGL(mult_predict_kernel, dim3(grid), dim3(256), 0, ST, m_x, scale, mean_t, var_t, n, d);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
 extern "C" int favae_fa_xi_init(const double* mean, const double* cov, double* xi, long long n, void* stream) {
     FAVAE_CHECK_ARG(mean && cov && xi && n > 0, "favae_fa_xi_init: bad argument");
     hipLaunchKernelGGL(xi_init_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, ST, mean, cov, xi, (size_t)n);

@@ -68,6 +68,11 @@ def xi_init(mean, cov, xi):
     L.check(_raw.favae_fa_xi_init(L.ptr(mean), L.ptr(cov), L.ptr(xi), _ll(mean.numel()), L.stream_ptr()))
 
 
+def mult_predict(m_x, scale, mean_t, var_t):
+    N, d = m_x.shape
+    L.check(_raw.favae_fa_mult_predict(L.ptr(m_x), L.ptr(scale), L.ptr(mean_t), L.ptr(var_t), _ll(N), _i(d), L.stream_ptr()))
+
+
 def chol_inv(A, sc, s=None, diag_add=0.0, out_scale=1.0):
     """(inverse [K,K] device tensor, logdet_factored, logdet_out, ok)."""
     K = A.shape[0]

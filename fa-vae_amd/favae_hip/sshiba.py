@@ -377,6 +377,108 @@ class SSHIBA(object):
         out[(~nz) & (num != 0)] = 0.0
         return float(out.mean())
 
+    # ---- predict (cA :1336-1483 / :1485-1570, DA :1345-1478) ------------------------------------------------------
+    def _predict_latent(self, m_in, args):
+        """Posterior of Z given the input views (:1363-1423).  As in the reference only dict inputs of method 'img' and
+        'mult' contribute (a list input fails at :1378, other dict views add nothing).  Z_mean stays on the device."""
+        q = self.q_dist
+        K = q.Kc
+        if not isinstance(args[0], dict):
+            raise TypeError("list indices must be integers or slices, not str")      # what :1378 raises for list inputs
+        for arg in args:
+            if arg.get("SV") is not None:
+                raise NotImplementedError("kernel views are outside the FA-VAE hot path")
+        n_pred = int(np.shape(args[0]["data"])[0])
+        aux = self._up(np.eye(K))
+        for m in m_in:
+            Wm = self._up(q.W[m]["mean"])
+            aux = fa.axpby(1.0, aux, 1.0, fa.small_gemm(Wm, Wm, transA=True, alpha=self._tau(m)))
+        Zc, _, _, ok = fa.chol_inv(aux, self.sc)
+        X_sample = None
+        if not ok:
+            print("Cov Z is not invertible")
+            return n_pred, None, np.nan, X_sample
+        terms, cvec = [], None
+        for m, arg in enumerate(args):
+            mi = m_in[m]
+            Xs = None
+            if arg["method"] == "img":
+                X_mean, X_cov = self.img_vae[mi].update_x(arg["data"])
+                X_sample = X_mean + np.random.randn() * np.sqrt(X_cov)
+                Xs = X_sample
+            if arg["method"] == "mult":
+                Xs = np.log(np.abs((arg["data"] - 0.05)) / (1 - np.abs((arg["data"] - 0.05))))
+            if Xs is None:
+                continue
+            # sum_m tau_m (X_m - b_m) W_m Sigma  =  sum_m X_m P_m + c ,  P_m = tau_m W_m Sigma  (row GEMMs over N)
+            P = fa.small_gemm(self._up(q.W[mi]["mean"]), Zc, alpha=self._tau(mi))
+            cvec = fa.small_gemm(self._up(np.asarray(q.b[mi]["mean"]).reshape(1, -1)), P, alpha=-1.0,
+                                 beta=0.0 if cvec is None else 1.0, out=cvec)
+            terms.append((self._up(Xs), P))
+        if not terms:
+            Zd = torch.zeros(n_pred, K, dtype=F64, device=self.dev)
+        else:
+            Zd = torch.empty(n_pred, K, dtype=F64, device=self.dev)
+            for i, (Xd, P) in enumerate(terms):
+                if i == 0:
+                    fa.rows_gemm(Xd, P, cvec.reshape(-1), 1.0, None, 0.0, Zd)
+                else:
+                    fa.rows_gemm(Xd, P, None, 1.0, None, 0.0, Zd, accumulate=True)
+        return n_pred, Zd, Zc.cpu().numpy(), X_sample
+
+    def _predict_outputs(self, m_outs, n_pred, Zd, Z_cov, X_sample, sameimage):
+        q = self.q_dist
+        if Zd is None:                       # the reference goes on with the Z_mean of an earlier call (or fails)
+            Zd = self._up(self.Z_mean)
+        self.Z_mean = Zd.cpu().numpy()
+        predictions = {}
+        if isinstance(m_outs, int):
+            m_outs = [m_outs]
+        for m_out in m_outs:
+            W, b = np.asarray(q.W[m_out]["mean"]), np.asarray(q.b[m_out]["mean"]).reshape(1, -1)
+            d = self.d[m_out]
+            Wt = self._up(W.T)
+
+            def rows_affine(shift):
+                out = torch.empty(n_pred, d, dtype=F64, device=self.dev)
+                return fa.rows_gemm(Zd, Wt, self._up(shift.reshape(-1)), 1.0, None, 0.0, out)
+
+            if self.method[m_out] == "reg":
+                var_x = q.tau_mean(m_out) ** (-1) * np.eye(d) + np.linalg.multi_dot([W, Z_cov, W.T])
+                predictions["output_view" + str(m_out)] = {"mean_x": rows_affine(b).cpu().numpy(), "var_x": var_x}
+            if self.method[m_out] == "img":
+                vae = self.img_vae[m_out]
+                if self.VARIANT == "A" and not sameimage:                                            # cA :1438-1446
+                    shift = np.random.normal() * np.sqrt(np.diag(Z_cov))
+                    sampleX = rows_affine(shift @ W.T - b)                                           # minus b, as written
+                    pred_img = vae.decoder(sampleX.float())
+                    predictions = pred_img, self.Z_mean, 0
+                else:
+                    Z_in = {"mean": self.Z_mean, "cov": Z_cov}
+                    pred_img, xcart = vae.predict(Z=Z_in, W=q.W[m_out], b=q.b[m_out], tau=q.tau_mean(m_out))
+                    if self.VARIANT == "A":
+                        predictions = pred_img, self.Z_mean, xcart
+                    else:
+                        if X_sample is None:
+                            raise NameError("name 'X_sample' is not defined")                      # DA :1450 without an image input
+                        predictions = pred_img, X_sample, Z_in, xcart
+            elif self.method[m_out] == "mult":
+                var_d = 1.0 / self._tau(m_out) + np.einsum("ij,jk,ik->i", W, Z_cov, W)
+                scale = self._up((1 + math.pi / 8 * var_d) ** (-0.5))
+                mean_t = torch.empty(n_pred, d, dtype=F64, device=self.dev)
+                var_t = torch.empty_like(mean_t)
+                fa.mult_predict(rows_affine(b), scale, mean_t, var_t)
+                predictions["output_view" + str(m_out)] = {"mean_x": mean_t.cpu().numpy(), "var_x": var_t.cpu().numpy()}
+        return predictions
+
+    def predict(self, m_in, m_outs, *args):
+        n_pred, Zd, Z_cov, X_sample = self._predict_latent(m_in, args)
+        return self._predict_outputs(m_outs, n_pred, Zd, Z_cov, X_sample, False)
+
+    def predict_sameimage(self, m_in, m_outs, *args):
+        n_pred, Zd, Z_cov, X_sample = self._predict_latent(m_in, args)
+        return self._predict_outputs(m_outs, n_pred, Zd, Z_cov, X_sample, True)
+
     # ---- mean-field updates ----------------------------------------------------------------------------------------
     def update_w(self, m):
         """:1058-1075"""

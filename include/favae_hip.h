@@ -178,6 +178,10 @@ int favae_fa_rows_gemm(const double* X, int ldx, int d, const double* P, int ldp
 int favae_fa_mult_update(const double* t, const double* zwb, double* xi, double* mean, double* cov, double tau, long long n,
                          double* out2, double* scratch, size_t scratch_doubles, void* stream);
 int favae_fa_xi_init(const double* mean, const double* cov, double* xi, long long n, void* stream);
+/* Multilabel output of SSHIBA.predict (cA/favae.py:1469-1481): for rows of m_x [N][d] and scale[d] = (1 + pi/8 var_x[d,d])^-1/2,
+ * mean_t = sigmoid(m_x scale), var_t = exp(s) / (1 + exp(s)^2) (as the reference writes it). */
+int favae_fa_mult_predict(const double* m_x, const double* scale, double* mean_t, double* var_t, long long N, int d,
+                          void* stream);
 /* out = out_scale (s s^T) o ((s s^T) o A + diag_add I)^-1 through the Cholesky factor, one workgroup, LDS-resident for
  * K <= ~135 (myInverse cA/favae.py:904-922; update_w :1062-1065 with s = alpha^-1/2, diag_add = 1/tau, out_scale = 1/tau).
  * s may be NULL. work: 2*K*K doubles. logdet2[0] = log det of the factored matrix, logdet2[1] = log det out.

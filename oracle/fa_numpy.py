@@ -275,6 +275,79 @@ class SSHIBAOracle:
             mean_t[:, d] = sigmoid(m_x[:, d] * (1 + math.pi / 8 * var_x[d, d]) ** (-0.5))
         return mean_t
 
+    # -- predict: cA/favae.py:1336-1483 (variant A), DA/favae.py:1345-1478 (variants B, C) ------------------
+    def _predict_latent(self, m_in, args):
+        """:1363-1423 -- posterior of Z given the input views.  Only dict inputs of method 'img' / 'mult' add to
+        Z_mean in the reference (a list input fails at :1378, any other dict adds nothing)."""
+        q = self.q_dist
+        n_pred = np.shape(args[0]["data"])[0]
+        aux = np.eye(q.Kc)
+        for m in m_in:
+            aux += q.tau_mean(m) * np.dot(q.W[m]["mean"].T, q.W[m]["mean"])
+        Z_cov = my_inverse(aux)
+        X_sample = None
+        if not np.any(np.isnan(Z_cov)):
+            self.Z_mean = np.zeros((n_pred, q.Kc))
+            for m, arg in enumerate(args):
+                mi = m_in[m]
+                if arg["method"] == "img":
+                    X_mean, X_cov = self.img_vae[mi].update_x(arg["data"])
+                    X_sample = X_mean + np.random.randn() * np.sqrt(X_cov)
+                    self.Z_mean += np.dot(X_sample - q.b[mi]["mean"], q.W[mi]["mean"]) * q.tau_mean(mi)
+                if arg["method"] == "mult":
+                    X_mean = np.log(np.abs((arg["data"] - 0.05)) / (1 - np.abs((arg["data"] - 0.05))))
+                    self.Z_mean += np.dot(X_mean - q.b[mi]["mean"], q.W[mi]["mean"]) * q.tau_mean(mi)
+            self.Z_mean = np.dot(self.Z_mean, Z_cov)
+        return n_pred, Z_cov, X_sample
+
+    def _predict_outputs(self, m_outs, n_pred, Z_cov, X_sample, sameimage):
+        import torch
+        q = self.q_dist
+        predictions = {}
+        if isinstance(m_outs, int):
+            m_outs = [m_outs]
+        for m_out in m_outs:
+            W, b = q.W[m_out]["mean"], q.b[m_out]["mean"]
+            if self.method[m_out] == "reg":
+                mean_x = np.dot(self.Z_mean, W.T) + b
+                var_x = q.tau_mean(m_out) ** (-1) * np.eye(self.d[m_out]) + np.linalg.multi_dot([W, Z_cov, W.T])
+                predictions["output_view" + str(m_out)] = {"mean_x": mean_x, "var_x": var_x}
+            if self.method[m_out] == "img":
+                if self.variant == "A" and not sameimage:                                # cA :1438-1446
+                    sampleZ = self.Z_mean + np.random.normal() * np.sqrt(np.diag(Z_cov))
+                    sampleX = sampleZ @ W.T - b                                          # minus, as written
+                    pred_img = self.img_vae[m_out].decode_eval(torch.tensor(sampleX).float())
+                    predictions = pred_img, self.Z_mean, 0
+                else:
+                    Z_in = {"mean": self.Z_mean, "cov": Z_cov}
+                    pred_img, xcart = self.img_vae[m_out].predict(Z=Z_in, W=q.W[m_out], b=q.b[m_out], tau=q.tau_mean(m_out))
+                    if self.variant == "A":                                              # predict_sameimage :1544
+                        predictions = pred_img, self.Z_mean, xcart
+                    else:                                                                # DA :1450
+                        if X_sample is None:
+                            raise NameError("name 'X_sample' is not defined")          # what the reference does
+                        predictions = pred_img, X_sample, Z_in, xcart
+            elif self.method[m_out] == "mult":
+                m_x = np.dot(self.Z_mean, W.T) + b
+                var_x = q.tau_mean(m_out) ** (-1) * np.eye(self.d[m_out]) + np.linalg.multi_dot([W, Z_cov, W.T])
+                mean_t = np.zeros((n_pred, self.d[m_out]))
+                var_t = np.zeros((n_pred, self.d[m_out]))
+                for d in np.arange(self.d[m_out]):
+                    s = m_x[:, d] * (1 + math.pi / 8 * var_x[d, d]) ** (-0.5)
+                    mean_t[:, d] = sigmoid(s)
+                    var_t[:, d] = np.exp(s) / (1 + np.exp(s) ** 2)                       # :1479, as written
+                predictions["output_view" + str(m_out)] = {"mean_x": mean_t, "var_x": var_t}
+        return predictions
+
+    def predict(self, m_in, m_outs, *args):
+        n_pred, Z_cov, X_sample = self._predict_latent(m_in, args)
+        return self._predict_outputs(m_outs, n_pred, Z_cov, X_sample, False)
+
+    def predict_sameimage(self, m_in, m_outs, *args):
+        """cA/favae.py:1485-1570 (variant A only)."""
+        n_pred, Z_cov, X_sample = self._predict_latent(m_in, args)
+        return self._predict_outputs(m_outs, n_pred, Z_cov, X_sample, True)
+
     # -- mean-field updates --------------------------------------------------------------------------------
     def update_w(self, m):
         """cA/favae.py:1058-1075 (non-sparse branch)."""

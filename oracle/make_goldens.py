@@ -11,6 +11,9 @@ Fixtures
                           prior: losses, mu/std, gradient and parameter checksums.
   vae_epoch.npz           ImgVAE.trainloop (N=24 => batches 16+8... uses batch 64 => one batch of 24) for
                           3 epochs + update_x + reconstruction: epoch metrics, X moments, checksums.
+  predict_fa_A/B.npz      SSHIBA.predict after the FA-only fits: 'mult' view in -> 'reg' view out and -> 'mult' view out.
+  favae_A_predict.npz     after the favae_A fit: predict img -> mult, mult -> img (decoder of a sampled latent),
+                          predict_sameimage mult -> img (seeds set before each call).
   favae_A.npz             full variant-A fit, one image view (z=8) + one 'mult' view, N=32, Kc=4, 2 iterations
                           (50 + 5 epochs as the reference schedules them).
 """
@@ -90,6 +93,26 @@ def gen_fa(folder, name, Kc=10, iters=4, rank=5, pretrained_kw=True):
     print(name, "L =", model.L[-3:], "Kc =", model.q_dist.Kc)
 
 
+def gen_predict_fa(folder, name, pretrained_kw=True):
+    fav = rh.import_reference(folder)
+    X0, lab = fa_inputs()
+    model = fav.SSHIBA(10, 1)
+    v0, v1 = model.struct_data(X0, "reg"), model.struct_data(lab, "mult")
+    kw = dict(max_iter=4, pruning_crit=1e-3, verbose=1, store=False)
+    if pretrained_kw:
+        kw["pretrained"] = 0
+    run_quiet(lambda: model.fit(v0, v1, **kw))
+    _, lab_t = fa_inputs(n=100, seed=2)
+    p_reg = run_quiet(lambda: model.predict([1], [0], model.struct_data(lab_t, "mult")))
+    zm = np.copy(model.Z_mean)
+    p_mult = run_quiet(lambda: model.predict([1], [1], model.struct_data(lab_t, "mult")))
+    out = dict(Z_mean=zm, reg_mean=p_reg["output_view0"]["mean_x"], reg_var=p_reg["output_view0"]["var_x"],
+               mult_mean=p_mult["output_view1"]["mean_x"], mult_var=p_mult["output_view1"]["var_x"],
+               Kc=np.array(model.q_dist.Kc))
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, "Kc", model.q_dist.Kc, "reg_mean", out["reg_mean"].shape, float(np.abs(out["mult_mean"]).mean()))
+
+
 def gen_vae_step():
     import torch
     vm = rh.import_vae_module("condition_a_VAE", "celeba_deepvanilla_vae")
@@ -165,8 +188,31 @@ def gen_favae_A():
     out["total_elbo0"] = np.array(model.total_elbo[0], dtype=np.float64)
     for k, p in model.img_vae[0].state_dict().items():
         out["p_" + k] = checksum(p.numpy())
-    np.savez_compressed(os.path.join(OUT, "favae_A.npz"), **out)
+    old = os.path.join(OUT, "favae_A.npz")
+    if os.path.exists(old):                                  # the fit is deterministic: the committed file must not move
+        ref = np.load(old)
+        worst = max(float(np.max(np.abs(ref[k] - out[k]))) for k in ref.files)
+        print("favae_A re-run vs committed file: max abs diff", worst)
+        assert worst == 0.0, "favae_A.npz changed on regeneration"
+    else:
+        np.savez_compressed(old, **out)
     print("favae_A L =", model.L)
+    # ---- predict paths on the trained model (cA/favae.py:1336-1570) ----
+    import torch
+    img_t, lab_t = img_inputs(12, seed=5)
+    pr = {}
+    np.random.seed(11); torch.manual_seed(11)
+    p = run_quiet(lambda: model.predict([0], [1], model.struct_data(img_t, "img")))
+    pr["i2m_Z_mean"], pr["i2m_mean"], pr["i2m_var"] = np.copy(model.Z_mean), p["output_view1"]["mean_x"], p["output_view1"]["var_x"]
+    np.random.seed(12); torch.manual_seed(12)
+    pred_img, zm, xc = run_quiet(lambda: model.predict([1], [0], model.struct_data(lab_t, "mult")))
+    pr["m2i_Z_mean"], pr["m2i_img"] = np.copy(zm), checksum(pred_img.detach().cpu().numpy())
+    pr["m2i_img_shape"] = np.array(pred_img.shape)
+    np.random.seed(13); torch.manual_seed(13)
+    pred_img, zm, xc = run_quiet(lambda: model.predict_sameimage([1], [0], model.struct_data(lab_t, "mult")))
+    pr["same_Z_mean"], pr["same_img"], pr["same_xcart"] = np.copy(zm), checksum(pred_img), checksum(xc.numpy())
+    np.savez_compressed(os.path.join(OUT, "favae_A_predict.npz"), **pr)
+    print("favae_A_predict: img->mult mean", float(pr["i2m_mean"].mean()), "mult->img", pr["m2i_img"][:2], pr["same_img"][:2])
 
 
 if __name__ == "__main__":
@@ -176,6 +222,9 @@ if __name__ == "__main__":
         gen_fa("condition_a_VAE", "fa_A.npz")
         gen_fa("domain_adaptation", "fa_B.npz", pretrained_kw=False)
         gen_fa("condition_a_VAE", "fa_A_prune.npz", Kc=30, iters=40, rank=3)
+    if "predict_fa" in which:
+        gen_predict_fa("condition_a_VAE", "predict_fa_A.npz")
+        gen_predict_fa("domain_adaptation", "predict_fa_B.npz", pretrained_kw=False)
     if "vae_step" in which:
         gen_vae_step()
     if "vae_epoch" in which:

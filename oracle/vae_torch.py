@@ -250,3 +250,28 @@ class OracleImgVAE:
             for s in range(0, n, self.batch_size):
                 out[s:s + self.batch_size] = decoder(sample[s:s + self.batch_size], self.P, self.B, False).numpy()
         return out
+
+    # -- predict: cA/celeba_deepvanilla_vae.py:387-430 ----------------------------------------------------------
+    def predict(self, Z=None, W=None, b=None, tau=None, mean_x=None, var_x=None):
+        if mean_x is None:
+            Zs = Z["mean"] + np.random.normal() * np.sqrt(np.diag(Z["cov"]))
+            Ws = W["mean"] + np.random.normal() * np.sqrt(np.diag(W["cov"]))
+            bs = b["mean"] + np.random.normal() * np.sqrt(np.diag(b["cov"]))
+            mean = torch.from_numpy(Zs @ Ws.T + bs)
+            std = torch.sqrt(torch.ones_like(mean) / torch.from_numpy(np.asarray(1 / tau)))
+        else:
+            mean, std = torch.from_numpy(mean_x), torch.sqrt(torch.from_numpy(var_x))
+        rsample = torch.distributions.Normal(mean, std).rsample().float()
+        n = rsample.shape[0]
+        out = np.zeros((n,) + tuple(self.img.shape[1:]))
+        draw_epoch_order(n, False)
+        with torch.no_grad():
+            for s in range(0, n, self.batch_size):
+                out[s:s + self.batch_size] = decoder(rsample[s:s + self.batch_size], self.P, self.B, False).numpy()
+        return out, rsample
+
+    def decode_eval(self, z):
+        """`self.decoder(z)` as SSHIBA.predict calls it (cA/favae.py:1445) on a module left in eval mode by the
+        reconstruction diagnostic / update_x that precede it."""
+        with torch.no_grad():
+            return decoder(z, self.P, self.B, False)

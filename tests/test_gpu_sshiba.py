@@ -60,6 +60,16 @@ def test_fa_only_fit_matches_reference_golden(golden, folder, name, kw):
     model.fit(model.struct_data(X0, "reg"), model.struct_data(lab, "mult"), max_iter=4, pruning_crit=1e-3, verbose=0,
               store=False, **kw)
     _check_q(model, golden(name), 1e-8)
+    # SSHIBA.predict against the reference's own outputs (oracle/make_goldens.py gen_predict_fa)
+    gp = golden("predict_" + name)
+    _, lab_t = fa_inputs(n=100, seed=2)
+    p = model.predict([1], [0], model.struct_data(lab_t, "mult"))
+    _close(model.Z_mean, gp["Z_mean"], 1e-8, 1e-10)
+    _close(p["output_view0"]["mean_x"], gp["reg_mean"], 1e-8, 1e-10)
+    _close(p["output_view0"]["var_x"], gp["reg_var"], 1e-8, 1e-12)
+    p = model.predict([1], [1], model.struct_data(lab_t, "mult"))
+    _close(p["output_view1"]["mean_x"], gp["mult_mean"], 1e-8, 1e-10)
+    _close(p["output_view1"]["var_x"], gp["mult_var"], 1e-8, 1e-10)
 
 
 def test_fa_only_fit_with_pruning_matches_reference_golden(golden):
@@ -125,6 +135,32 @@ def test_full_variant_A_short_horizon_matches_oracle():
     _close(model.q_dist.Z["mean"], ref.q_dist.Z["mean"], 0, 1e-2 * np.abs(ref.q_dist.Z["mean"]).max())
     _close(model.q_dist.W[1]["mean"], ref.q_dist.W[1]["mean"], 0, 1e-2 * np.abs(ref.q_dist.W[1]["mean"]).max())
     _close(model.wandb_metrics["g R2 reconstruction"], ref.metrics["R2 reconstruction 0"], 0, 1e-3)
+    # ---- predict / predict_sameimage, like for like: the oracle takes over the HIP model's state --------------
+    q, rq = model.q_dist, ref.q_dist
+    rq.Kc = q.Kc
+    for m in range(model.m):
+        for k in ("mean", "cov"):
+            rq.W[m][k] = np.array(q.W[m][k])
+            rq.b[m][k] = np.array(q.b[m][k])
+        rq.tau[m]["a"], rq.tau[m]["b"] = q.tau[m]["a"], q.tau[m]["b"]
+    ref.img_vae[0].load_state_dict({k: v.detach().cpu() for k, v in model.img_vae[0].state_dict().items()})
+    img_t, lab_t = img_inputs(12, seed=5)
+    outs = []
+    for mdl, sd in ((model, model.struct_data), (ref, fo.struct_data)):
+        np.random.seed(11); torch.manual_seed(11)
+        p = mdl.predict([0], [1], sd(img_t, "img"))                         # image in, labels out
+        o = [np.array(mdl.Z_mean), p["output_view1"]["mean_x"], p["output_view1"]["var_x"]]
+        np.random.seed(12); torch.manual_seed(12)
+        pred_img, zm, xc = mdl.predict([1], [0], sd(lab_t, "mult"))         # labels in, image out (decoder of a sample)
+        assert xc == 0
+        o += [np.array(zm), pred_img.detach().cpu().double().numpy()]
+        np.random.seed(13); torch.manual_seed(13)
+        pred_img, zm, xc = mdl.predict_sameimage([1], [0], sd(lab_t, "mult"))
+        o += [np.asarray(pred_img), xc.cpu().numpy()]
+        outs.append(o)
+    for a, b in zip(*outs):
+        assert a.shape == b.shape
+        _close(a, b, 1e-4, 1e-4 * max(1.0, float(np.abs(b).max())))          # fp32 conv path: north_star 1e-4
     # the trainers pickle the fitted model (cA/favae_trainer.py:117-119)
     import pickle
     blob = pickle.dumps({"model": model})

@@ -40,6 +40,16 @@ def test_fa_only_matches_reference(golden, variant, name):
     model = fa.SSHIBAOracle(10, 1, variant=variant)
     model.fit(fa.struct_data(X0, "reg"), fa.struct_data(lab, "mult"), max_iter=4, pruning_crit=1e-3)
     _check_q(model, g)
+    # SSHIBA.predict on the fitted model (cA/favae.py:1336-1483): multilabel view in, regression / multilabel view out
+    gp = golden("predict_" + name)
+    _, lab_t = fa_inputs(n=100, seed=2)
+    p = model.predict([1], [0], fa.struct_data(lab_t, "mult"))
+    _close(model.Z_mean, gp["Z_mean"], rtol=1e-8, atol=1e-10)
+    _close(p["output_view0"]["mean_x"], gp["reg_mean"], rtol=1e-8, atol=1e-10)
+    _close(p["output_view0"]["var_x"], gp["reg_var"], rtol=1e-8, atol=1e-12)
+    p = model.predict([1], [1], fa.struct_data(lab_t, "mult"))
+    _close(p["output_view1"]["mean_x"], gp["mult_mean"], rtol=1e-8, atol=1e-10)
+    _close(p["output_view1"]["var_x"], gp["mult_var"], rtol=1e-8, atol=1e-10)
 
 
 def test_fa_pruning_matches_reference(golden):
@@ -124,3 +134,22 @@ def test_full_variant_A_fit_matches_reference(golden):
     _close(model.q_dist.Z["mean"], g["Z_mean"], rtol=1e-3, atol=1e-5)
     _close(model.X[0]["mean"], g["X0_mean"], rtol=1e-3, atol=1e-5)
     _close(model.q_dist.W[0]["mean"], g["W0_mean"], rtol=1e-3, atol=1e-6)
+    # predict / predict_sameimage on the trained model, same seeds as oracle/make_goldens.py.  The tolerances are those
+    # of the fit above (the predict arithmetic itself is pinned to 1e-8 by the FA-only test).
+    gp = golden("favae_A_predict.npz")
+    img_t, lab_t = img_inputs(12, seed=5)
+    np.random.seed(11); torch.manual_seed(11)
+    p = model.predict([0], [1], fa.struct_data(img_t, "img"))
+    _close(model.Z_mean, gp["i2m_Z_mean"], rtol=2e-3, atol=1e-4)
+    _close(p["output_view1"]["mean_x"], gp["i2m_mean"], rtol=2e-3, atol=1e-4)
+    _close(p["output_view1"]["var_x"], gp["i2m_var"], rtol=2e-3, atol=1e-4)
+    np.random.seed(12); torch.manual_seed(12)
+    pred_img, zm, xc = model.predict([1], [0], fa.struct_data(lab_t, "mult"))
+    assert tuple(pred_img.shape) == tuple(gp["m2i_img_shape"]) and xc == 0
+    _close(zm, gp["m2i_Z_mean"], rtol=2e-3, atol=1e-4)
+    _close(checksum(pred_img.numpy()), gp["m2i_img"], rtol=2e-3, atol=2e-3)
+    np.random.seed(13); torch.manual_seed(13)
+    pred_img, zm, xc = model.predict_sameimage([1], [0], fa.struct_data(lab_t, "mult"))
+    _close(zm, gp["same_Z_mean"], rtol=2e-3, atol=1e-4)
+    _close(checksum(pred_img), gp["same_img"], rtol=2e-3, atol=2e-3)
+    _close(checksum(xc.numpy()), gp["same_xcart"], rtol=2e-3, atol=2e-3)
