@@ -630,6 +630,10 @@ extern "C" int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const 
     FAVAE_CHECK_ARG((size_t)Nb * Hl * Wl < (1u << 31), "favae_conv_wgrad: too many pixels");
     FAVAE_CHECK_ARG(((uintptr_t)rows % 16) == 0 && ((uintptr_t)cols % 16) == 0, "favae_conv_wgrad: 16-byte alignment");
     hipStream_t st = (hipStream_t)stream;
+    if (g_force_pm_tile < 0 && cols_large && Cc <= 4 && wgrad_nw_applicable(Rc, Cc, ks, stride, 1)) {
+        ProfScope prof(15, 2.0 * Rc * (double)Cc * Nb * Hs * Ws * 9, st);   // wide = rows (small grid), narrow = cols
+        return wgrad_nw_launch(rows, cols, dw, Nb, Hs, Ws, Rc, Hl, Wl, Cc, stride, 1, 9 * Cc, Cc, 1, dtype, st);
+    }
     if (g_force_pm_tile < 0 && cols_large && Rc <= 4 && stride == 1 && wgrad_nw_applicable(Cc, Rc, ks, stride, 0)) {
         ProfScope prof(15, 2.0 * Rc * (double)Cc * Nb * Hs * Ws * 9, st);   // wide = cols (large grid), narrow = rows
         return wgrad_nw_launch(cols, rows, dw, Nb, Hl, Wl, Cc, Hs, Ws, Rc, stride, 0, 1, Cc, 9 * Cc, dtype, st);

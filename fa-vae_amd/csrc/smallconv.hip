@@ -62,7 +62,9 @@ __global__ __launch_bounds__(256) void wgrad_nw(const T* __restrict__ wide, cons
             acc[k][0] += v[k] * wv[0]; acc[k][1] += v[k] * wv[1]; acc[k][2] += v[k] * wv[2]; acc[k][3] += v[k] * wv[3];
         }
     }
-    // block reduction over the PP pixel lanes, one (tap, c) at a time, then one atomic per output element
+    // block reduction over the PP pixel lanes, one (tap, c) at a time, into an LDS image of the whole output; then one
+    // pass of atomics in output order (256 contiguous bytes per wave instruction, the full-rate shape)
+    __shared__ float S[36 * 256];
 #pragma unroll
     for (int i = 0; i < 9 * CS; ++i) {
         *(float4*)(red + tid * 4) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
@@ -70,10 +72,16 @@ __global__ __launch_bounds__(256) void wgrad_nw(const T* __restrict__ wide, cons
         if (tid < Cw) {
             float s = 0.f;
             for (int p = 0; p < PP; ++p) s += red[(p * L + (tid >> 2)) * 4 + (tid & 3)];
-            const int tap = i / CS, c = i - tap * CS;
-            atomicAdd(dw + (size_t)tid * s_ch + (size_t)tap * s_tap + (size_t)c * s_c, s);
+            S[i * Cw + tid] = s;
         }
         __syncthreads();
+    }
+    const int nout = 9 * CS * Cw;
+    for (int o = tid; o < nout; o += 256) {
+        int ch, tap, c;
+        if (s_ch == 1) { ch = o % Cw; const int r = o / Cw; c = r / 9; tap = r - c * 9; }       // dw[c][tap][ch]
+        else { ch = o / (9 * CS); const int r = o - ch * 9 * CS; tap = r / CS; c = r - tap * CS; }   // dw[ch][tap][c]
+        atomicAdd(dw + o, S[(tap * CS + c) * Cw + ch]);
     }
 }
 
@@ -103,7 +111,8 @@ int wgrad_nw_launch(const void* wide, const void* narrow, float* dw, int Nb, int
                     int stride, int narrow_is_large, int s_ch, int s_tap, int s_c, int dtype, hipStream_t st) {
     const int total = Nb * Hq * Wq;
     const int PP = 256 / (Cw / 4);
-    int ppb = std::max(PP, cdiv(cdiv(total, 1024), PP) * PP);
+    // >= 256 pixels per block: the block epilogue (27 LDS reductions + one atomic pass) is worth ~16 pixel iterations
+    int ppb = std::max(256, cdiv(cdiv(total, 1024), PP) * PP);
     const int grid = cdiv(total, ppb);
     const int flip = narrow_is_large ? 0 : 1;
     return dtype == FAVAE_F32

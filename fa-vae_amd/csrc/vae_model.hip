@@ -83,6 +83,8 @@ struct Vae {
     char* zero_lo; size_t zero_bytes;
     // weight gradients run on a second stream next to the dgrad -> BN-backward chain of the main stream
     hipStream_t side; hipEvent_t ev_fork[NL]; hipEvent_t ev_join; bool overlap;
+    // single-device epochs: Adam + weight re-layout of a layer follow its weight gradient on the side stream
+    struct { bool on; float lr, b1, b2, eps; long long step; int pending; } ada;
     const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(SH + L[l].wc_off * esz); }
     const void* Wt(int l) const { return (const void*)(SH + L[l].wt_off * esz); }
     long long rows(int l, int B) const { return (long long)B * L[l].Hout * L[l].Hout; }
@@ -201,11 +203,30 @@ int wgrad_launch(Vae& v, int l, const void* in, int B, void* st);
 
 // weight gradient of layer l given draw[l] (just produced on the main stream) and the layer input; with overlap on it
 // is queued on the side stream behind an event, so the main stream continues with the input gradient at once
+int adam_layer(Vae& v, int l, void* st);
+
 int wgrad(Vae& v, int l, const void* in, int B, void* st) {
     if (!v.overlap) return wgrad_launch(v, l, in, B, st);
     FAVAE_HIP(hipEventRecord(v.ev_fork[l], (hipStream_t)st));
     FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_fork[l], 0));
-    return wgrad_launch(v, l, in, B, (void*)v.side);
+    // Layer-wise optimiser step on the side stream.  The layer whose weight gradient was queued before this one may be
+    // updated now: this fork event was recorded after its input-gradient GEMM (the last reader of its weight shadows)
+    // was queued on the main stream, and its BN / bias gradients were complete before its own fork.
+    if (v.ada.on && v.ada.pending >= 0) RC(adam_layer(v, v.ada.pending, (void*)v.side));
+    RC(wgrad_launch(v, l, in, B, (void*)v.side));
+    if (v.ada.on) v.ada.pending = l;
+    return FAVAE_OK;
+}
+
+// Adam over the arena slice of layer l (weights, bias, BN affine) + its dtype shadows
+int adam_layer(Vae& v, int l, void* st) {
+    const Layer& L = v.L[l];
+    const long long lo = L.w_off, hi = l + 1 < NL ? v.L[l + 1].w_off : v.nparam;
+    RC(favae_adam_step(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, st));
+    void* c = L.wc_off >= 0 ? v.SH + L.wc_off * v.esz : nullptr;
+    void* t = L.wt_off >= 0 ? v.SH + L.wt_off * v.esz : nullptr;
+    if (c || t) RC(favae_weight_prep(v.P + L.w_off, c, t, L.Cout, L.taps, L.Cin, v.dtype, st));
+    return FAVAE_OK;
 }
 
 int wgrad_launch(Vae& v, int l, const void* in, int B, void* st) {
@@ -303,6 +324,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     const char* e = getenv("FAVAE_SINGLE_STREAM");
     v.overlap = !(e && e[0] == '1');
     v.side = nullptr;
+    v.ada = {false, 0.f, 0.f, 0.f, 0.f, 0, -1};
     if (v.overlap) {
         bool ok = hipStreamCreateWithFlags(&v.side, hipStreamNonBlocking) == hipSuccess;
         for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_fork[l], hipEventDisableTiming) == hipSuccess;
@@ -385,6 +407,10 @@ extern "C" int favae_vae_train_fwdbwd(favae_vae* h, const float* data_nhwc, cons
     RC(bn_bwd(v, 0, B, st));
     RC(wgrad(v, 0, v.xt, B, st));
     if (v.overlap) {
+        if (v.ada.on && v.ada.pending >= 0) {
+            RC(adam_layer(v, v.ada.pending, (void*)v.side));   // encoder.0: no input gradient reads its shadows
+            v.ada.pending = -1;
+        }
         FAVAE_HIP(hipEventRecord(v.ev_join, v.side));
         FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_join, 0));
     }
@@ -409,8 +435,15 @@ extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const
     long long s = 0;
     for (long long o = 0; o < n; o += batch, ++s) {
         const int B = (int)std::min<long long>(batch, n - o);
-        RC(favae_vae_train_fwdbwd(h, data_nhwc, perm + o, B, eps + o * v.z, prior, tau, beta, var_x, metrics + 2 * s, st));
-        RC(favae_vae_adam(h, lr, 0.9f, 0.999f, 1e-8f, step0 + s + 1, st));
+        if (v.overlap) {   // optimiser step layer by layer behind the weight gradients (same arithmetic, see adam_layer)
+            v.ada = {true, lr, 0.9f, 0.999f, 1e-8f, step0 + s + 1, -1};
+            const int rc = favae_vae_train_fwdbwd(h, data_nhwc, perm + o, B, eps + o * v.z, prior, tau, beta, var_x, metrics + 2 * s, st);
+            v.ada.on = false;
+            RC(rc);
+        } else {
+            RC(favae_vae_train_fwdbwd(h, data_nhwc, perm + o, B, eps + o * v.z, prior, tau, beta, var_x, metrics + 2 * s, st));
+            RC(favae_vae_adam(h, lr, 0.9f, 0.999f, 1e-8f, step0 + s + 1, st));
+        }
     }
     return FAVAE_OK;
 }
