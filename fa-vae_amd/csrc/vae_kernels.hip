@@ -328,6 +328,155 @@ struct BnBwdApplyF {
     __device__ void finish(int c, const double* tot) const { if (dbias) dbias[c] = (float)tot[0]; }
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// "Channel-owner" BatchNorm kernels for the small layers (R <= 1024 rows: the 4x4 and 2x2 feature maps at batch 64).
+// One 512-thread block owns 16 channels and ALL rows, keeps its elements in registers between the statistics and the
+// apply phase, and needs no hand-over between blocks: statistics + apply (forward) or both reduction passes + apply
+// (backward) are one launch instead of two, which is what counts for tensors of 0.25-0.5 M elements.
+// Sums are fp64 in a fixed order (bit-reproducible), as in colreduce.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int OWN_THREADS = 512, OWN_CT = 16, OWN_RG = OWN_THREADS / 4, OWN_MAXP = 8, OWN_WAVES = OWN_THREADS / 64;
+
+// sum the per-thread fp64 partials val[NQ][4] over the row groups of the block; result for channel (tl*4+j) of
+// quantity q lands in tot[q][16] (shared), valid after the trailing barrier
+template <int NQ>
+__device__ __forceinline__ void own_reduce(double (*val)[4], double* sm /* [NQ][OWN_WAVES][16] */, double* tot /* [NQ][16] */) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = tid & 3;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double t = val[q][j];
+            for (int o = 4; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+            if (lane < 4) sm[(q * OWN_WAVES + wave) * 16 + tl * 4 + j] = t;
+        }
+    __syncthreads();
+    if (tid < NQ * 16) {
+        const int q = tid >> 4, c = tid & 15;
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < OWN_WAVES; ++w) t += sm[(q * OWN_WAVES + w) * 16 + c];
+        tot[q * 16 + c] = t;
+    }
+    __syncthreads();
+}
+
+template <class T>
+__global__ __launch_bounds__(OWN_THREADS) void bn_fwd_owner(const float* __restrict__ raw, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ act,
+                                                            float* __restrict__ mean, float* __restrict__ invstd,
+                                                            float* __restrict__ run_mean, float* __restrict__ run_var, int R,
+                                                            int C, float eps, float mom) {
+    __shared__ double sm[2 * OWN_WAVES * 16], tot[2 * 16];
+    __shared__ float ab[2 * 16];
+    const int tid = threadIdx.x, tl = tid & 3, rg = tid >> 2;
+    const int c0 = blockIdx.x * OWN_CT + tl * 4;
+    float x[OWN_MAXP][4];
+    double val[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int p = 0; p < OWN_MAXP; ++p) {
+        const int r = rg + p * OWN_RG;
+        if (r < R) {
+            VecLoad<float, 4>::ld(raw + (size_t)r * C + c0, x[p]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { val[0][j] += x[p][j]; val[1][j] += (double)x[p][j] * x[p][j]; }
+        }
+    }
+    own_reduce<2>(val, sm, tot);
+    if (tid < 16) {
+        const int c = blockIdx.x * OWN_CT + tid;
+        const double Rd = (double)R, m = tot[tid] / Rd;
+        double var = tot[16 + tid] / Rd - m * m;
+        if (var < 0) var = 0;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        mean[c] = (float)m;
+        invstd[c] = is;
+        if (run_mean) {
+            const double unb = R > 1 ? var * Rd / (Rd - 1) : var;
+            run_mean[c] = (1.f - mom) * run_mean[c] + mom * (float)m;
+            run_var[c] = (1.f - mom) * run_var[c] + mom * (float)unb;
+        }
+        const float a = is * gamma[c];
+        ab[tid] = a;
+        ab[16 + tid] = beta[c] - (float)m * a;
+    }
+    __syncthreads();
+    float a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = ab[tl * 4 + j]; b[j] = ab[16 + tl * 4 + j]; }
+#pragma unroll
+    for (int p = 0; p < OWN_MAXP; ++p) {
+        const int r = rg + p * OWN_RG;
+        if (r < R) {
+            float y[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = lrelu(x[p][j] * a[j] + b[j]);
+            VecLoad<T, 4>::st(act + (size_t)r * C + c0, y);
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(OWN_THREADS) void bn_bwd_owner(const float* __restrict__ dact, const T* __restrict__ act,
+                                                            const float* __restrict__ raw, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            T* __restrict__ draw, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ dbias, int R, int C) {
+    __shared__ double sm[2 * OWN_WAVES * 16], tot[2 * 16];
+    const int tid = threadIdx.x, tl = tid & 3, rg = tid >> 2;
+    const int c0 = blockIdx.x * OWN_CT + tl * 4;
+    float mu[4], is[4], gi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; gi[j] = gamma[c0 + j] * is[j]; }
+    float d[OWN_MAXP][4], xh[OWN_MAXP][4];
+    double val[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int p = 0; p < OWN_MAXP; ++p) {
+        const int r = rg + p * OWN_RG;
+        if (r < R) {
+            const size_t i = (size_t)r * C + c0;
+            float a[4], x[4];
+            VecLoad<T, 4>::ld(act + i, a);
+            VecLoad<float, 4>::ld(dact + i, d[p]);
+            VecLoad<float, 4>::ld(raw + i, x);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d[p][j] *= (a[j] > 0.f ? 1.f : 0.01f);
+                xh[p][j] = (x[j] - mu[j]) * is[j];
+                val[0][j] += d[p][j]; val[1][j] += (double)d[p][j] * xh[p][j];
+            }
+        }
+    }
+    own_reduce<2>(val, sm, tot);
+    if (tid < 16) {
+        const int c = blockIdx.x * OWN_CT + tid;
+        dbeta[c] = (float)tot[tid];
+        dgamma[c] = (float)tot[16 + tid];
+    }
+    const float invR = (float)(1.0 / (double)R);
+    float k1[4], k2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { k1[j] = (float)tot[tl * 4 + j] * invR; k2[j] = (float)tot[16 + tl * 4 + j] * invR; }
+    double gs[1][4] = {{0, 0, 0, 0}};
+#pragma unroll
+    for (int p = 0; p < OWN_MAXP; ++p) {
+        const int r = rg + p * OWN_RG;
+        if (r < R) {
+            float g[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { g[j] = gi[j] * (d[p][j] - k1[j] - xh[p][j] * k2[j]); gs[0][j] += g[j]; }
+            VecLoad<T, 4>::st(draw + (size_t)r * C + c0, g);
+        }
+    }
+    if (dbias) {   // uniform
+        __syncthreads();   // tot is re-used
+        own_reduce<1>(gs, sm, tot);
+        if (tid < 16) dbias[blockIdx.x * OWN_CT + tid] = (float)tot[tid];
+    }
+}
+
+inline bool owner_applicable(long long R, int C) { return R <= (long long)OWN_RG * OWN_MAXP && C % OWN_CT == 0; }
+
 template <class T>
 struct ColsumF {
     const T* x; int C; float* out;
@@ -621,10 +770,36 @@ extern "C" int favae_bn_lrelu_fwd(const float* raw, const float* mean, const flo
     return FAVAE_OK;
 }
 
+extern "C" int favae_bn_train_fwd(const float* raw, const float* gamma, const float* beta, void* act, float* mean,
+                                  float* invstd, float* run_mean, float* run_var, long long R, int C, float eps, float momentum,
+                                  double* scratch, size_t scratch_doubles, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(raw && gamma && beta && act && mean && invstd && scratch && R > 0 && R < (1LL << 31) && C > 0 && C % 4 == 0,
+                    "favae_bn_train_fwd: bad argument");
+    if (owner_applicable(R, C)) {
+        if (dtype == FAVAE_F32)
+            hipLaunchKernelGGL(bn_fwd_owner<float>, dim3(C / OWN_CT), dim3(OWN_THREADS), 0, ST, raw, gamma, beta, (float*)act, mean,
+                               invstd, run_mean, run_var, (int)R, C, eps, momentum);
+        else
+            hipLaunchKernelGGL(bn_fwd_owner<bf16_t>, dim3(C / OWN_CT), dim3(OWN_THREADS), 0, ST, raw, gamma, beta, (bf16_t*)act, mean,
+                               invstd, run_mean, run_var, (int)R, C, eps, momentum);
+        FAVAE_LAUNCH_CHECK();
+        return FAVAE_OK;
+    }
+    int rc = favae_bn_stats(raw, R, C, eps, momentum, mean, invstd, run_mean, run_var, scratch, scratch_doubles, stream);
+    if (rc) return rc;
+    return favae_bn_lrelu_fwd(raw, mean, invstd, gamma, beta, act, R, C, 1, dtype, stream);
+}
+
 template <class T>
 static int bn_bwd_impl(const float* dact, const T* act, const float* raw, const float* mean, const float* invstd,
                        const float* gamma, T* draw, float* dgamma, float* dbeta, float* dbias, long long R, int C,
                        double* scratch, size_t cap, float* s1s2, hipStream_t st) {
+    if (owner_applicable(R, C)) {
+        hipLaunchKernelGGL(bn_bwd_owner<T>, dim3(C / OWN_CT), dim3(OWN_THREADS), 0, st, dact, act, raw, mean, invstd, gamma, draw,
+                           dgamma, dbeta, dbias, (int)R, C);
+        FAVAE_LAUNCH_CHECK();
+        return FAVAE_OK;
+    }
     int rc = run_colreduce<2>(R, C, scratch, cap, BnBwdRedF<T>{dact, act, raw, mean, invstd, C, dgamma, dbeta, s1s2}, st);
     if (rc) return rc;
     return run_colreduce<1>(R, C, scratch, cap,

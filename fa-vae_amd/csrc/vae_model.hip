@@ -165,9 +165,9 @@ int bn_fwd(Vae& v, int l, int B, bool train, void* st) {
     const Layer& L = v.L[l];
     const long long R = v.rows(l, B);
     if (train)
-        RC(favae_bn_stats(v.raw[l], R, L.Cout, 1e-5f, 0.1f, v.mean[l], v.invstd[l], v.BUF + L.rm_off, v.BUF + L.rv_off, v.scratch, v.scratch_doubles, st));
-    else
-        RC(favae_bn_eval_prep(v.BUF + L.rm_off, v.BUF + L.rv_off, L.Cout, 1e-5f, v.mean[l], v.invstd[l], st));
+        return favae_bn_train_fwd(v.raw[l], v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l], v.invstd[l], v.BUF + L.rm_off,
+                                  v.BUF + L.rv_off, R, L.Cout, 1e-5f, 0.1f, v.scratch, v.scratch_doubles, v.dtype, st);
+    RC(favae_bn_eval_prep(v.BUF + L.rm_off, v.BUF + L.rv_off, L.Cout, 1e-5f, v.mean[l], v.invstd[l], st));
     return favae_bn_lrelu_fwd(v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.P + L.be_off, v.act[l], R, L.Cout, 1, v.dtype, st);
 }
 

@@ -75,6 +75,11 @@ int favae_bn_eval_prep(const float* run_mean, const float* run_var, int C, float
 /* act = LeakyReLU_0.01((raw-mean)*invstd*gamma+beta) stored as dtype (:34-35); apply_act=0 skips the LeakyReLU. */
 int favae_bn_lrelu_fwd(const float* raw, const float* mean, const float* invstd, const float* gamma, const float* beta,
                        void* act, long long R, int C, int apply_act, int dtype, void* stream);
+/* Training-mode BN + LeakyReLU in one call (statistics, running-stat update, apply; :34-35 under self.train()): same
+ * results as favae_bn_stats followed by favae_bn_lrelu_fwd; small layers (R <= 1024) run as one launch. */
+int favae_bn_train_fwd(const float* raw, const float* gamma, const float* beta, void* act, float* mean, float* invstd,
+                       float* run_mean, float* run_var, long long R, int C, float eps, float momentum, double* scratch,
+                       size_t scratch_doubles, int dtype, void* stream);
 /* backward of BN(train)+LeakyReLU (autograd of :34-35 under loss.backward() :249): draw (dtype) = d loss / d raw,
  * dgamma, dbeta, and dbias = column sums of draw (gradient of the preceding conv bias; NULL to skip).
  * s1s2: 2*C floats of scratch. */

@@ -49,6 +49,14 @@ def test_bn_lrelu_forward_backward(R, C):
     L.check(raw_.favae_bn_lrelu_fwd(L.ptr(xd), L.ptr(mean), L.ptr(invstd), L.ptr(g32), L.ptr(b32), L.ptr(act), ll_(R), i_(C), i_(1),
                                     i_(0), L.stream_ptr()))
     assert _err(act, a.detach().view(R, C)) < 1e-5
+    # the one-call training forward (one launch for the small layers) gives the same numbers, bit for bit
+    act2, mean2, invstd2 = torch.zeros(R, C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    rm2, rv2 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    L.check(raw_.favae_bn_train_fwd(L.ptr(xd), L.ptr(g32), L.ptr(b32), L.ptr(act2), L.ptr(mean2), L.ptr(invstd2), L.ptr(rm2),
+                                    L.ptr(rv2), ll_(R), i_(C), f_(1e-5), f_(0.1), L.ptr(scratch), sz_(scratch.numel()), i_(0),
+                                    L.stream_ptr()))
+    assert _err(mean2, mean) < 1e-6 and _err(invstd2, invstd) < 1e-6 and _err(rm2, rmd) < 1e-6 and _err(rv2, rvd) < 1e-6
+    assert _err(act2, act) < 1e-6
     dad = da.view(R, C).float().to(dev).contiguous()
     draw, dg, db, dbias = (torch.zeros(R, C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev),
                            torch.zeros(C, device=dev))
