@@ -15,6 +15,7 @@
 // T = float  -> v_mfma_f32_32x32x2_f32 (exact fp32, parity path);  T = bf16 -> v_mfma_f32_32x32x16_bf16.
 // Accumulation is always fp32; outputs are fp32.
 #include <algorithm>
+#include <cstdlib>
 #include "common.h"
 #include "favae_hip.h"
 #include "smallconv.h"
@@ -567,7 +568,10 @@ int dispatch_pm(PmParams p, hipStream_t st) {
     p.ntn = cdiv(p.Cc, BN);
     const int nchunk = cdiv(p.K, BK);
     const int blocks = cdiv(p.Rc, BM) * p.ntn * p.ks * p.ks;
-    int sk = p.splitk > 0 ? p.splitk : std::min(std::max(1, nchunk / 8), std::max(1, (512 + blocks / 2) / blocks));
+    // ~256 blocks: the weight gradients run on the side stream beside the main chain; a grid that fills the chip several
+    // times over delays the main-stream kernels more than it shortens itself (tools/prof_step.py sweep)
+    static const int pm_target = getenv("FAVAE_PM_TARGET") ? atoi(getenv("FAVAE_PM_TARGET")) : 256;
+    int sk = p.splitk > 0 ? p.splitk : std::min(std::max(1, nchunk / 8), std::max(1, (pm_target + blocks / 2) / blocks));
     p.splitk = std::max(1, std::min(sk, nchunk));
     dim3 grid(cdiv(p.Rc, BM) * p.ntn, p.splitk, p.ks * p.ks);
     ProfScope prof(10 + tile, 2.0 * p.Rc * (double)p.Cc * p.K * p.ks * p.ks, st);

@@ -7,6 +7,7 @@
 // Border taps use a clamped coordinate and a 0/1 mask, so all loads of a pixel are issued together.
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include "common.h"
 #include "smallconv.h"
 
@@ -112,7 +113,8 @@ int wgrad_nw_launch(const void* wide, const void* narrow, float* dw, int Nb, int
     const int total = Nb * Hq * Wq;
     const int PP = 256 / (Cw / 4);
     // >= 256 pixels per block: the block epilogue (27 LDS reductions + one atomic pass) is worth ~16 pixel iterations
-    int ppb = std::max(256, cdiv(cdiv(total, 1024), PP) * PP);
+    static const int nw_blocks = getenv("FAVAE_NW_BLOCKS") ? atoi(getenv("FAVAE_NW_BLOCKS")) : 256;
+    int ppb = std::max(256, cdiv(cdiv(total, nw_blocks), PP) * PP);
     const int grid = cdiv(total, ppb);
     const int flip = narrow_is_large ? 0 : 1;
     return dtype == FAVAE_F32
