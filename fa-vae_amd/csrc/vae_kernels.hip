@@ -4,6 +4,7 @@
 // [rows][C] matrices.  Reference: condition_a_VAE/celeba_deepvanilla_vae.py (line numbers cited per kernel).
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include "common.h"
 #include "favae_hip.h"
 
@@ -44,7 +45,8 @@ RedGeom red_geom(long long R, int C) {
     while (g.TPR < cv && g.TPR < cap) g.TPR *= 2;
     g.RG = RED_THREADS / g.TPR;
     g.ctiles = cdiv(cv, g.TPR);
-    const int target = std::max(1, std::min(8 * (RED_THREADS / 64), 512 / g.ctiles));   // tail: <= 8 loads per thread
+    static const int red_cap = getenv("FAVAE_RED_CAP") ? atoi(getenv("FAVAE_RED_CAP")) : 128;
+    const int target = std::max(1, std::min(red_cap, 512 / g.ctiles));
     const long long min_rows = (long long)g.RG * 4;
     long long ns = std::max(1LL, std::min((long long)target, cdivll(R, min_rows)));
     if (R <= (long long)g.RG * 4) ns = 1;    // a single slab needs no cross-block hand-over at all
@@ -119,20 +121,22 @@ __global__ __launch_bounds__(RED_THREADS) void colreduce(int R, int C, int TPR, 
     if (tid == 0) is_last = __hip_atomic_fetch_add(&tickets[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nslab - 1);
     __syncthreads();
     if (!is_last) return;
-    // last block of this channel tile: CT channels x (RED_THREADS / CT) slab parts, at most 8 loads per thread and value
+    // last block of this channel tile: CT channels x (RED_THREADS / CT) slab parts
     const int CT = TPR * VW, ch = tid % CT, part = tid / CT, parts = RED_THREADS / CT;
     const int c = blockIdx.y * CT + ch;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        double x[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int i = part + q * parts;
-            x[q] = (c < C && i < nslab) ? __hip_atomic_load(&partial[((size_t)i * NV + v) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-        }
         double t = 0.0;
+        for (int base = 0; base < nslab; base += 8 * parts) {   // batches of 8 independent loads, summed in slab order
+            double x[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t += x[q];
+            for (int q = 0; q < 8; ++q) {
+                const int i = base + part + q * parts;
+                x[q] = (c < C && i < nslab) ? __hip_atomic_load(&partial[((size_t)i * NV + v) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += x[q];
+        }
         sm[v * RED_THREADS + tid] = t;
     }
     __syncthreads();
