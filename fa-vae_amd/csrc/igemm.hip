@@ -124,6 +124,7 @@ struct KcParams {
     float* out;
     int Nb, Hi, Wi, Cin, Ho, Wo, Cout;
     int ks, stride, pad, ldw, splitk, M, ntn, HoC, WoC;
+    int out_bf16;   // store the result as bf16 (unsplit reductions only)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -335,7 +336,14 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
                 }
                 float4 v = *(const float4*)(tile + row * TS + c4);
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                *(float4*)(p.out + opix * p.Cout + n) = v;
+                if (p.out_bf16) {
+                    uint2 u;
+                    u.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+                    u.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+                    *(uint2*)((bf16_t*)p.out + opix * p.Cout + n) = u;
+                } else {
+                    *(float4*)(p.out + opix * p.Cout + n) = v;
+                }
             }
             return;
         }
@@ -359,7 +367,9 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
                 float v = acc[a][b][r];
                 if (add_bias) v += p.bias[n];
                 float* dst = p.out + opix * p.Cout + n;
-                if (p.splitk > 1) atomicAdd(dst, v); else *dst = v;
+                if (p.out_bf16) ((bf16_t*)p.out)[opix * p.Cout + n] = f32_to_bf16(v);
+                else if (p.splitk > 1) atomicAdd(dst, v);
+                else *dst = v;
             }
         }
     }
@@ -551,6 +561,7 @@ int dispatch_kc(KcParams p, int classes, int target_blocks, hipStream_t st) {
     if (p.splitk > 0) sk = p.splitk;
     else if (2 * blocks < target_blocks) sk = std::min(std::max(1, nchunk / 4), (target_blocks + blocks / 2) / blocks);
     p.splitk = std::max(1, std::min(sk, nchunk));
+    if (p.out_bf16) p.splitk = 1;   // a bf16 result cannot be accumulated across blocks
     if (p.splitk > 1 && !prezeroed)
         FAVAE_HIP(hipMemsetAsync(p.out, 0, (size_t)p.Nb * p.Ho * p.Wo * p.Cout * sizeof(float), st));
     if (slow) return launch_kc<T, TR, true, 64, 64, 2, 2>(p, classes, st);
@@ -591,7 +602,10 @@ extern "C" int favae_conv_igemm(const void* in, const void* w, const float* bias
     FAVAE_CHECK_ARG(Nb > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Ho > 0 && Wo > 0 && Cout > 0, "favae_conv_igemm: bad shape");
     FAVAE_CHECK_ARG((ks == 1 && pad == 0) || (ks == 3 && pad == 1), "favae_conv_igemm: ks/pad must be 1/0 or 3/1");
     FAVAE_CHECK_ARG(stride == 1 || stride == 2, "favae_conv_igemm: stride must be 1 or 2");
+    const int out_bf16 = (dtype & FAVAE_OUT_BF16) != 0;
+    dtype &= 0xF;
     FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_conv_igemm: dtype");
+    FAVAE_CHECK_ARG(!(out_bf16 && dtype != FAVAE_BF16), "favae_conv_igemm: FAVAE_OUT_BF16 needs FAVAE_BF16");
     FAVAE_CHECK_ARG(!(stride == 2 && ks != 3), "favae_conv_igemm: stride 2 needs ks 3");
     if (scatter) FAVAE_CHECK_ARG(Ho == Hi * stride && Wo == Wi * stride, "favae_conv_igemm: scatter form needs Ho = s*Hi");
     else FAVAE_CHECK_ARG(Ho == (Hi + 2 * pad - ks) / stride + 1 && Wo == (Wi + 2 * pad - ks) / stride + 1,
@@ -604,12 +618,12 @@ extern "C" int favae_conv_igemm(const void* in, const void* w, const float* bias
     // one thread per output pixel pays off once the pixel count fills the chip several times over (the decoder side)
     if (g_force_kc_tile < 0 && (long long)Nb * Ho * Wo >= 131072 && thin_in_applicable(Cin, Cout, ks, stride, scatter)) {
         ProfScope prof(14, 2.0 * Nb * Ho * Wo * (double)Cout * 9 * Cin, (hipStream_t)stream);
-        return thin_in_launch(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, stride, scatter, dtype, (hipStream_t)stream);
+        return thin_in_launch(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, stride, scatter, dtype, out_bf16, (hipStream_t)stream);
     }
     KcParams p;
     p.in = in; p.w = w; p.bias = bias; p.out = out;
     p.Nb = Nb; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
-    p.ks = ks; p.stride = stride; p.pad = pad; p.ldw = ks * ks * Cin; p.splitk = splitk;
+    p.ks = ks; p.stride = stride; p.pad = pad; p.ldw = ks * ks * Cin; p.splitk = splitk; p.out_bf16 = out_bf16;
     int classes = 1;
     if (scatter && stride == 2) { classes = 4; p.HoC = Ho / 2; p.WoC = Wo / 2; }
     else { p.HoC = Ho; p.WoC = Wo; }

@@ -8,4 +8,4 @@ int wgrad_nw_launch(const void* wide, const void* narrow, float* dw, int Nb, int
                     int stride, int narrow_is_large, int s_ch, int s_tap, int s_c, int dtype, hipStream_t st);
 bool thin_in_applicable(int Cs, int Co, int ks, int stride, int scatter);
 int thin_in_launch(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cs, int Ho, int Wo,
-                   int Co, int stride, int scatter, int dtype, hipStream_t st);
+                   int Co, int stride, int scatter, int dtype, int out_bf16, hipStream_t st);

@@ -134,7 +134,7 @@ namespace {
 template <class T, int CS, int CO>
 __global__ __launch_bounds__(256) void conv_thin_in(const T* __restrict__ in, const float* __restrict__ wk /* [9*CS][CO] fp32 */,
                                                     const float* __restrict__ bias, float* __restrict__ out, int Hi, int Wi,
-                                                    int Ho, int Wo, int stride, int flip, int total) {
+                                                    int Ho, int Wo, int stride, int flip, int total, int out_bf16) {
     const int pix = min(blockIdx.x * 256 + (int)threadIdx.x, total - 1);   // tail threads redo the last pixel, store nothing
     const int n = pix / (Ho * Wo), rem = pix - n * Ho * Wo, y = rem / Wo, x = rem - y * Wo;
     float v[9 * CS];
@@ -180,7 +180,17 @@ __global__ __launch_bounds__(256) void conv_thin_in(const T* __restrict__ in, co
 #pragma unroll
         for (int i = 0; i < 64 / PPI; ++i) {
             const int pr = i * PPI + lane / LPR, c4 = (lane % LPR) * 4;
-            if (pix_w0 + pr < total) *(float4*)(out + (size_t)(pix_w0 + pr) * CO + hb + c4) = *(const float4*)(wt + pr * RSF + c4);
+            if (pix_w0 + pr < total) {
+                const float4 r4 = *(const float4*)(wt + pr * RSF + c4);
+                if (out_bf16) {
+                    uint2 u;
+                    u.x = (unsigned)f32_to_bf16(r4.x) | ((unsigned)f32_to_bf16(r4.y) << 16);
+                    u.y = (unsigned)f32_to_bf16(r4.z) | ((unsigned)f32_to_bf16(r4.w) << 16);
+                    *(uint2*)((bf16_t*)out + (size_t)(pix_w0 + pr) * CO + hb + c4) = u;
+                } else {
+                    *(float4*)(out + (size_t)(pix_w0 + pr) * CO + hb + c4) = r4;
+                }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -209,7 +219,7 @@ std::atomic<unsigned> g_wk_next{0};
 }  // namespace
 
 int thin_in_launch(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cs, int Ho, int Wo,
-                   int Co, int stride, int scatter, int dtype, hipStream_t st) {
+                   int Co, int stride, int scatter, int dtype, int out_bf16, hipStream_t st) {
     static float* per_device[64] = {nullptr};
     int dev = 0;
     FAVAE_HIP(hipGetDevice(&dev));
@@ -224,7 +234,7 @@ int thin_in_launch(const void* in, const void* w, const float* bias, float* out,
         hipLaunchKernelGGL(thin_in_wprep<bf16_t>, dim3(cdiv(K * Co, 256)), dim3(256), 0, st, (const bf16_t*)w, wk_scratch, K, Co);
 #define TI_CASE(T_, CS_)                                                                                                   \
     hipLaunchKernelGGL((conv_thin_in<T_, CS_, 64>), dim3(grid), dim3(256), 4 * 64 * (32 + 4) * sizeof(float), st, (const T_*)in, wk_scratch, bias, out, Hi, Wi, \
-                       Ho, Wo, stride, scatter, total)
+                       Ho, Wo, stride, scatter, total, out_bf16)
     if (dtype == FAVAE_F32) {
         switch (Cs) { case 1: TI_CASE(float, 1); break; case 2: TI_CASE(float, 2); break; case 3: TI_CASE(float, 3); break; default: TI_CASE(float, 4); }
     } else {

@@ -4,6 +4,7 @@
 // [rows][C] matrices.  Reference: condition_a_VAE/celeba_deepvanilla_vae.py (line numbers cited per kernel).
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 #include <cstdlib>
 #include "common.h"
 #include "favae_hip.h"
@@ -46,7 +47,8 @@ RedGeom red_geom(long long R, int C) {
     g.RG = RED_THREADS / g.TPR;
     g.ctiles = cdiv(cv, g.TPR);
     static const int red_cap = getenv("FAVAE_RED_CAP") ? atoi(getenv("FAVAE_RED_CAP")) : 128;
-    const int target = std::max(1, std::min(red_cap, 512 / g.ctiles));
+    static const int red_cap_big = getenv("FAVAE_RED_CAP_BIG") ? atoi(getenv("FAVAE_RED_CAP_BIG")) : 256;
+    const int target = std::max(1, std::min(R >= 200000 ? red_cap_big : red_cap, 512 / g.ctiles));
     const long long min_rows = (long long)g.RG * 4;
     long long ns = std::max(1LL, std::min((long long)target, cdivll(R, min_rows)));
     if (R <= (long long)g.RG * 4) ns = 1;    // a single slab needs no cross-block hand-over at all
@@ -194,13 +196,14 @@ template <class T> struct VecLoad<T, 1> {
 };
 
 // ---- BatchNorm2d (train) statistics: nn.BatchNorm2d(h_dim), celeba_deepvanilla_vae.py:34,58,72 -------------
+template <class RT>
 struct StatsF {
-    const float* x; int C; double R; float eps, mom; float *mean, *invstd, *run_mean, *run_var;
+    const RT* x; int C; double R; float eps, mom; float *mean, *invstd, *run_mean, *run_var;
     struct Ctx {};
     __device__ void init(Ctx&, int) const {}
     template <int VW> __device__ void row(const Ctx&, int r, int c0, double (*acc)[VW]) const {
         float v[VW];
-        VecLoad<float, VW>::ld(x + (size_t)r * C + c0, v);
+        VecLoad<RT, VW>::ld(x + (size_t)r * C + c0, v);
 #pragma unroll
         for (int j = 0; j < VW; ++j) { acc[0][j] += v[j]; acc[1][j] += (double)v[j] * v[j]; }
     }
@@ -248,8 +251,8 @@ __device__ __forceinline__ float lrelu(float y) { return y > 0.f ? y : 0.01f * y
 
 // The grid stride is a multiple of C (host picks it), so a thread keeps its 4 channels for the whole loop and the
 // affine form y = x * a + b is set up once.
-template <class T>
-__global__ __launch_bounds__(256) void bn_lrelu_fwd(const float* __restrict__ raw, const float* __restrict__ mean,
+template <class T, class RT>
+__global__ __launch_bounds__(256) void bn_lrelu_fwd(const RT* __restrict__ raw, const float* __restrict__ mean,
                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, T* __restrict__ act, size_t nvec, int C,
                                                     int apply_act) {
@@ -263,8 +266,9 @@ __global__ __launch_bounds__(256) void bn_lrelu_fwd(const float* __restrict__ ra
     }
 #pragma unroll 4
     for (size_t i = i0; i < nvec; i += stride) {
-        const float4 x = *(const float4*)(raw + i * 4);
-        float y[4] = {x.x * a[0] + b[0], x.y * a[1] + b[1], x.z * a[2] + b[2], x.w * a[3] + b[3]};
+        float x[4];
+        VecLoad<RT, 4>::ld(raw + i * 4, x);
+        float y[4] = {x[0] * a[0] + b[0], x[1] * a[1] + b[1], x[2] * a[2] + b[2], x[3] * a[3] + b[3]};
         if (apply_act) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = lrelu(y[j]);
@@ -274,9 +278,9 @@ __global__ __launch_bounds__(256) void bn_lrelu_fwd(const float* __restrict__ ra
 }
 
 // ---- BN + LeakyReLU backward ---------------------------------------------------------------------------------
-template <class T>
+template <class T, class RT, class DT>
 struct BnBwdRedF {
-    const float* dact; const T* act; const float* raw; const float* mean; const float* invstd; int C;
+    const DT* dact; const T* act; const RT* raw; const float* mean; const float* invstd; int C;
     float *dgamma, *dbeta, *s1s2;
     struct Ctx { float mu[4], is[4]; };
     __device__ void init(Ctx& k, int c0) const {
@@ -286,8 +290,8 @@ struct BnBwdRedF {
         const size_t i = (size_t)r * C + c0;
         float a[VW], d[VW], x[VW];
         VecLoad<T, VW>::ld(act + i, a);
-        VecLoad<float, VW>::ld(dact + i, d);
-        VecLoad<float, VW>::ld(raw + i, x);
+        VecLoad<DT, VW>::ld(dact + i, d);
+        VecLoad<RT, VW>::ld(raw + i, x);
 #pragma unroll
         for (int j = 0; j < VW; ++j) {
             const float dd = d[j] * (a[j] > 0.f ? 1.f : 0.01f);
@@ -303,9 +307,9 @@ struct BnBwdRedF {
     }
 };
 
-template <class T>
+template <class T, class RT, class DT>
 struct BnBwdApplyF {
-    const float* dact; const T* act; const float* raw; const float* mean; const float* invstd; const float* gamma;
+    const DT* dact; const T* act; const RT* raw; const float* mean; const float* invstd; const float* gamma;
     const float* s1s2; T* draw; int C; float invR; float* dbias;
     struct Ctx { float mu[4], is[4], gi[4], k1[4], k2[4]; };
     __device__ void init(Ctx& k, int c0) const {
@@ -318,8 +322,8 @@ struct BnBwdApplyF {
         const size_t i = (size_t)r * C + c0;
         float a[VW], d[VW], x[VW], g[VW];
         VecLoad<T, VW>::ld(act + i, a);
-        VecLoad<float, VW>::ld(dact + i, d);
-        VecLoad<float, VW>::ld(raw + i, x);
+        VecLoad<DT, VW>::ld(dact + i, d);
+        VecLoad<RT, VW>::ld(raw + i, x);
 #pragma unroll
         for (int j = 0; j < VW; ++j) {
             const float dd = d[j] * (a[j] > 0.f ? 1.f : 0.01f);
@@ -742,10 +746,14 @@ inline int ew_grid(size_t n) { return (int)std::min<size_t>(4096, std::max<size_
 
 #define ST ((hipStream_t)stream)
 
+#define DT_BASE(d) ((d) & 0xF)
+#define RAW_IS_BF16(d) (((d) & FAVAE_RAW_BF16) != 0)
+#define DACT_IS_BF16(d) (((d) & FAVAE_DACT_BF16) != 0)
+
 extern "C" int favae_bn_stats(const float* raw, long long R, int C, float eps, float momentum, float* mean, float* invstd,
                               float* run_mean, float* run_var, double* scratch, size_t scratch_doubles, void* stream) {
     FAVAE_CHECK_ARG(raw && mean && invstd && scratch && R > 0 && C > 0 && R < (1LL << 31), "favae_bn_stats: bad argument");
-    return run_colreduce<2>(R, C, scratch, scratch_doubles, StatsF{raw, C, (double)R, eps, momentum, mean, invstd, run_mean, run_var}, ST);
+    return run_colreduce<2>(R, C, scratch, scratch_doubles, StatsF<float>{raw, C, (double)R, eps, momentum, mean, invstd, run_mean, run_var}, ST);
 }
 
 extern "C" int favae_bn_eval_prep(const float* run_mean, const float* run_var, int C, float eps, float* mean, float* invstd,
@@ -756,9 +764,10 @@ extern "C" int favae_bn_eval_prep(const float* run_mean, const float* run_var, i
     return FAVAE_OK;
 }
 
-extern "C" int favae_bn_lrelu_fwd(const float* raw, const float* mean, const float* invstd, const float* gamma,
+extern "C" int favae_bn_lrelu_fwd(const void* raw, const float* mean, const float* invstd, const float* gamma,
                                   const float* beta, void* act, long long R, int C, int apply_act, int dtype, void* stream) {
     FAVAE_CHECK_ARG(raw && mean && invstd && gamma && beta && act && R > 0 && C > 0 && C % 4 == 0, "favae_bn_lrelu_fwd: bad argument");
+    FAVAE_CHECK_ARG(!(RAW_IS_BF16(dtype) && DT_BASE(dtype) != FAVAE_BF16), "favae_bn_lrelu_fwd: FAVAE_RAW_BF16 needs FAVAE_BF16");
     const size_t nvec = (size_t)R * C / 4;
     // grid stride (vectors) must be a multiple of C/4: blocks of 256 vectors, grid a multiple of C/4 / gcd(C/4, 256)
     int c4 = C / 4, gg = c4, t = 256;
@@ -766,60 +775,79 @@ extern "C" int favae_bn_lrelu_fwd(const float* raw, const float* mean, const flo
     const int mult = c4 / gg;
     long long grid = (long long)std::min<size_t>(2048, (nvec + 255) / 256);
     grid = std::max<long long>(mult, grid / mult * mult);
-    if (dtype == FAVAE_F32)
-        hipLaunchKernelGGL(bn_lrelu_fwd<float>, dim3((unsigned)grid), dim3(256), 0, ST, raw, mean, invstd, gamma, beta, (float*)act, nvec, C, apply_act);
+    if (DT_BASE(dtype) == FAVAE_F32)
+        hipLaunchKernelGGL((bn_lrelu_fwd<float, float>), dim3((unsigned)grid), dim3(256), 0, ST, (const float*)raw, mean, invstd, gamma, beta, (float*)act, nvec, C, apply_act);
+    else if (RAW_IS_BF16(dtype))
+        hipLaunchKernelGGL((bn_lrelu_fwd<bf16_t, bf16_t>), dim3((unsigned)grid), dim3(256), 0, ST, (const bf16_t*)raw, mean, invstd, gamma, beta, (bf16_t*)act, nvec, C, apply_act);
     else
-        hipLaunchKernelGGL(bn_lrelu_fwd<bf16_t>, dim3((unsigned)grid), dim3(256), 0, ST, raw, mean, invstd, gamma, beta, (bf16_t*)act, nvec, C, apply_act);
+        hipLaunchKernelGGL((bn_lrelu_fwd<bf16_t, float>), dim3((unsigned)grid), dim3(256), 0, ST, (const float*)raw, mean, invstd, gamma, beta, (bf16_t*)act, nvec, C, apply_act);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }
 
-extern "C" int favae_bn_train_fwd(const float* raw, const float* gamma, const float* beta, void* act, float* mean,
+extern "C" int favae_bn_train_fwd(const void* raw, const float* gamma, const float* beta, void* act, float* mean,
                                   float* invstd, float* run_mean, float* run_var, long long R, int C, float eps, float momentum,
                                   double* scratch, size_t scratch_doubles, int dtype, void* stream) {
     FAVAE_CHECK_ARG(raw && gamma && beta && act && mean && invstd && scratch && R > 0 && R < (1LL << 31) && C > 0 && C % 4 == 0,
                     "favae_bn_train_fwd: bad argument");
+    FAVAE_CHECK_ARG(!(RAW_IS_BF16(dtype) && DT_BASE(dtype) != FAVAE_BF16), "favae_bn_train_fwd: FAVAE_RAW_BF16 needs FAVAE_BF16");
+    if (RAW_IS_BF16(dtype)) {
+        int rc = run_colreduce<2>(R, C, scratch, scratch_doubles,
+                                  StatsF<bf16_t>{(const bf16_t*)raw, C, (double)R, eps, momentum, mean, invstd, run_mean, run_var}, ST);
+        if (rc) return rc;
+        return favae_bn_lrelu_fwd(raw, mean, invstd, gamma, beta, act, R, C, 1, dtype, stream);
+    }
+    const float* rawf = (const float*)raw;
     if (owner_applicable(R, C)) {
-        if (dtype == FAVAE_F32)
-            hipLaunchKernelGGL(bn_fwd_owner<float>, dim3(C / OWN_CT), dim3(OWN_THREADS), 0, ST, raw, gamma, beta, (float*)act, mean,
+        if (DT_BASE(dtype) == FAVAE_F32)
+            hipLaunchKernelGGL(bn_fwd_owner<float>, dim3(C / OWN_CT), dim3(OWN_THREADS), 0, ST, rawf, gamma, beta, (float*)act, mean,
                                invstd, run_mean, run_var, (int)R, C, eps, momentum);
         else
-            hipLaunchKernelGGL(bn_fwd_owner<bf16_t>, dim3(C / OWN_CT), dim3(OWN_THREADS), 0, ST, raw, gamma, beta, (bf16_t*)act, mean,
+            hipLaunchKernelGGL(bn_fwd_owner<bf16_t>, dim3(C / OWN_CT), dim3(OWN_THREADS), 0, ST, rawf, gamma, beta, (bf16_t*)act, mean,
                                invstd, run_mean, run_var, (int)R, C, eps, momentum);
         FAVAE_LAUNCH_CHECK();
         return FAVAE_OK;
     }
-    int rc = favae_bn_stats(raw, R, C, eps, momentum, mean, invstd, run_mean, run_var, scratch, scratch_doubles, stream);
+    int rc = favae_bn_stats(rawf, R, C, eps, momentum, mean, invstd, run_mean, run_var, scratch, scratch_doubles, stream);
     if (rc) return rc;
     return favae_bn_lrelu_fwd(raw, mean, invstd, gamma, beta, act, R, C, 1, dtype, stream);
 }
 
-template <class T>
-static int bn_bwd_impl(const float* dact, const T* act, const float* raw, const float* mean, const float* invstd,
-                       const float* gamma, T* draw, float* dgamma, float* dbeta, float* dbias, long long R, int C,
+template <class T, class RT, class DT>
+static int bn_bwd_impl(const void* dact_, const void* act_, const void* raw_, const float* mean, const float* invstd,
+                       const float* gamma, void* draw_, float* dgamma, float* dbeta, float* dbias, long long R, int C,
                        double* scratch, size_t cap, float* s1s2, hipStream_t st) {
-    if (owner_applicable(R, C)) {
-        hipLaunchKernelGGL(bn_bwd_owner<T>, dim3(C / OWN_CT), dim3(OWN_THREADS), 0, st, dact, act, raw, mean, invstd, gamma, draw,
-                           dgamma, dbeta, dbias, (int)R, C);
-        FAVAE_LAUNCH_CHECK();
-        return FAVAE_OK;
+    const DT* dact = (const DT*)dact_; const T* act = (const T*)act_; const RT* raw = (const RT*)raw_; T* draw = (T*)draw_;
+    if constexpr (std::is_same<RT, float>::value && std::is_same<DT, float>::value) {
+        if (owner_applicable(R, C)) {
+            hipLaunchKernelGGL(bn_bwd_owner<T>, dim3(C / OWN_CT), dim3(OWN_THREADS), 0, st, dact, act, raw, mean, invstd, gamma, draw,
+                               dgamma, dbeta, dbias, (int)R, C);
+            FAVAE_LAUNCH_CHECK();
+            return FAVAE_OK;
+        }
     }
-    int rc = run_colreduce<2>(R, C, scratch, cap, BnBwdRedF<T>{dact, act, raw, mean, invstd, C, dgamma, dbeta, s1s2}, st);
+    int rc = run_colreduce<2>(R, C, scratch, cap, BnBwdRedF<T, RT, DT>{dact, act, raw, mean, invstd, C, dgamma, dbeta, s1s2}, st);
     if (rc) return rc;
     return run_colreduce<1>(R, C, scratch, cap,
-                            BnBwdApplyF<T>{dact, act, raw, mean, invstd, gamma, s1s2, draw, C, (float)(1.0 / (double)R), dbias}, st);
+                            BnBwdApplyF<T, RT, DT>{dact, act, raw, mean, invstd, gamma, s1s2, draw, C, (float)(1.0 / (double)R), dbias}, st);
 }
 
-extern "C" int favae_bn_lrelu_bwd(const float* dact, const void* act, const float* raw, const float* mean,
+extern "C" int favae_bn_lrelu_bwd(const void* dact, const void* act, const void* raw, const float* mean,
                                   const float* invstd, const float* gamma, void* draw, float* dgamma, float* dbeta,
                                   float* dbias, long long R, int C, double* scratch, size_t scratch_doubles, float* s1s2,
                                   int dtype, void* stream) {
     FAVAE_CHECK_ARG(dact && act && raw && mean && invstd && gamma && draw && dgamma && dbeta && scratch && s1s2,
                     "favae_bn_lrelu_bwd: null pointer");
     FAVAE_CHECK_ARG(R > 0 && R < (1LL << 31) && C > 0, "favae_bn_lrelu_bwd: bad shape");
-    if (dtype == FAVAE_F32)
-        return bn_bwd_impl<float>(dact, (const float*)act, raw, mean, invstd, gamma, (float*)draw, dgamma, dbeta, dbias, R, C, scratch, scratch_doubles, s1s2, ST);
-    return bn_bwd_impl<bf16_t>(dact, (const bf16_t*)act, raw, mean, invstd, gamma, (bf16_t*)draw, dgamma, dbeta, dbias, R, C, scratch, scratch_doubles, s1s2, ST);
+    FAVAE_CHECK_ARG(!((RAW_IS_BF16(dtype) || DACT_IS_BF16(dtype)) && (DT_BASE(dtype) != FAVAE_BF16 || C % 4 != 0)),
+                    "favae_bn_lrelu_bwd: FAVAE_RAW_BF16 / FAVAE_DACT_BF16 need FAVAE_BF16 and C %% 4 == 0");
+#define BWD_ARGS dact, act, raw, mean, invstd, gamma, draw, dgamma, dbeta, dbias, R, C, scratch, scratch_doubles, s1s2, ST
+    if (DT_BASE(dtype) == FAVAE_F32) return bn_bwd_impl<float, float, float>(BWD_ARGS);
+    if (RAW_IS_BF16(dtype) && DACT_IS_BF16(dtype)) return bn_bwd_impl<bf16_t, bf16_t, bf16_t>(BWD_ARGS);
+    if (RAW_IS_BF16(dtype)) return bn_bwd_impl<bf16_t, bf16_t, float>(BWD_ARGS);
+    if (DACT_IS_BF16(dtype)) return bn_bwd_impl<bf16_t, float, bf16_t>(BWD_ARGS);
+    return bn_bwd_impl<bf16_t, float, float>(BWD_ARGS);
+#undef BWD_ARGS
 }
 
 extern "C" int favae_colsum(const void* x, long long R, int C, float* out, double* scratch, size_t scratch_doubles, int dtype,

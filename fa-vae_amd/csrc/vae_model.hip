@@ -80,6 +80,8 @@ struct Vae {
     size_t scratch_doubles;
     // split-K targets small enough to be zeroed by one memset per training step
     bool raw_pooled[NL], dact_pooled[NL];
+    // bf16 path: conv output (raw) and activation gradient (dact) of the largest BN layers are stored as bf16
+    bool raw_bf[NL], dact_bf[NL];
     char* zero_lo; size_t zero_bytes;
     // weight gradients run on a second stream next to the dgrad -> BN-backward chain of the main stream
     hipStream_t side; hipEvent_t ev_fork[NL]; hipEvent_t ev_join; bool overlap;
@@ -100,7 +102,19 @@ struct Carver {
     }
 };
 
+void choose_storage(Vae& v) {
+    // Off by default: measured on MI355X the bf16 storage of raw/dact does not shorten the BN kernels of these layers (they
+    // are bound by launch geometry, not by bytes), so the extra rounding buys nothing.  FAVAE_BF16_RAW=1 turns it on.
+    const char* e = getenv("FAVAE_BF16_RAW");
+    const bool off = v.dtype != FAVAE_BF16 || !(e && e[0] == '1');
+    for (int l = 0; l < NL; ++l) {
+        const size_t n = (size_t)v.rows(l, v.Bmax) * v.L[l].Cout;
+        v.raw_bf[l] = v.dact_bf[l] = !off && v.L[l].bn && n >= ((size_t)1 << 22);
+    }
+}
+
 void carve(Vae& v, char* base, size_t cap, size_t* need) {
+    choose_storage(v);
     Carver c{base, 0, cap};
     const int B = v.Bmax;
     // zero pool first: the fp32 conv outputs (raw) and input gradients (dact) of the layers whose GEMMs may split the
@@ -123,8 +137,8 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
     for (int l = 0; l < NL; ++l) {
         const size_t n = (size_t)v.rows(l, B) * v.L[l].Cout;
         if (n > pool_max) {
-            v.raw[l] = (float*)c.take(n * 4);
-            v.dact[l] = (float*)c.take(n * 4);
+            v.raw[l] = (float*)c.take(n * (v.raw_bf[l] ? 2 : 4));
+            v.dact[l] = (float*)c.take(n * (v.dact_bf[l] ? 2 : 4));
         }
         v.act[l] = (char*)c.take(n * v.esz);
         v.draw[l] = (char*)c.take(n * v.esz);
@@ -149,26 +163,28 @@ int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false
     const Layer& L = v.L[l];
     const float* bias = v.P + L.b_off;
     const int sk = (pooled && v.raw_pooled[l]) ? -1 : 0;
+    const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_OUT_BF16 : 0);
     switch (L.kind) {
     case CONV_S2:
-        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 2, 1, 0, sk, v.dtype, st);
+        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 2, 1, 0, sk, dt, st);
     case CONV_S1:
-        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 1, 1, 0, sk, v.dtype, st);
+        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 1, 1, 0, sk, dt, st);
     case CONVT_S2:
-        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 2, 1, 1, sk, v.dtype, st);
+        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 2, 1, 1, sk, dt, st);
     default:
-        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, 1, 1, L.Cin, 1, 1, L.Cout, 1, 1, 0, 0, sk, v.dtype, st);
+        return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, 1, 1, L.Cin, 1, 1, L.Cout, 1, 1, 0, 0, sk, dt, st);
     }
 }
 
 int bn_fwd(Vae& v, int l, int B, bool train, void* st) {
     const Layer& L = v.L[l];
     const long long R = v.rows(l, B);
+    const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0);
     if (train)
         return favae_bn_train_fwd(v.raw[l], v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l], v.invstd[l], v.BUF + L.rm_off,
-                                  v.BUF + L.rv_off, R, L.Cout, 1e-5f, 0.1f, v.scratch, v.scratch_doubles, v.dtype, st);
+                                  v.BUF + L.rv_off, R, L.Cout, 1e-5f, 0.1f, v.scratch, v.scratch_doubles, dt, st);
     RC(favae_bn_eval_prep(v.BUF + L.rm_off, v.BUF + L.rv_off, L.Cout, 1e-5f, v.mean[l], v.invstd[l], st));
-    return favae_bn_lrelu_fwd(v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.P + L.be_off, v.act[l], R, L.Cout, 1, v.dtype, st);
+    return favae_bn_lrelu_fwd(v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.P + L.be_off, v.act[l], R, L.Cout, 1, dt, st);
 }
 
 int encoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false) {
@@ -196,7 +212,8 @@ int decoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false) {
 int bn_bwd(Vae& v, int l, int B, void* st) {
     const Layer& L = v.L[l];
     return favae_bn_lrelu_bwd(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.draw[l], v.G + L.g_off,
-                              v.G + L.be_off, v.G + L.b_off, v.rows(l, B), L.Cout, v.scratch, v.scratch_doubles, v.s1s2, v.dtype, st);
+                              v.G + L.be_off, v.G + L.b_off, v.rows(l, B), L.Cout, v.scratch, v.scratch_doubles, v.s1s2,
+                              v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0) | (v.dact_bf[l] ? FAVAE_DACT_BF16 : 0), st);
 }
 
 int wgrad_launch(Vae& v, int l, const void* in, int B, void* st);
@@ -245,18 +262,19 @@ int wgrad_launch(Vae& v, int l, const void* in, int B, void* st) {
 }
 
 // input gradient of layer l: draw[l] -> out (fp32, shaped like the layer input)
-int dgrad(Vae& v, int l, float* out, int B, void* st, bool out_zeroed) {
+int dgrad(Vae& v, int l, float* out, int B, void* st, bool out_zeroed, bool out_bf = false) {
     const Layer& L = v.L[l];
     const int sk = out_zeroed ? -1 : 0;
+    const int dt = v.dtype | (out_bf ? FAVAE_OUT_BF16 : 0);
     switch (L.kind) {
     case CONV_S2:   // scatter form with [Cin][tap][Cout]
-        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, 2, 1, 1, sk, v.dtype, st);
+        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, 2, 1, 1, sk, dt, st);
     case CONV_S1:
-        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, 1, 1, 1, sk, v.dtype, st);
+        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, 1, 1, 1, sk, dt, st);
     case CONVT_S2:  // gather form
-        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, 2, 1, 0, sk, v.dtype, st);
+        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, 2, 1, 0, sk, dt, st);
     default:
-        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, 1, 1, L.Cout, 1, 1, L.Cin, 1, 1, 0, 0, sk, v.dtype, st);
+        return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, 1, 1, L.Cout, 1, 1, L.Cin, 1, 1, 0, 0, sk, dt, st);
     }
 }
 
@@ -385,11 +403,11 @@ extern "C" int favae_vae_train_fwdbwd(favae_vae* h, const float* data_nhwc, cons
     // ---- backward ----
     RC(favae_colsum(v.draw[L_OUT], v.rows(L_OUT, B), v.ch, v.G + v.L[L_OUT].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
     RC(wgrad(v, L_OUT, v.act[11], B, st));
-    RC(dgrad(v, L_OUT, v.dact[11], B, st, v.dact_pooled[11]));
+    RC(dgrad(v, L_OUT, v.dact[11], B, st, v.dact_pooled[11], v.dact_bf[11]));
     for (int l = 11; l >= 7; --l) {
         RC(bn_bwd(v, l, B, st));
         RC(wgrad(v, l, v.act[l - 1], B, st));
-        RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1]));
+        RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1], v.dact_bf[l - 1]));
     }
     RC(favae_cast(v.dact[L_DI], v.draw[L_DI], (long long)B * 4096, v.dtype, st));
     RC(favae_colsum(v.draw[L_DI], B, 4096, v.G + v.L[L_DI].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
@@ -402,7 +420,7 @@ extern "C" int favae_vae_train_fwdbwd(favae_vae* h, const float* data_nhwc, cons
     for (int l = 4; l >= 1; --l) {
         RC(bn_bwd(v, l, B, st));
         RC(wgrad(v, l, v.act[l - 1], B, st));
-        RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1]));
+        RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1], v.dact_bf[l - 1]));
     }
     RC(bn_bwd(v, 0, B, st));
     RC(wgrad(v, 0, v.xt, B, st));

@@ -26,6 +26,12 @@ extern "C" {
 
 #define FAVAE_F32 0
 #define FAVAE_BF16 1
+/* Storage flags, OR-ed into a `dtype` argument together with FAVAE_BF16 (the fp32 parity path never uses them): the
+ * conv output / BN input tensor `raw`, or the activation gradient `dact`, is stored as bf16 instead of fp32.  Used for
+ * the 64-channel layers of 4-17 M elements per batch, where every fp32 pass over the tensor is HBM time. */
+#define FAVAE_RAW_BF16 0x10
+#define FAVAE_DACT_BF16 0x20
+#define FAVAE_OUT_BF16 0x40
 
 const char* favae_last_error(void);
 int favae_version(void);
@@ -73,17 +79,17 @@ int favae_bn_stats(const float* raw, long long R, int C, float eps, float moment
 int favae_bn_eval_prep(const float* run_mean, const float* run_var, int C, float eps, float* mean, float* invstd,
                        void* stream);
 /* act = LeakyReLU_0.01((raw-mean)*invstd*gamma+beta) stored as dtype (:34-35); apply_act=0 skips the LeakyReLU. */
-int favae_bn_lrelu_fwd(const float* raw, const float* mean, const float* invstd, const float* gamma, const float* beta,
+int favae_bn_lrelu_fwd(const void* raw, const float* mean, const float* invstd, const float* gamma, const float* beta,
                        void* act, long long R, int C, int apply_act, int dtype, void* stream);
 /* Training-mode BN + LeakyReLU in one call (statistics, running-stat update, apply; :34-35 under self.train()): same
  * results as favae_bn_stats followed by favae_bn_lrelu_fwd; small layers (R <= 1024) run as one launch. */
-int favae_bn_train_fwd(const float* raw, const float* gamma, const float* beta, void* act, float* mean, float* invstd,
+int favae_bn_train_fwd(const void* raw, const float* gamma, const float* beta, void* act, float* mean, float* invstd,
                        float* run_mean, float* run_var, long long R, int C, float eps, float momentum, double* scratch,
                        size_t scratch_doubles, int dtype, void* stream);
 /* backward of BN(train)+LeakyReLU (autograd of :34-35 under loss.backward() :249): draw (dtype) = d loss / d raw,
  * dgamma, dbeta, and dbias = column sums of draw (gradient of the preceding conv bias; NULL to skip).
  * s1s2: 2*C floats of scratch. */
-int favae_bn_lrelu_bwd(const float* dact, const void* act, const float* raw, const float* mean, const float* invstd,
+int favae_bn_lrelu_bwd(const void* dact, const void* act, const void* raw, const float* mean, const float* invstd,
                        const float* gamma, void* draw, float* dgamma, float* dbeta, float* dbias, long long R, int C,
                        double* scratch, size_t scratch_doubles, float* s1s2, int dtype, void* stream);
 /* out[c] = sum_r x[r][c]  (bias gradients of layers without BN). */

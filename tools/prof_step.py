@@ -27,6 +27,8 @@ torch.cuda.synchronize()
 for r in range(reps):
     t = time.time()
     eng.train_epoch(data, perm, eps, prior, 1.5, 1.0, 0.01, 1e-3, 64, metrics)
+    t_enq = time.time() - t
     torch.cuda.synchronize()
     dt = time.time() - t
+    print('host enqueue %.3f ms/step' % (1e3 * t_enq / nsteps))
     print('%s epoch N=%d: %.3f s  %.3f ms/step  %.0f samples/s  loss %.1f' % (dtype, N, dt, 1e3 * dt / nsteps, N / dt, metrics[-1, 0].item()))
