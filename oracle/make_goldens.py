@@ -14,6 +14,8 @@ Fixtures
   predict_fa_A/B.npz      SSHIBA.predict after the FA-only fits: 'mult' view in -> 'reg' view out and -> 'mult' view out.
   favae_A_predict.npz     after the favae_A fit: predict img -> mult, mult -> img (decoder of a sampled latent),
                           predict_sameimage mult -> img (seeds set before each call).
+  favae_B.npz             full variant-B (domain_adaptation) fit: two image views (z=8) + one 'mult' view, N=16, Kc=4,
+                          2 iterations (50 + 20 epochs per view), then predict image view 0 -> image view 1.
   favae_A.npz             full variant-A fit, one image view (z=8) + one 'mult' view, N=32, Kc=4, 2 iterations
                           (50 + 5 epochs as the reference schedules them).
 """
@@ -215,6 +217,34 @@ def gen_favae_A():
     print("favae_A_predict: img->mult mean", float(pr["i2m_mean"].mean()), "mult->img", pr["m2i_img"][:2], pr["same_img"][:2])
 
 
+def gen_favae_B():
+    import torch
+    fav = rh.import_reference("domain_adaptation")
+    N = 16
+    img0, lab = img_inputs(N)
+    img1, _ = img_inputs(N, seed=4, zt=np.random.RandomState(1).randn(N, 5))     # second domain, same latent factors
+    lab = lab[:, :3]
+    model = fav.SSHIBA(4, 1)
+    v0 = model.struct_data(img0, "img", latent_dim=8, lr=1e-3, dataset="g0")
+    v1 = model.struct_data(img1, "img", latent_dim=8, lr=1e-3, dataset="g1")
+    v2 = model.struct_data(lab, "mult")
+    run_quiet(lambda: model.fit(v0, v1, v2, max_iter=2, pruning_crit=1e-3, verbose=1, store=False))
+    out = {}
+    dump_q(model, out)
+    for i in range(len(model.total_elbo)):
+        out["total_elbo%d" % i] = np.array(model.total_elbo[i], dtype=np.float64)
+    for m in (0, 1):
+        for k, p in model.img_vae[m].state_dict().items():
+            out["p%d_%s" % (m, k)] = checksum(p.numpy())
+    img_t, _ = img_inputs(N, seed=5)          # DA/celeba2cartoon_vae.update_x encodes self.img whatever it is handed (:240-258),
+    np.random.seed(21); torch.manual_seed(21)   # so predict only runs with n_pred == N
+    pred_img, X_sample, Z_in, xcart = run_quiet(lambda: model.predict([0], [1], model.struct_data(img_t, "img")))
+    out["pred_img"], out["pred_X_sample"], out["pred_Z_mean"] = checksum(pred_img), X_sample, Z_in["mean"]
+    out["pred_Z_cov"], out["pred_xcart"] = Z_in["cov"], checksum(xcart.numpy())
+    np.savez_compressed(os.path.join(OUT, "favae_B.npz"), **out)
+    print("favae_B L =", model.L, "elbo lists", len(model.total_elbo), "pred", out["pred_img"][:2])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["fa", "vae_step", "vae_epoch", "favae_A"]
@@ -229,5 +259,7 @@ if __name__ == "__main__":
         gen_vae_step()
     if "vae_epoch" in which:
         gen_vae_epoch()
+    if "favae_B" in which:
+        gen_favae_B()
     if "favae_A" in which:
         gen_favae_A()

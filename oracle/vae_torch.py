@@ -147,10 +147,11 @@ class OracleImgVAE:
     """Mirror of ImgVAE (cA/celeba_deepvanilla_vae.py:108-430) on functional torch-CPU ops."""
 
     def __init__(self, dimx=2, channels=1, var_x=0.01, lr=1e-5, h=None, w=None, dataset=None, latentspace_lr=1,
-                 prior="moment", force_beta_one=True, batch_size=64):
+                 prior="moment", force_beta_one=True, batch_size=64, update_x_self_img=False):
         self.dimx = self.latentdim = dimx
         self.channels, self.var_x, self.lr, self.dataset, self.latentspace_lr = channels, var_x, lr, dataset, latentspace_lr
         self.prior, self.force_beta_one, self.batch_size = prior, force_beta_one, batch_size
+        self.update_x_self_img = update_x_self_img      # DA/celeba2cartoon_vae.py:240-258 encodes self.img whatever it is handed
         self.P, self.B = init_state(dimx, channels)
         self.names = list(self.P.keys())
         self.optim = torch.optim.Adam([self.P[k] for k in self.names], self.lr)
@@ -229,8 +230,11 @@ class OracleImgVAE:
 
     # -- update_x: cA/celeba_deepvanilla_vae.py:331-358 --------------------------------------------------------
     def update_x(self, img=None):
-        img = torch.Tensor(img) if img is not None else self.img
+        n_out = img.shape[0] if img is not None else self.img.shape[0]
+        img = torch.Tensor(img) if (img is not None and not self.update_x_self_img) else self.img
         n = img.shape[0]
+        if n != n_out:
+            raise ValueError("could not broadcast input array from shape (%d,%d) into shape (%d,%d)" % (n, self.latentdim, n_out, self.latentdim))
         mu, var = np.zeros((n, self.latentdim)), np.zeros((n, self.latentdim))
         draw_epoch_order(n, False)
         with torch.no_grad():

@@ -32,10 +32,10 @@ def fa_inputs(n=512, rank=5, seed=1):
     return X0, lab
 
 
-def img_inputs(n, seed=1):
+def img_inputs(n, seed=1, zt=None):
     """Same generator as oracle/make_goldens.py:img_inputs."""
     rs = np.random.RandomState(seed)
-    Zt = rs.randn(n, 5)
+    Zt = rs.randn(n, 5) if zt is None else zt
     Pm = rs.randn(5, 3 * 64 * 64) * 0.7
     img = (1 / (1 + np.exp(-(Zt @ Pm)))).reshape(n, 3, 64, 64).astype(np.float32)
     lab = (Zt @ rs.randn(5, 40) > 0).astype(int)

@@ -136,14 +136,7 @@ def test_full_variant_A_short_horizon_matches_oracle():
     _close(model.q_dist.W[1]["mean"], ref.q_dist.W[1]["mean"], 0, 1e-2 * np.abs(ref.q_dist.W[1]["mean"]).max())
     _close(model.wandb_metrics["g R2 reconstruction"], ref.metrics["R2 reconstruction 0"], 0, 1e-3)
     # ---- predict / predict_sameimage, like for like: the oracle takes over the HIP model's state --------------
-    q, rq = model.q_dist, ref.q_dist
-    rq.Kc = q.Kc
-    for m in range(model.m):
-        for k in ("mean", "cov"):
-            rq.W[m][k] = np.array(q.W[m][k])
-            rq.b[m][k] = np.array(q.b[m][k])
-        rq.tau[m]["a"], rq.tau[m]["b"] = q.tau[m]["a"], q.tau[m]["b"]
-    ref.img_vae[0].load_state_dict({k: v.detach().cpu() for k, v in model.img_vae[0].state_dict().items()})
+    _take_over_state(model, ref)
     img_t, lab_t = img_inputs(12, seed=5)
     outs = []
     for mdl, sd in ((model, model.struct_data), (ref, fo.struct_data)):
@@ -168,6 +161,65 @@ def test_full_variant_A_short_horizon_matches_oracle():
     _close(back.q_dist.Z["mean"], model.q_dist.Z["mean"], 0, 0)
     sd0, sd1 = model.img_vae[0].state_dict(), back.img_vae[0].state_dict()
     assert all(torch.equal(sd0[k], sd1[k]) for k in sd0)
+
+
+def _take_over_state(model, ref):
+    """Give the oracle the HIP model's posterior and VAE weights, so that predict is compared like for like."""
+    q, rq = model.q_dist, ref.q_dist
+    rq.Kc = q.Kc
+    for m in range(model.m):
+        for k in ("mean", "cov"):
+            rq.W[m][k] = np.array(q.W[m][k])
+            rq.b[m][k] = np.array(q.b[m][k])
+        rq.tau[m]["a"], rq.tau[m]["b"] = q.tau[m]["a"], q.tau[m]["b"]
+        if model.img_vae[m] is not None:
+            ref.img_vae[m].load_state_dict({k: v.detach().cpu() for k, v in model.img_vae[m].state_dict().items()})
+
+
+def test_full_variant_B_two_image_views_matches_oracle():
+    """domain_adaptation (variant B): two image views + one multilabel view, sampled FA prior, beta 0.1 / 0.5 schedule,
+    N=16, Kc=4, two SSHIBA iterations shortened to 2 and 1 epochs; then predict image view 0 -> image view 1.
+    The oracle's variant-B path is pinned on the reference's own run (tests/golden/favae_B.npz, CPU suite)."""
+    fav = load_variant("domain_adaptation")
+    N = 16
+    img0, lab = img_inputs(N)
+    img1, _ = img_inputs(N, seed=4, zt=np.random.RandomState(1).randn(N, 5))
+    lab = lab[:, :3]
+    np.random.seed(0)
+    torch.manual_seed(0)
+    fac = lambda **kw: vt.OracleImgVAE(prior="sampled", force_beta_one=False, update_x_self_img=True, **kw)
+    ref = fo.SSHIBAOracle(4, 1, variant="B", vae_factory=fac)
+    ref.epochs_override = [2, 1]
+    ref.fit(fo.struct_data(img0, "img", latent_dim=8, lr=1e-3, dataset="g0"),
+            fo.struct_data(img1, "img", latent_dim=8, lr=1e-3, dataset="g1"), fo.struct_data(lab, "mult"),
+            max_iter=2, pruning_crit=1e-3)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = fav.SSHIBA(4, 1)
+    model.epochs_override = [2, 1]
+    model.fit(model.struct_data(img0, "img", latent_dim=8, lr=1e-3, dataset="g0"),
+              model.struct_data(img1, "img", latent_dim=8, lr=1e-3, dataset="g1"), model.struct_data(lab, "mult"),
+              max_iter=2, pruning_crit=1e-3, verbose=0, store=False)
+    # first epoch of either view: identical state going in -> the tight tolerance
+    _close(model.total_elbo[0][0], ref.total_elbo[0][0], 1e-5)
+    _close(model.total_elbo[1][0], ref.total_elbo[1][0], 1e-5)
+    # free-running quantities: regression guard (see the variant-A test)
+    _close(model.L, ref.L, 5e-3)
+    for i in range(4):
+        _close(model.total_elbo[i], ref.total_elbo[i], 3e-2)      # N=16, lr 1e-3: the second iteration has drifted ~1 %
+    _close(model.q_dist.Z["mean"], ref.q_dist.Z["mean"], 0, 2e-2 * np.abs(ref.q_dist.Z["mean"]).max())
+    # predict image -> image on the same state (n_pred == N: the reference's update_x encodes the training images)
+    _take_over_state(model, ref)
+    img_t, _ = img_inputs(N, seed=5)
+    outs = []
+    for mdl, sd in ((model, model.struct_data), (ref, fo.struct_data)):
+        np.random.seed(21); torch.manual_seed(21)
+        pred_img, X_sample, Z_in, xcart = mdl.predict([0], [1], sd(img_t, "img"))
+        outs.append([np.asarray(pred_img), np.asarray(X_sample), np.asarray(Z_in["mean"]), np.asarray(Z_in["cov"]),
+                     xcart.cpu().numpy()])
+    for a, b in zip(*outs):
+        assert a.shape == b.shape
+        _close(a, b, 1e-4, 1e-4 * max(1.0, float(np.abs(b).max())))
 
 
 def _sharded_worker(rank, ws, port, q):

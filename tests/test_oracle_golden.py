@@ -153,3 +153,34 @@ def test_full_variant_A_fit_matches_reference(golden):
     _close(zm, gp["same_Z_mean"], rtol=2e-3, atol=1e-4)
     _close(checksum(pred_img), gp["same_img"], rtol=2e-3, atol=2e-3)
     _close(checksum(xc.numpy()), gp["same_xcart"], rtol=2e-3, atol=2e-3)
+
+
+def test_full_variant_B_fit_matches_reference(golden):
+    """domain_adaptation: two image views (z=8) + one multilabel view, N=16, Kc=4, two iterations (50 + 20 epochs per
+    view, beta 0.1 / 0.5, sampled FA prior), then predict image view 0 -> image view 1."""
+    g = golden("favae_B.npz")
+    N = 16
+    img0, lab = img_inputs(N)
+    img1, _ = img_inputs(N, seed=4, zt=np.random.RandomState(1).randn(N, 5))
+    lab = lab[:, :3]
+    np.random.seed(0)
+    torch.manual_seed(0)
+    fac = lambda **kw: vt.OracleImgVAE(prior="sampled", force_beta_one=False, update_x_self_img=True, **kw)
+    model = fa.SSHIBAOracle(4, 1, variant="B", vae_factory=fac, diagnostics=True)
+    model.fit(fa.struct_data(img0, "img", latent_dim=8, lr=1e-3, dataset="g0"),
+              fa.struct_data(img1, "img", latent_dim=8, lr=1e-3, dataset="g1"), fa.struct_data(lab, "mult"),
+              max_iter=2, pruning_crit=1e-3)
+    _close(model.L, g["L"], rtol=1e-4)
+    for i in range(4):
+        _close(model.total_elbo[i], g["total_elbo%d" % i], rtol=1e-5)
+    _close(model.q_dist.Z["mean"], g["Z_mean"], rtol=2e-3, atol=1e-4)
+    _close(model.X[1]["mean"], g["X1_mean"], rtol=2e-3, atol=1e-4)
+    _close(model.q_dist.W[0]["mean"], g["W0_mean"], rtol=2e-3, atol=1e-5)
+    img_t, _ = img_inputs(N, seed=5)
+    np.random.seed(21); torch.manual_seed(21)
+    pred_img, X_sample, Z_in, xcart = model.predict([0], [1], fa.struct_data(img_t, "img"))
+    _close(X_sample, g["pred_X_sample"], rtol=2e-3, atol=1e-4)
+    _close(Z_in["mean"], g["pred_Z_mean"], rtol=2e-3, atol=1e-4)
+    _close(Z_in["cov"], g["pred_Z_cov"], rtol=2e-3, atol=1e-6)
+    _close(checksum(pred_img), g["pred_img"], rtol=2e-3, atol=2e-3)
+    _close(checksum(xcart.numpy()), g["pred_xcart"], rtol=2e-3, atol=2e-3)
