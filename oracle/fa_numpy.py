@@ -109,7 +109,8 @@ def struct_data(X, method, latent_dim=None, lr=None, epochs=None, dataset=None):
 class SSHIBAOracle:
     """Restates SSHIBA.fit / fit_iterate / update / update_bound / pruning for variants
     'A' (cA/favae.py: predictive Z for the VAE prior, moment prior, schedule 50/5/5) and
-    'B' (DA/favae.py: joint Z, schedule 50/20/20 with beta 0.1/0.5/1, sampled prior).
+    'B' (DA/favae.py: joint Z, schedule 50/20/20 with beta 0.1/0.5/1, sampled prior) and 'C' (TL/favae.py with
+    betaVAE.py: the coordinator of 'B', but `favae` is never passed, so the VAE trains against N(0,I)).
     `vae_factory(dimx, channels, lr, dataset, latentspace_lr)` builds the image-view model
     (oracle.vae_torch.OracleImgVAE in the tests)."""
 
@@ -234,8 +235,9 @@ class SSHIBAOracle:
             epochs = self.epochs_override[min(iter_count, len(self.epochs_override) - 1)]
         trained = False
         if self.keep_training[m]:
+            # variant C (TL/favae.py:812 with betaVAE.py) never passes `favae`: the VAE keeps its N(0,I) prior
             self.keep_training[m] = vae.trainloop(img=self.t[m]["data"], Z=Z_in, W=q.W[m], b=q.b[m],
-                                                  tau=q.tau_mean(m), epochs=epochs, favae=True, beta=beta)
+                                                  tau=q.tau_mean(m), epochs=epochs, favae=self.variant != "C", beta=beta)
             trained = True
         elif iter_count % 10 == 0:
             if self.variant == "A":                                                      # cA :821 (N(0,I) prior)
@@ -243,7 +245,7 @@ class SSHIBAOracle:
                               epochs=epochs)
             else:                                                                        # DA :827
                 vae.trainloop(img=self.t[m]["data"], Z=Z_in, W=q.W[m], b=q.b[m], tau=q.tau_mean(m),
-                              epochs=epochs, favae=True)
+                              epochs=epochs, favae=self.variant != "C")
             trained = True
         if trained:
             self.total_elbo.append(vae.elbo_training)

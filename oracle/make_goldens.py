@@ -16,6 +16,9 @@ Fixtures
                           predict_sameimage mult -> img (seeds set before each call).
   favae_B.npz             full variant-B (domain_adaptation) fit: two image views (z=8) + one 'mult' view, N=16, Kc=4,
                           2 iterations (50 + 20 epochs per view), then predict image view 0 -> image view 1.
+  favae_C.npz             variant C (transfer_learning/favae.py + betaVAE.py: the VAE keeps its N(0,I) prior because the
+                          coordinator never passes favae=True): one image view (z=8) + one 'mult' view, N=16, Kc=4, 2 iterations.
+  vae_beta_epoch.npz      stand-alone beta-VAE (transfer_learning/betaVAE.py): trainloop(epochs=3, beta=4) + update_x.
   favae_A.npz             full variant-A fit, one image view (z=8) + one 'mult' view, N=32, Kc=4, 2 iterations
                           (50 + 5 epochs as the reference schedules them).
 """
@@ -217,6 +220,40 @@ def gen_favae_A():
     print("favae_A_predict: img->mult mean", float(pr["i2m_mean"].mean()), "mult->img", pr["m2i_img"][:2], pr["same_img"][:2])
 
 
+def gen_favae_C():
+    fav = rh.import_reference("transfer_learning")
+    N = 16
+    img, lab = img_inputs(N)
+    model = fav.SSHIBA(4, 1)
+    v0 = model.struct_data(img, "img", latent_dim=8, lr=1e-3, dataset="g")
+    v1 = model.struct_data(lab[:, :5], "mult")
+    run_quiet(lambda: model.fit(v0, v1, max_iter=2, pruning_crit=1e-3, verbose=1, store=False))
+    out = {}
+    dump_q(model, out)
+    for i in range(len(model.total_elbo)):
+        out["total_elbo%d" % i] = np.array(model.total_elbo[i], dtype=np.float64)
+        out["kl%d" % i] = np.array(model.kl_q_p[i], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "favae_C.npz"), **out)
+    print("favae_C L =", model.L, "elbo lists", len(model.total_elbo))
+
+
+def gen_vae_beta_epoch():
+    import torch
+    vm = rh.import_vae_module("transfer_learning", "betaVAE")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    vae = run_quiet(lambda: vm.ImgVAE(dimx=8, channels=3, lr=1e-3, h=64, w=64, dataset="g"))
+    N = 24
+    img, _ = img_inputs(N)
+    keep = run_quiet(lambda: vae.trainloop(img=img, epochs=3, beta=4))
+    mu, var = run_quiet(lambda: vae.update_x(img=img))
+    out = dict(keep=np.array(keep), elbo=np.array(vae.elbo_training, dtype=np.float64),
+               rec_loss=np.array(vae.reconstruc_during_training, dtype=np.float64),
+               kl=np.array(vae.KL_QandP, dtype=np.float64), mu=mu, var=var)
+    np.savez_compressed(os.path.join(OUT, "vae_beta_epoch.npz"), **out)
+    print("vae_beta_epoch elbo", out["elbo"], "kl", out["kl"])
+
+
 def gen_favae_B():
     import torch
     fav = rh.import_reference("domain_adaptation")
@@ -259,6 +296,10 @@ if __name__ == "__main__":
         gen_vae_step()
     if "vae_epoch" in which:
         gen_vae_epoch()
+    if "favae_C" in which:
+        gen_favae_C()
+    if "vae_beta" in which:
+        gen_vae_beta_epoch()
     if "favae_B" in which:
         gen_favae_B()
     if "favae_A" in which:

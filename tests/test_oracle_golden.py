@@ -184,3 +184,40 @@ def test_full_variant_B_fit_matches_reference(golden):
     _close(Z_in["cov"], g["pred_Z_cov"], rtol=2e-3, atol=1e-6)
     _close(checksum(pred_img), g["pred_img"], rtol=2e-3, atol=2e-3)
     _close(checksum(xcart.numpy()), g["pred_xcart"], rtol=2e-3, atol=2e-3)
+
+
+def test_full_variant_C_fit_matches_reference(golden):
+    """transfer_learning/favae.py + betaVAE.py: one image view + one multilabel view, N=16, Kc=4, two iterations; the
+    VAE keeps the N(0,I) prior (the coordinator never passes favae=True), beta follows the 0.1 / 0.5 schedule."""
+    g = golden("favae_C.npz")
+    N = 16
+    img, lab = img_inputs(N)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    fac = lambda **kw: vt.OracleImgVAE(prior="sampled", force_beta_one=False, update_x_self_img=True, **kw)
+    model = fa.SSHIBAOracle(4, 1, variant="C", vae_factory=fac)
+    model.fit(fa.struct_data(img, "img", latent_dim=8, lr=1e-3, dataset="g"), fa.struct_data(lab[:, :5], "mult"),
+              max_iter=2, pruning_crit=1e-3)
+    _close(model.L, g["L"], rtol=1e-4)
+    for i in range(2):
+        _close(model.total_elbo[i], g["total_elbo%d" % i], rtol=1e-5)
+        _close(model.kl_q_p[i], g["kl%d" % i], rtol=1e-4)
+    _close(model.X[0]["mean"], g["X0_mean"], rtol=2e-3, atol=1e-4)
+    _close(model.q_dist.W[1]["mean"], g["W1_mean"], rtol=2e-3, atol=1e-5)
+
+
+def test_standalone_beta_vae_matches_reference(golden):
+    """transfer_learning/betaVAE.py on its own: trainloop(epochs=3, beta=4) against N(0,I) (the second epoch is worse
+    than the first, so restore_weights reloads the checkpoint), then update_x."""
+    g = golden("vae_beta_epoch.npz")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    vae = vt.OracleImgVAE(dimx=8, channels=3, lr=1e-3, dataset="g", prior="sampled", force_beta_one=False, update_x_self_img=True)
+    img, _ = img_inputs(24)
+    keep = vae.trainloop(img=img, epochs=3, beta=4)
+    assert bool(keep) == bool(g["keep"])
+    _close(vae.elbo_training, g["elbo"], rtol=1e-5)
+    _close(vae.KL_QandP, g["kl"], rtol=1e-4)
+    mu, var = vae.update_x(img=img)
+    _close(mu, g["mu"], rtol=1e-3, atol=1e-4)
+    _close(var, g["var"], rtol=1e-3, atol=1e-6)
