@@ -17,7 +17,8 @@ Fixtures
   favae_B.npz             full variant-B (domain_adaptation) fit: two image views (z=8) + one 'mult' view, N=16, Kc=4,
                           2 iterations (50 + 20 epochs per view), then predict image view 0 -> image view 1.
   favae_C.npz             variant C (transfer_learning/favae.py + betaVAE.py: the VAE keeps its N(0,I) prior because the
-                          coordinator never passes favae=True): one image view (z=8) + one 'mult' view, N=16, Kc=4, 2 iterations.
+                          coordinator never passes favae=True): image view (z=8) + 'reg' view (pretrained latents) + 'mult' view as in
+                          TL/trainer_FAVAE.py, N=16, Kc=4, 2 iterations.
   vae_beta_epoch.npz      stand-alone beta-VAE (transfer_learning/betaVAE.py): trainloop(epochs=3, beta=4) + update_x.
   favae_A.npz             full variant-A fit, one image view (z=8) + one 'mult' view, N=32, Kc=4, 2 iterations
                           (50 + 5 epochs as the reference schedules them).
@@ -225,9 +226,11 @@ def gen_favae_C():
     N = 16
     img, lab = img_inputs(N)
     model = fav.SSHIBA(4, 1)
+    X0, _ = fa_inputs(n=N, seed=3)            # stands in for the pretrained-VAE latents of TL/trainer_FAVAE.py:24-31
     v0 = model.struct_data(img, "img", latent_dim=8, lr=1e-3, dataset="g")
-    v1 = model.struct_data(lab[:, :5], "mult")
-    run_quiet(lambda: model.fit(v0, v1, max_iter=2, pruning_crit=1e-3, verbose=1, store=False))
+    v1 = model.struct_data(X0, "reg")
+    v2 = model.struct_data(lab[:, :5], "mult")
+    run_quiet(lambda: model.fit(v0, v1, v2, max_iter=2, pruning_crit=1e-3, verbose=1, store=False))   # view order of :96
     out = {}
     dump_q(model, out)
     for i in range(len(model.total_elbo)):

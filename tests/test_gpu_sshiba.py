@@ -234,14 +234,15 @@ def test_full_variant_C_matches_oracle():
     fac = lambda **kw: vt.OracleImgVAE(prior="sampled", force_beta_one=False, update_x_self_img=True, **kw)
     ref = fo.SSHIBAOracle(4, 1, variant="C", vae_factory=fac)
     ref.epochs_override = [2, 1]
-    ref.fit(fo.struct_data(img, "img", latent_dim=8, lr=1e-3, dataset="g"), fo.struct_data(lab[:, :5], "mult"), max_iter=2,
-            pruning_crit=1e-3)
+    X0, _ = fa_inputs(n=N, seed=3)                      # 'reg' view = pretrained latents, view order of TL/trainer_FAVAE.py:96
+    ref.fit(fo.struct_data(img, "img", latent_dim=8, lr=1e-3, dataset="g"), fo.struct_data(X0, "reg"),
+            fo.struct_data(lab[:, :5], "mult"), max_iter=2, pruning_crit=1e-3)
     np.random.seed(0)
     torch.manual_seed(0)
     model = fav.SSHIBA(4, 1)
     model.epochs_override = [2, 1]
-    model.fit(model.struct_data(img, "img", latent_dim=8, lr=1e-3, dataset="g"), model.struct_data(lab[:, :5], "mult"),
-              max_iter=2, pruning_crit=1e-3, verbose=0, store=False)
+    model.fit(model.struct_data(img, "img", latent_dim=8, lr=1e-3, dataset="g"), model.struct_data(X0, "reg"),
+              model.struct_data(lab[:, :5], "mult"), max_iter=2, pruning_crit=1e-3, verbose=0, store=False)
     _close(model.total_elbo[0][0], ref.total_elbo[0][0], 1e-5)          # like for like: shared initial state
     _close(model.kl_q_p[0][0], ref.kl_q_p[0][0], 1e-4)
     _close(model.L, ref.L, 0.25, 5.0)                                   # free-running: sanity bound only (N=16)

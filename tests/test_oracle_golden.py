@@ -187,7 +187,8 @@ def test_full_variant_B_fit_matches_reference(golden):
 
 
 def test_full_variant_C_fit_matches_reference(golden):
-    """transfer_learning/favae.py + betaVAE.py: one image view + one multilabel view, N=16, Kc=4, two iterations; the
+    """transfer_learning/favae.py + betaVAE.py: image + 'reg' (pretrained latents) + multilabel views as in
+    TL/trainer_FAVAE.py:96, N=16, Kc=4, two iterations; the
     VAE keeps the N(0,I) prior (the coordinator never passes favae=True), beta follows the 0.1 / 0.5 schedule."""
     g = golden("favae_C.npz")
     N = 16
@@ -196,14 +197,16 @@ def test_full_variant_C_fit_matches_reference(golden):
     torch.manual_seed(0)
     fac = lambda **kw: vt.OracleImgVAE(prior="sampled", force_beta_one=False, update_x_self_img=True, **kw)
     model = fa.SSHIBAOracle(4, 1, variant="C", vae_factory=fac)
-    model.fit(fa.struct_data(img, "img", latent_dim=8, lr=1e-3, dataset="g"), fa.struct_data(lab[:, :5], "mult"),
-              max_iter=2, pruning_crit=1e-3)
+    X0, _ = fa_inputs(n=N, seed=3)
+    model.fit(fa.struct_data(img, "img", latent_dim=8, lr=1e-3, dataset="g"), fa.struct_data(X0, "reg"),
+              fa.struct_data(lab[:, :5], "mult"), max_iter=2, pruning_crit=1e-3)
     _close(model.L, g["L"], rtol=1e-4)
     for i in range(2):
         _close(model.total_elbo[i], g["total_elbo%d" % i], rtol=1e-5)
         _close(model.kl_q_p[i], g["kl%d" % i], rtol=1e-4)
     _close(model.X[0]["mean"], g["X0_mean"], rtol=2e-3, atol=1e-4)
     _close(model.q_dist.W[1]["mean"], g["W1_mean"], rtol=2e-3, atol=1e-5)
+    _close(model.q_dist.W[2]["mean"], g["W2_mean"], rtol=2e-3, atol=1e-5)
 
 
 def test_standalone_beta_vae_matches_reference(golden):
