@@ -67,14 +67,32 @@ class VaeEngine:
                                       L.ptr(self.shadow), _sz(sh), L.ptr(self.workspace), _sz(ws)))
         self.h = h
         self.metrics = torch.zeros(2, dtype=torch.float64, device=self.dev)
+        # eval-mode passes over a whole data set (update_x, reconstruction diagnostic) are independent per sample (BN uses
+        # the running statistics), so they run through a second executor over the SAME parameters with a larger batch:
+        # 512-image GEMMs fill the chip, 64-image ones do not
+        self.eval_batch = 512
+        self.h_eval = None
+        self.workspace_eval = None
 
     def __del__(self):
         try:
-            if getattr(self, "h", None):
-                _raw.favae_vae_destroy(self.h)
-                self.h = None
+            for name in ("h", "h_eval"):
+                if getattr(self, name, None):
+                    _raw.favae_vae_destroy(getattr(self, name))
+                    setattr(self, name, None)
         except Exception:
             pass
+
+    def _eval_handle(self):
+        if self.h_eval is None:
+            ws = _raw.favae_vae_workspace_bytes(_i(self.z), _i(self.ch), _i(self.eval_batch), _i(self.dtype))
+            self.workspace_eval = torch.zeros(ws, dtype=torch.uint8, device=self.dev)
+            h = ctypes.c_void_p()
+            L.check(_raw.favae_vae_create(ctypes.byref(h), _i(self.z), _i(self.ch), _i(self.eval_batch), _i(self.dtype),
+                                          L.ptr(self.P), L.ptr(self.G), L.ptr(self.M), L.ptr(self.V), L.ptr(self.BUF),
+                                          L.ptr(self.shadow), _sz(self.shadow.numel()), L.ptr(self.workspace_eval), _sz(ws)))
+            self.h_eval = h
+        return self.h_eval
 
     # ---- layout conversion (pure data movement) ----------------------------------------------------------------
     def _w_to_arena(self, l, sd):
@@ -213,16 +231,17 @@ class VaeEngine:
                                       ctypes.c_void_p(xcov.data_ptr()), _i(int(train)), L.stream_ptr()))
 
     def encode_all(self, data, xmean, xcov, batch=64):
-        L.check(_raw.favae_vae_encode_all(self.h, L.ptr(data), _ll(data.shape[0]), _i(batch), L.ptr(xmean), L.ptr(xcov),
-                                          L.stream_ptr()))
+        """update_x over a resident data set; `batch` is the reference's loader batch, the eval executor uses its own."""
+        L.check(_raw.favae_vae_encode_all(self._eval_handle(), L.ptr(data), _ll(data.shape[0]), _i(max(batch, self.eval_batch)),
+                                          L.ptr(xmean), L.ptr(xcov), L.stream_ptr()))
 
     def decode(self, zin, B, out, train=False):
         L.check(_raw.favae_vae_decode(self.h, ctypes.c_void_p(zin.data_ptr()), _i(B), ctypes.c_void_p(out.data_ptr()),
                                       _i(int(train)), L.stream_ptr()))
 
     def reconstruct_stats(self, zin, data, acc3, batch=64):
-        L.check(_raw.favae_vae_reconstruct_stats(self.h, L.ptr(zin), L.ptr(data), _ll(zin.shape[0]), _i(batch), L.ptr(acc3),
-                                                 L.stream_ptr()))
+        L.check(_raw.favae_vae_reconstruct_stats(self._eval_handle(), L.ptr(zin), L.ptr(data), _ll(zin.shape[0]),
+                                                 _i(max(batch, self.eval_batch)), L.ptr(acc3), L.stream_ptr()))
 
     def nhwc_to_nchw_f64(self, x_nhwc, out):
         n, hh, ww, c = x_nhwc.shape

@@ -37,7 +37,7 @@ DT = [(torch.float32, 1e-5), (torch.bfloat16, 1e-4)]
 
 @pytest.mark.parametrize("dt,tol", DT)
 @pytest.mark.parametrize("Nb,Cin,Cout,H,splitk", [(4, 64, 128, 16, 1), (3, 32, 64, 8, 0), (2, 256, 512, 8, 4),
-                                                 (5, 3, 64, 64, 1), (64, 512, 1024, 4, 0)])
+                                                 (5, 3, 64, 64, 1), (160, 3, 64, 64, 0), (64, 512, 1024, 4, 0)])
 def test_conv_s2_forward(dt, tol, Nb, Cin, Cout, H, splitk):
     lib = _lib()
     g = torch.Generator().manual_seed(Nb * 1000 + Cin)

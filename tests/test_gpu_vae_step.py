@@ -133,6 +133,48 @@ def test_eval_encoder_and_decoder_match_oracle(dtype, tol):
     assert _rel(out.cpu().permute(0, 3, 1, 2).numpy(), rec.numpy()) <= tol
 
 
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("bf16", 2e-2)])
+def test_whole_dataset_eval_passes_equal_the_batch_64_passes(dtype, tol):
+    """update_x / reconstruction over a resident data set run through the large-batch eval executor (engine.eval_batch);
+    eval mode is independent per sample, so they must reproduce the batch-64 calls (the reference's loader size).
+    N = 1100: two full eval batches and a ragged tail."""
+    z, N = 8, 1100
+    torch.manual_seed(4)
+    P, Bf = vt.init_state(z, 3)
+    for k in Bf:
+        if k.endswith("running_var"):
+            Bf[k].uniform_(0.5, 1.5)
+        elif k.endswith("running_mean"):
+            Bf[k].normal_(0, 0.1)
+    eng = _engine(z, dtype)
+    sd = {k: v.detach().clone() for k, v in P.items()}
+    sd.update({k: v.clone() for k, v in Bf.items()})
+    eng.load_state_dict(sd)
+    rs = np.random.RandomState(2)
+    img = rs.rand(N, 3, 64, 64).astype(np.float32)
+    data = eng.upload_images(img)
+    f64 = dict(dtype=torch.float64, device="cuda")
+    xm, xc = torch.zeros(N, z, **f64), torch.zeros(N, z, **f64)
+    eng.encode_all(data, xm, xc, 64)
+    xm2, xc2 = torch.zeros(N, z, **f64), torch.zeros(N, z, **f64)
+    for s0 in range(0, N, 64):
+        b = min(64, N - s0)
+        eng.encode(data[s0:s0 + b], None, b, xm2[s0:s0 + b], xc2[s0:s0 + b])
+    assert _rel(xm.cpu().numpy(), xm2.cpu().numpy()) <= tol and _rel(xc.cpu().numpy(), xc2.cpu().numpy()) <= tol
+    zin = torch.randn(N, z, generator=torch.Generator().manual_seed(6)).cuda()
+    acc = torch.zeros(3, **f64)
+    eng.reconstruct_stats(zin, data, acc, 64)
+    out = torch.zeros(64, 64, 64, 3, device="cuda")
+    sse = sy = syy = 0.0
+    for s0 in range(0, N, 64):
+        b = min(64, N - s0)
+        eng.decode(zin[s0:s0 + b], b, out)
+        y, r = data[s0:s0 + b].double(), out[:b].double()
+        sse += float(((y - r) ** 2).sum()); sy += float(y.sum()); syy += float((y * y).sum())
+    got = acc.cpu().numpy()
+    np.testing.assert_allclose(got, [sse, sy, syy], rtol=max(tol, 1e-6))
+
+
 def test_state_dict_round_trip():
     z = 20
     torch.manual_seed(1)
