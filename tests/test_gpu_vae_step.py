@@ -50,7 +50,7 @@ def test_training_steps_match_oracle(dtype, tol_loss, tol_bulk, min_cos):
     current state, so every step is a like-for-like forward/backward comparison at a different point of training.
     bf16: activations and back-propagated gradients are stored in bf16, so ~1 % of the LeakyReLU slopes per layer
     differ from the fp32 forward; the loss terms / latent moments meet the 1e-2 of north_star, gradients are held to
-    a cosine of 0.97 per tensor (measured 0.982-1.000, tools/dbg_step.py)."""
+    a cosine of 0.97 per tensor (measured 0.982-1.000, tools/dbg_step2.py)."""
     z, Bn = 20, 16
     torch.manual_seed(0)
     np.random.seed(0)
