@@ -125,6 +125,14 @@ struct KcParams {
     int Nb, Hi, Wi, Cin, Ho, Wo, Cout;
     int ks, stride, pad, ldw, splitk, M, ntn, HoC, WoC;
     int out_bf16;   // store the result as bf16 (unsplit reductions only)
+    // optional per-channel sums over the output tile, added to red_bins[bin][2][Cout] (fp64 atomics; staged 64x64
+    // epilogue of unsplit reductions only).  mode 1: sum(y), sum(y^2) of the stored output (BatchNorm statistics);
+    // mode 2: y is the gradient w.r.t. a BN+LeakyReLU output: sum(dd), sum(dd * xhat) with dd = y * lrelu'(act),
+    // xhat = (raw - mean) * invstd (the two reductions of the BatchNorm backward).
+    double* red_bins;
+    int red_nbin, red_mode;
+    const void* red_act;
+    const float *red_raw, *red_mean, *red_invstd;
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
-    if constexpr (BM == 64 && BN == 64 && !SLOW) {
+    if constexpr (BM == 64 && BN == 64) {
         // unsplit reduction: the tile goes through LDS and leaves as 16 B per lane, 256 contiguous bytes per output
         // row (4 B per lane straight from the accumulators writes the same bytes in 4x the store instructions)
         if (p.splitk == 1 && (p.Cout & 3) == 0) {
@@ -324,6 +332,10 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
             const int c4 = (tid & 15) * 4, n = n0 + c4;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (add_bias && n < p.Cout) bv = *(const float4*)(p.bias + n);
+            const int red = p.red_bins ? p.red_mode : 0;   // block-uniform
+            double rs[4] = {0.0, 0.0, 0.0, 0.0}, rq[4] = {0.0, 0.0, 0.0, 0.0};
+            float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
+            if (red == 2 && n < p.Cout) { mu = *(const float4*)(p.red_mean + n); is = *(const float4*)(p.red_invstd + n); }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = (tid >> 4) + 16 * i, m = m0 + row;
@@ -343,6 +355,51 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
                     *(uint2*)((bf16_t*)p.out + opix * p.Cout + n) = u;
                 } else {
                     *(float4*)(p.out + opix * p.Cout + n) = v;
+                }
+                if (red == 1) {
+                    rs[0] += v.x; rs[1] += v.y; rs[2] += v.z; rs[3] += v.w;
+                    rq[0] += (double)v.x * v.x; rq[1] += (double)v.y * v.y; rq[2] += (double)v.z * v.z; rq[3] += (double)v.w * v.w;
+                } else if (red == 2) {
+                    const size_t e = opix * p.Cout + n;
+                    float a[4];
+                    if constexpr (sizeof(T) == 2) {
+                        const uint2 u = *(const uint2*)((const bf16_t*)p.red_act + e);
+                        a[0] = __uint_as_float(u.x << 16); a[1] = __uint_as_float(u.x & 0xffff0000u);
+                        a[2] = __uint_as_float(u.y << 16); a[3] = __uint_as_float(u.y & 0xffff0000u);
+                    } else {
+                        const float4 t = *(const float4*)((const float*)p.red_act + e);
+                        a[0] = t.x; a[1] = t.y; a[2] = t.z; a[3] = t.w;
+                    }
+                    const float4 x = *(const float4*)(p.red_raw + e);
+                    const float d0 = v.x * (a[0] > 0.f ? 1.f : 0.01f), d1 = v.y * (a[1] > 0.f ? 1.f : 0.01f);
+                    const float d2 = v.z * (a[2] > 0.f ? 1.f : 0.01f), d3 = v.w * (a[3] > 0.f ? 1.f : 0.01f);
+                    rs[0] += d0; rs[1] += d1; rs[2] += d2; rs[3] += d3;
+                    rq[0] += (double)d0 * ((x.x - mu.x) * is.x); rq[1] += (double)d1 * ((x.y - mu.y) * is.y);
+                    rq[2] += (double)d2 * ((x.z - mu.z) * is.z); rq[3] += (double)d3 * ((x.w - mu.w) * is.w);
+                }
+            }
+            if (red) {
+                // lanes tid, tid^16, tid^32 hold the same 4 columns; then the 4 waves through LDS; 128 atomics per block
+                // into one of red_nbin bins, so that a few dozen blocks at most meet on an address
+                __shared__ double redsm[4 * 2 * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    rs[j] += __shfl_xor(rs[j], 16, 64); rs[j] += __shfl_xor(rs[j], 32, 64);
+                    rq[j] += __shfl_xor(rq[j], 16, 64); rq[j] += __shfl_xor(rq[j], 32, 64);
+                }
+                if (lane < 16) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { redsm[(wave * 2 + 0) * 64 + c4 + j] = rs[j]; redsm[(wave * 2 + 1) * 64 + c4 + j] = rq[j]; }
+                }
+                __syncthreads();
+                if (tid < 128) {
+                    const int qq = tid >> 6, col = tid & 63;
+                    if (n0 + col < p.Cout) {
+                        const double t = (redsm[(0 * 2 + qq) * 64 + col] + redsm[(1 * 2 + qq) * 64 + col]) +
+                                         (redsm[(2 * 2 + qq) * 64 + col] + redsm[(3 * 2 + qq) * 64 + col]);
+                        const int bin = (int)((blockIdx.x / p.ntn + blockIdx.z * 5u) % (unsigned)p.red_nbin);
+                        unsafeAtomicAdd(p.red_bins + ((size_t)bin * 2 + qq) * p.Cout + n0 + col, t);
+                    }
                 }
             }
             return;
@@ -543,7 +600,7 @@ int launch_kc(const KcParams& p, int classes, hipStream_t st) {
 }
 
 template <class T, bool TR>
-int dispatch_kc(KcParams p, int classes, int target_blocks, hipStream_t st) {
+int dispatch_kc(KcParams p, int classes, int target_blocks, int* fused, hipStream_t st) {
     const bool slow = (p.Cin % BK) != 0;
     // Batch-64 layers are 2-5 GFLOP each: a 64x64 tile grid of 256-1024 blocks beat 128-wide tiles with deeper split-K
     // on every layer of the step (sweep on MI355X), because the fp32 atomic traffic of split-K grows with the tile
@@ -562,6 +619,9 @@ int dispatch_kc(KcParams p, int classes, int target_blocks, hipStream_t st) {
     else if (2 * blocks < target_blocks) sk = std::min(std::max(1, nchunk / 4), (target_blocks + blocks / 2) / blocks);
     p.splitk = std::max(1, std::min(sk, nchunk));
     if (p.out_bf16) p.splitk = 1;   // a bf16 result cannot be accumulated across blocks
+    // the per-channel epilogue sums exist in the staged 64x64 epilogue of unsplit reductions only
+    if (!(p.splitk == 1 && !narrow_n && (p.Cout & 3) == 0)) p.red_bins = nullptr;
+    if (fused) *fused = p.red_bins != nullptr;
     if (p.splitk > 1 && !prezeroed)
         FAVAE_HIP(hipMemsetAsync(p.out, 0, (size_t)p.Nb * p.Ho * p.Wo * p.Cout * sizeof(float), st));
     if (slow) return launch_kc<T, TR, true, 64, 64, 2, 2>(p, classes, st);
@@ -595,9 +655,12 @@ int dispatch_pm(PmParams p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int favae_conv_igemm(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi,
-                                int Cin, int Ho, int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk,
-                                int dtype, void* stream) {
+namespace {
+struct RedArgs { double* bins; int nbin, mode; const void* act; const float *raw, *mean, *invstd; int* fused; };
+
+int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cin, int Ho,
+                    int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk, int dtype, const RedArgs& red,
+                    void* stream) {
     FAVAE_CHECK_ARG(in && w && out, "favae_conv_igemm: null pointer");
     FAVAE_CHECK_ARG(Nb > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Ho > 0 && Wo > 0 && Cout > 0, "favae_conv_igemm: bad shape");
     FAVAE_CHECK_ARG((ks == 1 && pad == 0) || (ks == 3 && pad == 1), "favae_conv_igemm: ks/pad must be 1/0 or 3/1");
@@ -615,6 +678,7 @@ extern "C" int favae_conv_igemm(const void* in, const void* w, const float* bias
     if (Cin % BK == 0) FAVAE_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)w % 16) == 0, "favae_conv_igemm: 16-byte alignment");
     (void)esz;
     hipStream_t st = (hipStream_t)stream;
+    if (red.fused) *red.fused = 0;
     // one thread per output pixel pays off once the pixel count fills the chip several times over (the decoder side)
     if (g_force_kc_tile < 0 && (long long)Nb * Ho * Wo >= 131072 && thin_in_applicable(Cin, Cout, ks, stride, scatter)) {
         ProfScope prof(14, 2.0 * Nb * Ho * Wo * (double)Cout * 9 * Cin, (hipStream_t)stream);
@@ -624,14 +688,36 @@ extern "C" int favae_conv_igemm(const void* in, const void* w, const float* bias
     p.in = in; p.w = w; p.bias = bias; p.out = out;
     p.Nb = Nb; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
     p.ks = ks; p.stride = stride; p.pad = pad; p.ldw = ks * ks * Cin; p.splitk = splitk; p.out_bf16 = out_bf16;
+    p.red_bins = red.bins; p.red_nbin = red.nbin; p.red_mode = red.mode; p.red_act = red.act; p.red_raw = red.raw;
+    p.red_mean = red.mean; p.red_invstd = red.invstd;
     int classes = 1;
     if (scatter && stride == 2) { classes = 4; p.HoC = Ho / 2; p.WoC = Wo / 2; }
     else { p.HoC = Ho; p.WoC = Wo; }
     p.M = Nb * p.HoC * p.WoC;
     p.ntn = 1;
     const int target = scatter ? 1024 : 512;
-    if (dtype == FAVAE_F32) return scatter ? dispatch_kc<float, true>(p, classes, target, st) : dispatch_kc<float, false>(p, classes, target, st);
-    return scatter ? dispatch_kc<bf16_t, true>(p, classes, target, st) : dispatch_kc<bf16_t, false>(p, classes, target, st);
+    if (dtype == FAVAE_F32)
+        return scatter ? dispatch_kc<float, true>(p, classes, target, red.fused, st) : dispatch_kc<float, false>(p, classes, target, red.fused, st);
+    return scatter ? dispatch_kc<bf16_t, true>(p, classes, target, red.fused, st) : dispatch_kc<bf16_t, false>(p, classes, target, red.fused, st);
+}
+}  // namespace
+
+extern "C" int favae_conv_igemm(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi,
+                                int Cin, int Ho, int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk,
+                                int dtype, void* stream) {
+    const RedArgs none{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return conv_igemm_impl(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype, none, stream);
+}
+
+extern "C" int favae_conv_igemm_red(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi,
+                                    int Cin, int Ho, int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk,
+                                    int dtype, double* bins, int nbins, int mode, const void* act, const float* raw,
+                                    const float* mean, const float* invstd, int* fused, void* stream) {
+    FAVAE_CHECK_ARG(bins && fused && nbins >= 1 && nbins <= 256, "favae_conv_igemm_red: bins / fused / nbins");
+    FAVAE_CHECK_ARG(mode == 1 || (mode == 2 && act && raw && mean && invstd), "favae_conv_igemm_red: mode 1, or mode 2 with act/raw/mean/invstd");
+    FAVAE_CHECK_ARG(!(dtype & FAVAE_OUT_BF16), "favae_conv_igemm_red: fp32 output only");
+    const RedArgs red{bins, nbins, mode, act, raw, mean, invstd, fused};
+    return conv_igemm_impl(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype, red, stream);
 }
 
 extern "C" int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const void* cols, int Cc, int cols_large,

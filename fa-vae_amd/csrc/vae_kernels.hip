@@ -61,8 +61,10 @@ template <int NV, int VW, class F>
 __global__ __launch_bounds__(RED_THREADS) void colreduce(int R, int C, int TPR, int rps, int nslab, double* partial,
                                                          unsigned* tickets, F f) {
     __shared__ double sm[NV * RED_THREADS];
+    __shared__ double btot[F::BLOCK_INIT ? 128 : 1];   // per-tile totals a functor may prepare for its init()
     __shared__ int is_last;
     const int tid = threadIdx.x, tl = tid % TPR, rg = tid / TPR, RG = RED_THREADS / TPR;
+    if constexpr (F::BLOCK_INIT) f.block_init(sm, btot, TPR * VW);
     const int lane = tid & 63, wave = tid >> 6;
     const int c0 = (blockIdx.y * TPR + tl) * VW;
     const bool live = c0 < C;
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(RED_THREADS) void colreduce(int R, int C, int TPR, 
         for (int j = 0; j < VW; ++j) acc[v][j] = 0.0;
     if (live) {
         typename F::Ctx ctx;
-        f.init(ctx, c0);
+        f.init(ctx, c0, btot + (F::BLOCK_INIT ? tl * VW * 2 : 0));
         const int r0 = blockIdx.x * rps, r1 = min(R, r0 + rps);
 #pragma unroll 4
         for (int r = r0 + rg; r < r1; r += RG) f.row(ctx, r, c0, acc);
@@ -199,8 +201,9 @@ template <class T> struct VecLoad<T, 1> {
 template <class RT>
 struct StatsF {
     const RT* x; int C; double R; float eps, mom; float *mean, *invstd, *run_mean, *run_var;
+    static constexpr bool BLOCK_INIT = false;
     struct Ctx {};
-    __device__ void init(Ctx&, int) const {}
+    __device__ void init(Ctx&, int, const double*) const {}
     template <int VW> __device__ void row(const Ctx&, int r, int c0, double (*acc)[VW]) const {
         float v[VW];
         VecLoad<RT, VW>::ld(x + (size_t)r * C + c0, v);
@@ -277,13 +280,86 @@ __global__ __launch_bounds__(256) void bn_lrelu_fwd(const RT* __restrict__ raw, 
     }
 }
 
+// Per-block prologue of the kernels that consume epilogue sums (igemm.hip, KcParams::red_bins): add the nbin bins of the
+// 2*C per-channel sums; tot[q*C + c] is valid after the call.  Needs 2*C <= 512 and 2*C | 256 or 256 | 2*C.
+__device__ __forceinline__ void bins_total(const double* __restrict__ bins, int nbin, int C, double* sm /*[256]*/, double* tot /*[512]*/) {
+    const int tid = threadIdx.x, C2 = 2 * C;
+    if (C2 <= 256) {
+        const int qc = tid % C2, part = tid / C2, parts = 256 / C2;
+        double t = 0.0;
+#pragma unroll 8
+        for (int b = part; b < nbin; b += parts) t += bins[(size_t)b * C2 + qc];
+        sm[tid] = t;
+        __syncthreads();
+        if (tid < C2) {
+            double u = 0.0;
+            for (int k = 0; k < parts; ++k) u += sm[k * C2 + tid];
+            tot[tid] = u;
+        }
+    } else {
+        for (int qc = tid; qc < C2; qc += 256) {
+            double t = 0.0;
+#pragma unroll 8
+            for (int b = 0; b < nbin; ++b) t += bins[(size_t)b * C2 + qc];
+            tot[qc] = t;
+        }
+    }
+    __syncthreads();
+}
+inline bool bins_applicable(int C) { return C % 4 == 0 && C <= 256 && (2 * C <= 256 ? 256 % (2 * C) == 0 : (2 * C) % 256 == 0); }
+
+// BN(train) + LeakyReLU forward whose statistics were accumulated by the producing GEMM's epilogue (sum, sum of squares
+// per channel in `bins`): every block derives mean / invstd itself, block 0 also publishes them and the running stats.
+template <class T>
+__global__ __launch_bounds__(256) void bn_lrelu_fwd_bins(const float* __restrict__ raw, const double* __restrict__ bins, int nbin,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         T* __restrict__ act, float* __restrict__ mean, float* __restrict__ invstd,
+                                                         float* __restrict__ run_mean, float* __restrict__ run_var, size_t nvec,
+                                                         int C, double R, float eps, float mom) {
+    __shared__ double sm[256], tot[512];
+    __shared__ float ab[512];
+    bins_total(bins, nbin, C, sm, tot);
+    const int tid = threadIdx.x;
+    if (tid < C) {
+        const double m = tot[tid] / R;
+        double var = tot[C + tid] / R - m * m;
+        if (var < 0) var = 0;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        const float a = is * gamma[tid];
+        ab[tid] = a;
+        ab[C + tid] = beta[tid] - (float)m * a;
+        if (blockIdx.x == 0) {
+            mean[tid] = (float)m;
+            invstd[tid] = is;
+            if (run_mean) {
+                const double unb = R > 1 ? var * R / (R - 1) : var;
+                run_mean[tid] = (1.f - mom) * run_mean[tid] + mom * (float)m;
+                run_var[tid] = (1.f - mom) * run_var[tid] + mom * (float)unb;
+            }
+        }
+    }
+    __syncthreads();
+    const size_t i0 = (size_t)blockIdx.x * 256 + tid, stride = (size_t)gridDim.x * 256;
+    const int c = (int)((i0 * 4) % C);
+    float a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = ab[c + j]; b[j] = ab[C + c + j]; }
+#pragma unroll 4
+    for (size_t i = i0; i < nvec; i += stride) {
+        float x[4];
+        VecLoad<float, 4>::ld(raw + i * 4, x);
+        store4<T>(act + i * 4, lrelu(x[0] * a[0] + b[0]), lrelu(x[1] * a[1] + b[1]), lrelu(x[2] * a[2] + b[2]), lrelu(x[3] * a[3] + b[3]));
+    }
+}
+
 // ---- BN + LeakyReLU backward ---------------------------------------------------------------------------------
 template <class T, class RT, class DT>
 struct BnBwdRedF {
     const DT* dact; const T* act; const RT* raw; const float* mean; const float* invstd; int C;
     float *dgamma, *dbeta, *s1s2;
+    static constexpr bool BLOCK_INIT = false;
     struct Ctx { float mu[4], is[4]; };
-    __device__ void init(Ctx& k, int c0) const {
+    __device__ void init(Ctx& k, int c0, const double*) const {
         for (int j = 0; j < 4 && c0 + j < C; ++j) { k.mu[j] = mean[c0 + j]; k.is[j] = invstd[c0 + j]; }
     }
     template <int VW> __device__ void row(const Ctx& k, int r, int c0, double (*acc)[VW]) const {
@@ -311,11 +387,35 @@ template <class T, class RT, class DT>
 struct BnBwdApplyF {
     const DT* dact; const T* act; const RT* raw; const float* mean; const float* invstd; const float* gamma;
     const float* s1s2; T* draw; int C; float invR; float* dbias;
+    // bins != NULL: the two sums come from the epilogue of the GEMM that produced dact (igemm.hip, red_mode 2) instead of
+    // BnBwdRedF; every block adds the bins of its channel tile, the first slab also writes dgamma / dbeta
+    const double* bins; int nbin; float *dgamma, *dbeta;
+    static constexpr bool BLOCK_INIT = true;
     struct Ctx { float mu[4], is[4], gi[4], k1[4], k2[4]; };
-    __device__ void init(Ctx& k, int c0) const {
+    __device__ void block_init(double* sm, double* btot, int CT) const {
+        if (!bins) return;   // uniform
+        const int tid = threadIdx.x, n2 = 2 * CT, v = tid % n2, part = tid / n2, parts = RED_THREADS / n2;
+        const int q = v / CT, c = blockIdx.y * CT + v % CT;
+        double t = 0.0;
+        if (c < C) {
+#pragma unroll 8
+            for (int b = part; b < nbin; b += parts) t += bins[((size_t)b * 2 + q) * C + c];
+        }
+        sm[tid] = t;
+        __syncthreads();
+        if (tid < n2) {
+            double u = 0.0;
+            for (int k = 0; k < parts; ++k) u += sm[k * n2 + tid];
+            btot[(tid % CT) * 2 + q] = u;   // q = tid / CT for tid < n2
+            if (blockIdx.x == 0 && c < C) (q ? dgamma : dbeta)[c] = (float)u;
+        }
+        __syncthreads();
+    }
+    __device__ void init(Ctx& k, int c0, const double* bt) const {
         for (int j = 0; j < 4 && c0 + j < C; ++j) {
             k.mu[j] = mean[c0 + j]; k.is[j] = invstd[c0 + j]; k.gi[j] = gamma[c0 + j] * invstd[c0 + j];
-            k.k1[j] = s1s2[c0 + j] * invR; k.k2[j] = s1s2[C + c0 + j] * invR;
+            if (bins) { k.k1[j] = (float)bt[2 * j] * invR; k.k2[j] = (float)bt[2 * j + 1] * invR; }
+            else { k.k1[j] = s1s2[c0 + j] * invR; k.k2[j] = s1s2[C + c0 + j] * invR; }
         }
     }
     template <int VW> __device__ void row(const Ctx& k, int r, int c0, double (*acc)[VW]) const {
@@ -488,8 +588,9 @@ inline bool owner_applicable(long long R, int C) { return R <= (long long)OWN_RG
 template <class T>
 struct ColsumF {
     const T* x; int C; float* out;
+    static constexpr bool BLOCK_INIT = false;
     struct Ctx {};
-    __device__ void init(Ctx&, int) const {}
+    __device__ void init(Ctx&, int, const double*) const {}
     template <int VW> __device__ void row(const Ctx&, int r, int c0, double (*acc)[VW]) const {
         float v[VW];
         VecLoad<T, VW>::ld(x + (size_t)r * C + c0, v);
@@ -813,6 +914,29 @@ extern "C" int favae_bn_train_fwd(const void* raw, const float* gamma, const flo
     return favae_bn_lrelu_fwd(raw, mean, invstd, gamma, beta, act, R, C, 1, dtype, stream);
 }
 
+extern "C" int favae_bn_train_fwd_bins(const float* raw, const double* bins, int nbins, const float* gamma, const float* beta,
+                                       void* act, float* mean, float* invstd, float* run_mean, float* run_var, long long R,
+                                       int C, float eps, float momentum, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(raw && bins && gamma && beta && act && mean && invstd && R > 0 && R < (1LL << 31) && nbins >= 1,
+                    "favae_bn_train_fwd_bins: bad argument");
+    FAVAE_CHECK_ARG(bins_applicable(C), "favae_bn_train_fwd_bins: C = %d not supported (64, 128, 256 ...)", C);
+    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_bn_train_fwd_bins: dtype");
+    const size_t nvec = (size_t)R * C / 4;
+    int c4 = C / 4, gg = c4, t = 256;
+    while (t) { const int r = gg % t; gg = t; t = r; }
+    const int mult = c4 / gg;
+    long long grid = (long long)std::min<size_t>(2048, (nvec + 255) / 256);
+    grid = std::max<long long>(mult, grid / mult * mult);
+    if (dtype == FAVAE_F32)
+        hipLaunchKernelGGL(bn_lrelu_fwd_bins<float>, dim3((unsigned)grid), dim3(256), 0, ST, raw, bins, nbins, gamma, beta, (float*)act,
+                           mean, invstd, run_mean, run_var, nvec, C, (double)R, eps, momentum);
+    else
+        hipLaunchKernelGGL(bn_lrelu_fwd_bins<bf16_t>, dim3((unsigned)grid), dim3(256), 0, ST, raw, bins, nbins, gamma, beta, (bf16_t*)act,
+                           mean, invstd, run_mean, run_var, nvec, C, (double)R, eps, momentum);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
 template <class T, class RT, class DT>
 static int bn_bwd_impl(const void* dact_, const void* act_, const void* raw_, const float* mean, const float* invstd,
                        const float* gamma, void* draw_, float* dgamma, float* dbeta, float* dbias, long long R, int C,
@@ -829,7 +953,26 @@ static int bn_bwd_impl(const void* dact_, const void* act_, const void* raw_, co
     int rc = run_colreduce<2>(R, C, scratch, cap, BnBwdRedF<T, RT, DT>{dact, act, raw, mean, invstd, C, dgamma, dbeta, s1s2}, st);
     if (rc) return rc;
     return run_colreduce<1>(R, C, scratch, cap,
-                            BnBwdApplyF<T, RT, DT>{dact, act, raw, mean, invstd, gamma, s1s2, draw, C, (float)(1.0 / (double)R), dbias}, st);
+                            BnBwdApplyF<T, RT, DT>{dact, act, raw, mean, invstd, gamma, s1s2, draw, C, (float)(1.0 / (double)R), dbias,
+                                                   nullptr, 0, nullptr, nullptr}, st);
+}
+
+extern "C" int favae_bn_lrelu_bwd_bins(const float* dact, const void* act, const float* raw, const float* mean,
+                                       const float* invstd, const float* gamma, const double* bins, int nbins, void* draw,
+                                       float* dgamma, float* dbeta, float* dbias, long long R, int C, double* scratch,
+                                       size_t scratch_doubles, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(dact && act && raw && mean && invstd && gamma && bins && draw && dgamma && dbeta && scratch && nbins >= 1,
+                    "favae_bn_lrelu_bwd_bins: null pointer");
+    FAVAE_CHECK_ARG(R > 0 && R < (1LL << 31) && C > 0, "favae_bn_lrelu_bwd_bins: bad shape");
+    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_bn_lrelu_bwd_bins: dtype");
+    const float invR = (float)(1.0 / (double)R);
+    if (dtype == FAVAE_F32)
+        return run_colreduce<1>(R, C, scratch, scratch_doubles,
+                                BnBwdApplyF<float, float, float>{dact, (const float*)act, raw, mean, invstd, gamma, nullptr, (float*)draw, C,
+                                                                 invR, dbias, bins, nbins, dgamma, dbeta}, ST);
+    return run_colreduce<1>(R, C, scratch, scratch_doubles,
+                            BnBwdApplyF<bf16_t, float, float>{dact, (const bf16_t*)act, raw, mean, invstd, gamma, nullptr, (bf16_t*)draw, C,
+                                                              invR, dbias, bins, nbins, dgamma, dbeta}, ST);
 }
 
 extern "C" int favae_bn_lrelu_bwd(const void* dact, const void* act, const void* raw, const float* mean,

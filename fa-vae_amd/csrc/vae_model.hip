@@ -23,6 +23,7 @@ struct Layer {
 
 constexpr int NL = 13;
 constexpr int L_FC = 5, L_DI = 6, L_OUT = 12;
+constexpr int MAX_BINS = 32;
 
 inline long long al8(long long x) { return (x + 7) & ~7LL; }
 
@@ -83,6 +84,10 @@ struct Vae {
     // bf16 path: conv output (raw) and activation gradient (dact) of the largest BN layers are stored as bf16
     bool raw_bf[NL], dact_bf[NL];
     char* zero_lo; size_t zero_bytes;
+    // per-channel sums taken in GEMM epilogues (favae_conv_igemm_red): BN statistics in the forward pass (sbins), the two
+    // BN-backward reductions in the backward pass (gbins); part of the zero pool; *_fused = the last launch took them
+    double *sbins[NL], *gbins[NL];
+    bool stats_fused[NL], grad_fused[NL];
     // weight gradients run on a second stream next to the dgrad -> BN-backward chain of the main stream
     hipStream_t side; hipEvent_t ev_fork[NL]; hipEvent_t ev_join; bool overlap;
     // single-device epochs: Adam + weight re-layout of a layer follow its weight gradient on the side stream
@@ -130,6 +135,12 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
         }
     }
     v.dz = (float*)c.take((size_t)B * v.z * 4);
+    for (int l = 0; l < NL; ++l) {
+        const bool use = v.L[l].bn && v.L[l].Cout <= 256;
+        v.sbins[l] = use ? (double*)c.take((size_t)MAX_BINS * 2 * v.L[l].Cout * 8) : nullptr;
+        v.gbins[l] = use ? (double*)c.take((size_t)MAX_BINS * 2 * v.L[l].Cout * 8) : nullptr;
+        v.stats_fused[l] = v.grad_fused[l] = false;
+    }
     {
         char* end = (char*)c.take(0);
         v.zero_bytes = (size_t)(end - v.zero_lo);
@@ -159,11 +170,29 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
 
 #define RC(x) do { int rc_ = (x); if (rc_ != FAVAE_OK) return rc_; } while (0)
 
+// bins for the epilogue sums of a layer output of `rows` pixels: ~16 tiles of 64 pixels meet on one address
+int bins_for(long long rows) {
+    int nb = 4;
+    while (nb < MAX_BINS && (long long)nb * 16 * 64 < rows) nb *= 2;
+    return nb;
+}
+
 int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false) {
     const Layer& L = v.L[l];
     const float* bias = v.P + L.b_off;
     const int sk = (pooled && v.raw_pooled[l]) ? -1 : 0;
     const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_OUT_BF16 : 0);
+    v.stats_fused[l] = false;
+    if (pooled && v.sbins[l] && !v.raw_bf[l] && L.kind != LINEAR) {
+        // training step: the zero pool (and with it sbins) was cleared at the start of the step; take the BN statistics
+        // in the GEMM epilogue where this shape runs unsplit
+        const int scatter = L.kind == CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
+        int fused = 0;
+        RC(favae_conv_igemm_red(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, stride, 1, scatter,
+                                sk, dt, v.sbins[l], bins_for(v.rows(l, B)), 1, nullptr, nullptr, nullptr, nullptr, &fused, st));
+        v.stats_fused[l] = fused != 0;
+        return FAVAE_OK;
+    }
     switch (L.kind) {
     case CONV_S2:
         return favae_conv_igemm(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 2, 1, 0, sk, dt, st);
@@ -180,6 +209,11 @@ int bn_fwd(Vae& v, int l, int B, bool train, void* st) {
     const Layer& L = v.L[l];
     const long long R = v.rows(l, B);
     const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0);
+    if (train && v.stats_fused[l]) {
+        v.stats_fused[l] = false;
+        return favae_bn_train_fwd_bins(v.raw[l], v.sbins[l], bins_for(R), v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l],
+                                       v.invstd[l], v.BUF + L.rm_off, v.BUF + L.rv_off, R, L.Cout, 1e-5f, 0.1f, v.dtype, st);
+    }
     if (train)
         return favae_bn_train_fwd(v.raw[l], v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l], v.invstd[l], v.BUF + L.rm_off,
                                   v.BUF + L.rv_off, R, L.Cout, 1e-5f, 0.1f, v.scratch, v.scratch_doubles, dt, st);
@@ -211,6 +245,12 @@ int decoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false) {
 
 int bn_bwd(Vae& v, int l, int B, void* st) {
     const Layer& L = v.L[l];
+    if (v.grad_fused[l]) {   // the GEMM that produced dact[l] summed the two reductions in its epilogue
+        v.grad_fused[l] = false;
+        return favae_bn_lrelu_bwd_bins(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.gbins[l],
+                                       bins_for(v.rows(l, B)), v.draw[l], v.G + L.g_off, v.G + L.be_off, v.G + L.b_off,
+                                       v.rows(l, B), L.Cout, v.scratch, v.scratch_doubles, v.dtype, st);
+    }
     return favae_bn_lrelu_bwd(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.draw[l], v.G + L.g_off,
                               v.G + L.be_off, v.G + L.b_off, v.rows(l, B), L.Cout, v.scratch, v.scratch_doubles, v.s1s2,
                               v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0) | (v.dact_bf[l] ? FAVAE_DACT_BF16 : 0), st);
@@ -261,11 +301,20 @@ int wgrad_launch(Vae& v, int l, const void* in, int B, void* st) {
     }
 }
 
-// input gradient of layer l: draw[l] -> out (fp32, shaped like the layer input)
-int dgrad(Vae& v, int l, float* out, int B, void* st, bool out_zeroed, bool out_bf = false) {
+// input gradient of layer l: draw[l] -> out (fp32, shaped like the layer input).  o >= 0: out is dact[o], the gradient
+// w.r.t. the output of BN layer o; where the launch allows it the BN-backward reductions of layer o ride in its epilogue
+int dgrad(Vae& v, int l, float* out, int B, void* st, bool out_zeroed, bool out_bf = false, int o = -1) {
     const Layer& L = v.L[l];
     const int sk = out_zeroed ? -1 : 0;
     const int dt = v.dtype | (out_bf ? FAVAE_OUT_BF16 : 0);
+    if (o >= 0 && v.gbins[o] && !out_bf && !v.raw_bf[o] && L.kind != LINEAR) {
+        const int scatter = L.kind != CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
+        int fused = 0;
+        RC(favae_conv_igemm_red(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, stride, 1, scatter,
+                                sk, dt, v.gbins[o], bins_for(v.rows(o, B)), 2, v.act[o], v.raw[o], v.mean[o], v.invstd[o], &fused, st));
+        v.grad_fused[o] = fused != 0;
+        return FAVAE_OK;
+    }
     switch (L.kind) {
     case CONV_S2:   // scatter form with [Cin][tap][Cout]
         return favae_conv_igemm(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, 2, 1, 1, sk, dt, st);
@@ -403,11 +452,11 @@ extern "C" int favae_vae_train_fwdbwd(favae_vae* h, const float* data_nhwc, cons
     // ---- backward ----
     RC(favae_colsum(v.draw[L_OUT], v.rows(L_OUT, B), v.ch, v.G + v.L[L_OUT].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
     RC(wgrad(v, L_OUT, v.act[11], B, st));
-    RC(dgrad(v, L_OUT, v.dact[11], B, st, v.dact_pooled[11], v.dact_bf[11]));
+    RC(dgrad(v, L_OUT, v.dact[11], B, st, v.dact_pooled[11], v.dact_bf[11], 11));
     for (int l = 11; l >= 7; --l) {
         RC(bn_bwd(v, l, B, st));
         RC(wgrad(v, l, v.act[l - 1], B, st));
-        RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1], v.dact_bf[l - 1]));
+        RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1], v.dact_bf[l - 1], l > 7 ? l - 1 : -1));
     }
     RC(favae_cast(v.dact[L_DI], v.draw[L_DI], (long long)B * 4096, v.dtype, st));
     RC(favae_colsum(v.draw[L_DI], B, 4096, v.G + v.L[L_DI].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
@@ -420,7 +469,7 @@ extern "C" int favae_vae_train_fwdbwd(favae_vae* h, const float* data_nhwc, cons
     for (int l = 4; l >= 1; --l) {
         RC(bn_bwd(v, l, B, st));
         RC(wgrad(v, l, v.act[l - 1], B, st));
-        RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1], v.dact_bf[l - 1]));
+        RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1], v.dact_bf[l - 1], l - 1));
     }
     RC(bn_bwd(v, 0, B, st));
     RC(wgrad(v, 0, v.xt, B, st));

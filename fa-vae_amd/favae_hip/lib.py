@@ -75,6 +75,20 @@ def conv_igemm(x, w, bias, out, ks, stride, pad, scatter, splitk=0):
     return out
 
 
+def conv_igemm_red(x, w, bias, out, ks, stride, pad, scatter, bins, mode, act=None, raw=None, mean=None, invstd=None, splitk=0):
+    """conv_igemm with per-channel epilogue sums into bins [nbins, 2, Cout] f64 (zeroed by the caller); returns True if the
+    launch took them (favae_conv_igemm_red; mode 1 = BN statistics, mode 2 = the two BN-backward reductions)."""
+    Nb, Hi, Wi, Cin = x.shape
+    _, Ho, Wo, Cout = out.shape
+    assert w.dtype == x.dtype and out.dtype == torch.float32 and bins.dtype == torch.float64 and bins.shape[1:] == (2, Cout)
+    fused = ctypes.c_int(0)
+    check(_lib.favae_conv_igemm_red(ptr(x), ptr(w), ptr(bias), ptr(out), _i(Nb), _i(Hi), _i(Wi), _i(Cin), _i(Ho), _i(Wo),
+                                    _i(Cout), _i(ks), _i(stride), _i(pad), _i(scatter), _i(splitk), _i(dtype_code(x)),
+                                    ptr(bins), _i(bins.shape[0]), _i(mode), ptr(act), ptr(raw), ptr(mean), ptr(invstd),
+                                    ctypes.byref(fused), stream_ptr()))
+    return bool(fused.value)
+
+
 def conv_wgrad(rows, rows_large, cols, cols_large, dw, Nb, Hs, Ws, Hl, Wl, ks, stride, pad, splitk=0):
     """dw [Rc, ks*ks, Cc] f32 += sum_pix rows[pix, r] * cols[pix', c]."""
     Rc, Cc = rows.shape[-1], cols.shape[-1]

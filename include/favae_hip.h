@@ -49,6 +49,19 @@ int favae_conv_igemm(const void* in, const void* w, const float* bias, float* ou
                      int Ho, int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk, int dtype,
                      void* stream);
 
+/* favae_conv_igemm with per-channel sums of the result taken in the GEMM epilogue, so that the BatchNorm layer that
+ * follows (forward, :34,58,72) or precedes (backward, autograd of :34-35 under :249) needs no reduction pass of its own:
+ *   mode 1: bins[b][0][c] += sum y, bins[b][1][c] += sum y^2 over the pixels of a tile (nn.BatchNorm2d batch statistics);
+ *   mode 2: y is the gradient w.r.t. the output `act` of a BN+LeakyReLU whose input was `raw` (same [pixels][Cout]
+ *           shape as out): bins[b][0][c] += sum dd, bins[b][1][c] += sum dd * (raw - mean) * invstd, dd = y * lrelu'(act).
+ * bins: [nbins][2][Cout] doubles, zeroed by the caller; tiles spread over the bins (fp64 atomics), the consumer adds
+ * them up (favae_bn_train_fwd_bins / favae_bn_lrelu_bwd_bins).  *fused = 1 if the launch took the sums, 0 if this shape
+ * runs with a split reduction or a tile without that epilogue (then bins is untouched and the caller reduces itself). */
+int favae_conv_igemm_red(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cin,
+                         int Ho, int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk, int dtype,
+                         double* bins, int nbins, int mode, const void* act, const float* raw, const float* mean,
+                         const float* invstd, int* fused, void* stream);
+
 /* Weight gradient  dw[r][tap][c] += sum_pixels rows[pix][r] * cols[pix'][c]  (fp32 atomics; caller zeroes dw).
  * Exactly one of the two operands may be the large-spatial tensor (Hl x Wl), read at (s*h-p+kh, s*w-p+kw);
  * the other lives on the small grid (Hs x Ws).  Conv2d: rows = dout (small), cols = input (large).
@@ -86,12 +99,22 @@ int favae_bn_lrelu_fwd(const void* raw, const float* mean, const float* invstd, 
 int favae_bn_train_fwd(const void* raw, const float* gamma, const float* beta, void* act, float* mean, float* invstd,
                        float* run_mean, float* run_var, long long R, int C, float eps, float momentum, double* scratch,
                        size_t scratch_doubles, int dtype, void* stream);
+/* favae_bn_train_fwd with the statistics already summed by favae_conv_igemm_red (mode 1) into bins [nbins][2][C]. */
+int favae_bn_train_fwd_bins(const float* raw, const double* bins, int nbins, const float* gamma, const float* beta,
+                            void* act, float* mean, float* invstd, float* run_mean, float* run_var, long long R, int C,
+                            float eps, float momentum, int dtype, void* stream);
 /* backward of BN(train)+LeakyReLU (autograd of :34-35 under loss.backward() :249): draw (dtype) = d loss / d raw,
  * dgamma, dbeta, and dbias = column sums of draw (gradient of the preceding conv bias; NULL to skip).
  * s1s2: 2*C floats of scratch. */
 int favae_bn_lrelu_bwd(const void* dact, const void* act, const void* raw, const float* mean, const float* invstd,
                        const float* gamma, void* draw, float* dgamma, float* dbeta, float* dbias, long long R, int C,
                        double* scratch, size_t scratch_doubles, float* s1s2, int dtype, void* stream);
+/* favae_bn_lrelu_bwd with its two reductions already summed by favae_conv_igemm_red (mode 2) into bins [nbins][2][C]:
+ * one pass (draw, dbias) instead of two; dact and raw fp32. */
+int favae_bn_lrelu_bwd_bins(const float* dact, const void* act, const float* raw, const float* mean, const float* invstd,
+                            const float* gamma, const double* bins, int nbins, void* draw, float* dgamma, float* dbeta,
+                            float* dbias, long long R, int C, double* scratch, size_t scratch_doubles, int dtype,
+                            void* stream);
 /* out[c] = sum_r x[r][c]  (bias gradients of layers without BN). */
 int favae_colsum(const void* x, long long R, int C, float* out, double* scratch, size_t scratch_doubles, int dtype,
                  void* stream);

@@ -186,3 +186,106 @@ def test_final_conv_and_linear_weight_gradient(dt, tol):
     dwl = torch.zeros(Nout, 1, K, device="cuda")
     lib.conv_wgrad(dyl.to(dt).cuda(), 0, xl.to(dt).cuda(), 0, dwl, B, 1, 1, 1, 1, 1, 1, 0, 0)
     assert_close(dwl.cpu().view(Nout, K), dyl.t() @ xl, tol)
+
+
+@pytest.mark.parametrize("dt,tol", DT)
+@pytest.mark.parametrize("kind,Nb,Cin,Cout,H", [("conv", 64, 64, 128, 32), ("conv", 7, 3, 64, 36), ("convT", 32, 128, 64, 16)])
+def test_epilogue_sums_feed_batchnorm_forward(dt, tol, kind, Nb, Cin, Cout, H):
+    """favae_conv_igemm_red mode 1 + favae_bn_train_fwd_bins == conv followed by nn.BatchNorm2d(train) + LeakyReLU
+    (celeba_deepvanilla_vae.py:31-35, 50-59): the statistics ride in the GEMM epilogue."""
+    import ctypes
+    lib = _lib()
+    g = torch.Generator().manual_seed(5 + Cin + H)
+    x = q(torch.randn(Nb, Cin, H, H, generator=g), dt)
+    b = torch.randn(Cout, generator=g)
+    if kind == "conv":
+        w = q(torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1, dt)
+        y = F.conv2d(x, w, b, stride=2, padding=1)
+        wd = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous().to(dt).cuda()
+    else:
+        w = q(torch.randn(Cin, Cout, 3, 3, generator=g) * 0.1, dt)
+        y = F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1)
+        wd = w.permute(1, 2, 3, 0).reshape(Cout, 9, Cin).contiguous().to(dt).cuda()
+    Ho = y.shape[-1]
+    R = Nb * Ho * Ho
+    out = torch.empty(Nb, Ho, Ho, Cout, device="cuda")
+    bins = torch.zeros(8, 2, Cout, dtype=torch.float64, device="cuda")
+    fused = lib.conv_igemm_red(nhwc(x).to(dt).cuda(), wd, b.cuda(), out, 3, 2, 1, int(kind == "convT"), bins, 1)
+    assert fused, "this shape runs unsplit on 64x64 tiles and must take the sums"
+    assert_close(out.cpu(), nhwc(y), tol)
+    o64 = out.double().view(R, Cout)
+    tot = bins.sum(0)
+    assert_close(tot[0].cpu(), o64.sum(0).cpu(), 1e-9)
+    assert_close(tot[1].cpu(), (o64 * o64).sum(0).cpu(), 1e-9)
+    gamma = torch.rand(Cout, generator=g) + 0.5
+    beta = torch.randn(Cout, generator=g)
+    rm, rv = torch.zeros(Cout), torch.ones(Cout)
+    ref = F.leaky_relu(F.batch_norm(out.cpu().permute(0, 3, 1, 2).double(), rm.double(), rv.double(), gamma.double(), beta.double(),
+                                    True, 0.1, 1e-5), 0.01)
+    act = torch.empty(R, Cout, device="cuda", dtype=dt)
+    mean, invstd = torch.zeros(Cout, device="cuda"), torch.zeros(Cout, device="cuda")
+    rmd, rvd = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    i_, ll_, f_ = ctypes.c_int, ctypes.c_longlong, ctypes.c_float
+    gd, bd = gamma.cuda(), beta.cuda()
+    lib.check(lib.raw().favae_bn_train_fwd_bins(lib.ptr(out), lib.ptr(bins), i_(8), lib.ptr(gd), lib.ptr(bd), lib.ptr(act),
+                                                lib.ptr(mean), lib.ptr(invstd), lib.ptr(rmd), lib.ptr(rvd), ll_(R), i_(Cout), f_(1e-5),
+                                                f_(0.1), i_(lib.dtype_code(act)), lib.stream_ptr()))
+    assert_close(act.float().cpu(), nhwc(ref).reshape(R, Cout), 1e-5 if dt == torch.float32 else 8e-3)
+    bm = o64.mean(0).cpu()
+    bv = o64.var(0, unbiased=False).cpu()
+    assert_close(mean.cpu(), bm, 1e-6)
+    assert_close(invstd.cpu(), 1.0 / torch.sqrt(bv + 1e-5), 1e-6)
+    assert_close(rmd.cpu(), 0.1 * bm, 1e-6)
+    assert_close(rvd.cpu(), 0.9 + 0.1 * bv * R / (R - 1), 1e-6)
+
+
+@pytest.mark.parametrize("dt,tol", DT)
+@pytest.mark.parametrize("kind,Nb,Cin,Cout,H", [("conv", 64, 64, 128, 32), ("convT", 32, 128, 64, 32)])
+def test_epilogue_sums_feed_batchnorm_backward(dt, tol, kind, Nb, Cin, Cout, H):
+    """Input gradient of a conv whose input came out of BN + LeakyReLU: favae_conv_igemm_red mode 2 takes sum(dd) and
+    sum(dd * xhat) in the epilogue, favae_bn_lrelu_bwd_bins finishes the BN backward in one pass; against
+    favae_bn_lrelu_bwd fed by the plain GEMM (autograd of celeba_deepvanilla_vae.py:31-35 under :249)."""
+    import ctypes
+    lib = _lib()
+    g = torch.Generator().manual_seed(15 + Cin + H)
+    # the layer in question maps Cin -> Cout; its input gradient has Cin channels = channels of the BN layer before it
+    if kind == "conv":     # dgrad of Conv2d s2: scatter form, dy on the small grid
+        Hs, Hl, scatter = H // 2, H, 1
+    else:                  # dgrad of ConvTranspose2d s2: gather form, dy on the large grid
+        Hs, Hl, scatter = H, H // 2, 0
+    Hdy, Hout = Hs, Hl
+    dy = q(torch.randn(Nb, Hdy, Hdy, Cout, generator=g), dt)
+    wt = q(torch.randn(Cin, 9, Cout, generator=g) * 0.1, dt)
+    R = Nb * Hout * Hout
+    raw = (torch.randn(R, Cin, generator=g) * 2 + 0.3).cuda()
+    gamma, beta = (torch.rand(Cin, generator=g) + 0.5).cuda(), torch.randn(Cin, generator=g).cuda()
+    i_, ll_, f_, sz_ = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_size_t
+    rawl = lib.raw()
+    scratch = torch.zeros(2 * 1024 * 64 + 4096, dtype=torch.float64, device="cuda")
+    act = torch.empty(R, Cin, device="cuda", dtype=dt)
+    mean, invstd = torch.zeros(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
+    lib.check(rawl.favae_bn_train_fwd(lib.ptr(raw), lib.ptr(gamma), lib.ptr(beta), lib.ptr(act), lib.ptr(mean), lib.ptr(invstd),
+                                      lib.ptr(None), lib.ptr(None), ll_(R), i_(Cin), f_(1e-5), f_(0.1), lib.ptr(scratch),
+                                      sz_(scratch.numel()), i_(lib.dtype_code(act)), lib.stream_ptr()))
+    dyd, wtd = dy.to(dt).cuda(), wt.to(dt).cuda()
+    dact0 = torch.empty(Nb, Hout, Hout, Cin, device="cuda")
+    lib.conv_igemm(dyd, wtd, None, dact0, 3, 2, 1, scatter, 0)
+    draw0 = torch.empty(R, Cin, device="cuda", dtype=dt)
+    dg0, db0, dbias0 = (torch.zeros(Cin, device="cuda") for _ in range(3))
+    s1s2 = torch.zeros(2 * Cin, device="cuda")
+    lib.check(rawl.favae_bn_lrelu_bwd(lib.ptr(dact0), lib.ptr(act), lib.ptr(raw), lib.ptr(mean), lib.ptr(invstd), lib.ptr(gamma),
+                                      lib.ptr(draw0), lib.ptr(dg0), lib.ptr(db0), lib.ptr(dbias0), ll_(R), i_(Cin), lib.ptr(scratch),
+                                      sz_(scratch.numel()), lib.ptr(s1s2), i_(lib.dtype_code(act)), lib.stream_ptr()))
+    bins = torch.zeros(16, 2, Cin, dtype=torch.float64, device="cuda")
+    dact1 = torch.empty_like(dact0)
+    fused = lib.conv_igemm_red(dyd, wtd, None, dact1, 3, 2, 1, scatter, bins, 2, act=act, raw=raw, mean=mean, invstd=invstd)
+    assert fused
+    assert torch.equal(dact1, dact0)
+    draw1 = torch.empty_like(draw0)
+    dg1, db1, dbias1 = (torch.zeros(Cin, device="cuda") for _ in range(3))
+    lib.check(rawl.favae_bn_lrelu_bwd_bins(lib.ptr(dact1), lib.ptr(act), lib.ptr(raw), lib.ptr(mean), lib.ptr(invstd), lib.ptr(gamma),
+                                           lib.ptr(bins), i_(16), lib.ptr(draw1), lib.ptr(dg1), lib.ptr(db1), lib.ptr(dbias1), ll_(R),
+                                           i_(Cin), lib.ptr(scratch), sz_(scratch.numel()), i_(lib.dtype_code(act)), lib.stream_ptr()))
+    assert_close(dg1.cpu(), dg0.cpu(), 1e-6)
+    assert_close(db1.cpu(), db0.cpu(), 1e-6)
+    assert_close(draw1.float().cpu(), draw0.float().cpu(), 1e-6 if dt == torch.float32 else 8e-3)
