@@ -682,7 +682,12 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
     // one thread per output pixel pays off once the pixel count fills the chip several times over (the decoder side)
     if (g_force_kc_tile < 0 && (long long)Nb * Ho * Wo >= 131072 && thin_in_applicable(Cin, Cout, ks, stride, scatter)) {
         ProfScope prof(14, 2.0 * Nb * Ho * Wo * (double)Cout * 9 * Cin, (hipStream_t)stream);
-        return thin_in_launch(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, stride, scatter, dtype, out_bf16, (hipStream_t)stream);
+        ThinRed tr{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+        if (red.bins && red.mode == 2 && !out_bf16) {   // the statistics form (mode 1) is not needed on this path
+            tr = ThinRed{red.bins, red.nbin, red.act, red.raw, red.mean, red.invstd};
+            if (red.fused) *red.fused = 1;
+        }
+        return thin_in_launch(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, stride, scatter, dtype, out_bf16, tr, (hipStream_t)stream);
     }
     KcParams p;
     p.in = in; p.w = w; p.bias = bias; p.out = out;

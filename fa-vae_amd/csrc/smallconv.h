@@ -7,5 +7,7 @@ bool wgrad_nw_applicable(int Cw, int Cs, int ks, int stride, int narrow_is_large
 int wgrad_nw_launch(const void* wide, const void* narrow, float* dw, int Nb, int Hq, int Wq, int Cw, int Hn, int Wn, int Cs,
                     int stride, int narrow_is_large, int s_ch, int s_tap, int s_c, int dtype, hipStream_t st);
 bool thin_in_applicable(int Cs, int Co, int ks, int stride, int scatter);
+// optional BatchNorm-backward sums taken while the result is stored (bins == nullptr: none); see favae_conv_igemm_red mode 2
+struct ThinRed { double* bins; int nbin; const void* act; const float *raw, *mean, *invstd; };
 int thin_in_launch(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cs, int Ho, int Wo,
-                   int Co, int stride, int scatter, int dtype, int out_bf16, hipStream_t st);
+                   int Co, int stride, int scatter, int dtype, int out_bf16, const ThinRed& red, hipStream_t st);

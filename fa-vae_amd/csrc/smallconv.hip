@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cstdlib>
 #include "common.h"
+#include <type_traits>
 #include "smallconv.h"
 
 namespace {
@@ -131,10 +132,10 @@ int wgrad_nw_launch(const void* wide, const void* narrow, float* dw, int Nb, int
 //   out[pix][co] = bias[co] + sum_{tap, c} in[coord(pix, tap)][c] * w[co][tap][c]
 namespace {
 
-template <class T, int CS, int CO>
+template <class T, int CS, int CO, bool RED>
 __global__ __launch_bounds__(256) void conv_thin_in(const T* __restrict__ in, const float* __restrict__ wk /* [9*CS][CO] fp32 */,
                                                     const float* __restrict__ bias, float* __restrict__ out, int Hi, int Wi,
-                                                    int Ho, int Wo, int stride, int flip, int total, int out_bf16) {
+                                                    int Ho, int Wo, int stride, int flip, int total, int out_bf16, const ThinRed red) {
     const int pix = min(blockIdx.x * 256 + (int)threadIdx.x, total - 1);   // tail threads redo the last pixel, store nothing
     const int n = pix / (Ho * Wo), rem = pix - n * Ho * Wo, y = rem / Wo, x = rem - y * Wo;
     float v[9 * CS];
@@ -161,7 +162,26 @@ __global__ __launch_bounds__(256) void conv_thin_in(const T* __restrict__ in, co
     const int pix_w0 = blockIdx.x * 256 + wave * 64;   // first pixel of this wave
     constexpr int LPR = HC / 4;                        // lanes per pixel row (float4 each)
     constexpr int PPI = 64 / LPR;                      // pixel rows per store instruction
+    __shared__ double redsm[4 * 2 * HC];
+    using ActVec = typename std::conditional<sizeof(T) == 2, uint2, float4>::type;
     for (int hb = 0; hb < CO; hb += HC) {
+        // optional BatchNorm-backward sums of the layer this gradient belongs to (see KcParams::red_mode 2 in igemm.hip):
+        // a lane keeps its 4 channels over the 8 pixel rows it stores per pass; their act / raw values are fetched here,
+        // ahead of the FMAs, so that the store loop does not wait on memory
+        ActVec pa[64 / PPI];
+        float4 px[64 / PPI];
+        float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
+        if (RED) {
+            mu = *(const float4*)(red.mean + hb + (lane % LPR) * 4);
+            is = *(const float4*)(red.invstd + hb + (lane % LPR) * 4);
+#pragma unroll
+            for (int i = 0; i < 64 / PPI; ++i) {
+                const int prow = min(pix_w0 + i * PPI + lane / LPR, total - 1);
+                const size_t e = (size_t)prow * CO + hb + (lane % LPR) * 4;
+                pa[i] = *(const ActVec*)((const T*)red.act + e);
+                px[i] = *(const float4*)(red.raw + e);
+            }
+        }
 #pragma unroll
         for (int cb = 0; cb < HC; cb += 16) {   // 16 output channels at a time keeps the accumulators at 16 registers
             float acc[16];
@@ -177,11 +197,27 @@ __global__ __launch_bounds__(256) void conv_thin_in(const T* __restrict__ in, co
         // wave-local hand-over: the tile is written and read by the same wave
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        double rs[4] = {0.0, 0.0, 0.0, 0.0}, rq[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < 64 / PPI; ++i) {
             const int pr = i * PPI + lane / LPR, c4 = (lane % LPR) * 4;
             if (pix_w0 + pr < total) {
                 const float4 r4 = *(const float4*)(wt + pr * RSF + c4);
+                if (RED) {
+                    float a[4];
+                    if constexpr (sizeof(T) == 2) {
+                        a[0] = __uint_as_float(pa[i].x << 16); a[1] = __uint_as_float(pa[i].x & 0xffff0000u);
+                        a[2] = __uint_as_float(pa[i].y << 16); a[3] = __uint_as_float(pa[i].y & 0xffff0000u);
+                    } else {
+                        a[0] = pa[i].x; a[1] = pa[i].y; a[2] = pa[i].z; a[3] = pa[i].w;
+                    }
+                    const float4 xr = px[i];
+                    const float d0 = r4.x * (a[0] > 0.f ? 1.f : 0.01f), d1 = r4.y * (a[1] > 0.f ? 1.f : 0.01f);
+                    const float d2 = r4.z * (a[2] > 0.f ? 1.f : 0.01f), d3 = r4.w * (a[3] > 0.f ? 1.f : 0.01f);
+                    rs[0] += d0; rs[1] += d1; rs[2] += d2; rs[3] += d3;
+                    rq[0] += (double)d0 * ((xr.x - mu.x) * is.x); rq[1] += (double)d1 * ((xr.y - mu.y) * is.y);
+                    rq[2] += (double)d2 * ((xr.z - mu.z) * is.z); rq[3] += (double)d3 * ((xr.w - mu.w) * is.w);
+                }
                 if (out_bf16) {
                     uint2 u;
                     u.x = (unsigned)f32_to_bf16(r4.x) | ((unsigned)f32_to_bf16(r4.y) << 16);
@@ -194,6 +230,24 @@ __global__ __launch_bounds__(256) void conv_thin_in(const T* __restrict__ in, co
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (RED) {   // block-uniform
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                for (int o = LPR; o < 64; o <<= 1) { rs[j] += __shfl_xor(rs[j], o, 64); rq[j] += __shfl_xor(rq[j], o, 64); }
+            }
+            if (lane < LPR) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { redsm[(wave * 2 + 0) * HC + lane * 4 + j] = rs[j]; redsm[(wave * 2 + 1) * HC + lane * 4 + j] = rq[j]; }
+            }
+            __syncthreads();
+            if (threadIdx.x < 2 * HC) {
+                const int qq = threadIdx.x / HC, col = threadIdx.x % HC;
+                const double t = (redsm[(0 * 2 + qq) * HC + col] + redsm[(1 * 2 + qq) * HC + col]) +
+                                 (redsm[(2 * 2 + qq) * HC + col] + redsm[(3 * 2 + qq) * HC + col]);
+                unsafeAtomicAdd(red.bins + ((size_t)(blockIdx.x % (unsigned)red.nbin) * 2 + qq) * CO + hb + col, t);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -219,7 +273,7 @@ std::atomic<unsigned> g_wk_next{0};
 }  // namespace
 
 int thin_in_launch(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cs, int Ho, int Wo,
-                   int Co, int stride, int scatter, int dtype, int out_bf16, hipStream_t st) {
+                   int Co, int stride, int scatter, int dtype, int out_bf16, const ThinRed& red, hipStream_t st) {
     static float* per_device[64] = {nullptr};
     int dev = 0;
     FAVAE_HIP(hipGetDevice(&dev));
@@ -233,8 +287,12 @@ int thin_in_launch(const void* in, const void* w, const float* bias, float* out,
     else
         hipLaunchKernelGGL(thin_in_wprep<bf16_t>, dim3(cdiv(K * Co, 256)), dim3(256), 0, st, (const bf16_t*)w, wk_scratch, K, Co);
 #define TI_CASE(T_, CS_)                                                                                                   \
-    hipLaunchKernelGGL((conv_thin_in<T_, CS_, 64>), dim3(grid), dim3(256), 4 * 64 * (32 + 4) * sizeof(float), st, (const T_*)in, wk_scratch, bias, out, Hi, Wi, \
-                       Ho, Wo, stride, scatter, total, out_bf16)
+    if (red.bins)                                                                                                          \
+        hipLaunchKernelGGL((conv_thin_in<T_, CS_, 64, true>), dim3(grid), dim3(256), 4 * 64 * (32 + 4) * sizeof(float), st, (const T_*)in, wk_scratch, bias, out, Hi, Wi, \
+                           Ho, Wo, stride, scatter, total, out_bf16, red);                                                 \
+    else                                                                                                                   \
+        hipLaunchKernelGGL((conv_thin_in<T_, CS_, 64, false>), dim3(grid), dim3(256), 4 * 64 * (32 + 4) * sizeof(float), st, (const T_*)in, wk_scratch, bias, out, Hi, Wi, \
+                           Ho, Wo, stride, scatter, total, out_bf16, red)
     if (dtype == FAVAE_F32) {
         switch (Cs) { case 1: TI_CASE(float, 1); break; case 2: TI_CASE(float, 2); break; case 3: TI_CASE(float, 3); break; default: TI_CASE(float, 4); }
     } else {

@@ -600,6 +600,24 @@ struct ColsumF {
     __device__ void finish(int c, const double* tot) const { out[c] = (float)tot[0]; }
 };
 
+// column sums of an fp32 matrix that is also stored as T on the way (gradient hand-over of a layer without BN:
+// out[c] = bias gradient, y = the dtype copy the weight / input gradient GEMMs read)
+template <class T>
+struct ColsumCastF {
+    const float* x; T* y; int C; float* out;
+    static constexpr bool BLOCK_INIT = false;
+    struct Ctx {};
+    __device__ void init(Ctx&, int, const double*) const {}
+    template <int VW> __device__ void row(const Ctx&, int r, int c0, double (*acc)[VW]) const {
+        float v[VW];
+        VecLoad<float, VW>::ld(x + (size_t)r * C + c0, v);
+        VecLoad<T, VW>::st(y + (size_t)r * C + c0, v);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) acc[0][j] += v[j];
+    }
+    __device__ void finish(int c, const double* tot) const { out[c] = (float)tot[0]; }
+};
+
 // ---- reparameterise + KL(q || N(mu_P, 1/tau)) : celeba_deepvanilla_vae.py:86-92,137-150,231-232 --------------
 // one block; B*z is at most a few tens of thousands of elements
 template <class T>
@@ -655,6 +673,50 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd(const float* __restrict__ 
     }
 }
 
+// The same gradient in one block that also sums its columns: dbias [2z] = bias gradient of the encoder head (fc_mu | fc_var
+// rows of dfc).  Element-parallel first (values parked in LDS), then one thread per column adds its rows in order.
+constexpr int RKB_THREADS = 1024, RKB_MAX = 8192;   // B * 2z <= RKB_MAX
+template <class T>
+__global__ __launch_bounds__(RKB_THREADS) void reparam_kl_bwd_bias(const float* __restrict__ fc, const float* __restrict__ eps,
+                                                                   const double* __restrict__ prior, const int* __restrict__ idx,
+                                                                   const float* __restrict__ stdq, const float* __restrict__ dz,
+                                                                   float tau, float beta, int B, int z, T* __restrict__ dfc,
+                                                                   float* __restrict__ dbias) {
+    __shared__ float vals[RKB_MAX];
+    const double std_p = sqrt((double)(1.0f / tau));
+    const double sp = fmin(fmax(std_p, 1e-6), 1e20);
+    const double w = (double)beta / B;
+    const int z2 = 2 * z;
+    for (int i = threadIdx.x; i < B * z; i += RKB_THREADS) {
+        const int b = i / z, k = i - b * z;
+        const float mu = fc[b * z2 + k];
+        const float sd = stdq[i];
+        const double mp = prior ? prior[(size_t)(idx ? idx[b] : b) * z + k] : 0.0;
+        const bool in_rng = sd >= 1e-6f && sd <= 1e20f;
+        const double sq = fmin(fmax((double)sd, 1e-6), 1e20);
+        const float dkl_mu = (float)(w * ((double)mu - mp) / (sp * sp));
+        const float dkl_sd = in_rng ? (float)(w * (sq / (sp * sp) - 1.0 / sq)) : 0.f;
+        const float g = dz[i];
+        const float dmu = g + dkl_mu;
+        const float dls = (g * eps[i] + dkl_sd) * 0.5f * sd;
+        dfc[b * z2 + k] = from_f32<T>(dmu);
+        dfc[b * z2 + z + k] = from_f32<T>(dls);
+        vals[b * z2 + k] = dmu;
+        vals[b * z2 + z + k] = dls;
+    }
+    __syncthreads();
+    // 4 partial sums per column (rows b % 4 == part), combined in a fixed order
+    __shared__ double part[4 * 256];
+    const int c = threadIdx.x % 256, p4 = threadIdx.x / 256;
+    if (c < z2) {
+        double t = 0.0;
+        for (int b = p4; b < B; b += 4) t += vals[b * z2 + c];
+        part[p4 * 256 + c] = t;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < z2) dbias[threadIdx.x] = (float)((part[threadIdx.x] + part[256 + threadIdx.x]) + (part[512 + threadIdx.x] + part[768 + threadIdx.x]));
+}
+
 // eval-mode head of update_x: mu and var = std^2 as float64 rows of X.mean / X.cov (:331-358)
 __global__ void encode_head(const float* __restrict__ fc, int B, int z, double* __restrict__ xmean, double* __restrict__ xcov) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -693,6 +755,67 @@ __global__ void ll_finish(const double* partial, int n, double D, double var_x, 
     }
 }
 
+// Same, one launch: the block that takes the last ticket adds the per-block partials in a fixed order and writes the
+// reconstruction error; with dbias != NULL the column sums of the gradient (bias gradient of the output conv, C <= 4
+// interleaved channels) come out of the same pass.  Replaces sigmoid_ll + ll_finish + a column reduction.
+template <class T>
+__global__ __launch_bounds__(256) void sigmoid_ll_bias(const float* __restrict__ raw, const float* __restrict__ x, size_t n, int C,
+                                                       float inv_var_B, T* __restrict__ draw, double* __restrict__ partial,
+                                                       unsigned* __restrict__ ticket, double D, double var_x, double B,
+                                                       double* __restrict__ rec_err, float* __restrict__ dbias) {
+    __shared__ double sm[5 * 4];
+    __shared__ int is_last;
+    double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    const size_t stride = (size_t)gridDim.x * 256;
+    const int cstep = (int)(stride % (size_t)C);
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int c = (int)(i % (size_t)C);
+    for (; i < n; i += stride) {
+        const float s = 1.f / (1.f + expf(-raw[i]));
+        const float d = s - x[i];
+        a[0] += (double)d * d;
+        const float g = d * inv_var_B * s * (1.f - s);
+        draw[i] = from_f32<T>(g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[1 + j] += (c == j) ? g : 0.f;
+        c += cstep;
+        if (c >= C) c -= C;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        a[k] = wave_sum(a[k]);
+        if (lane == 0) sm[k * 4 + wave] = a[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5)
+        __hip_atomic_store(&partial[(size_t)blockIdx.x * 5 + threadIdx.x],
+                           (sm[threadIdx.x * 4] + sm[threadIdx.x * 4 + 1]) + (sm[threadIdx.x * 4 + 2] + sm[threadIdx.x * 4 + 3]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    double t[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) t[k] += __hip_atomic_load(&partial[(size_t)b * 5 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        t[k] = wave_sum(t[k]);
+        if (lane == 0) sm[k * 4 + wave] = t[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const double tot = (sm[threadIdx.x * 4] + sm[threadIdx.x * 4 + 1]) + (sm[threadIdx.x * 4 + 2] + sm[threadIdx.x * 4 + 3]);
+        if (threadIdx.x == 0) *rec_err = 0.5 * (D * log(2.0 * M_PI) + D * log(var_x)) + 0.5 * tot / (var_x * B);
+        else if (dbias && (int)threadIdx.x - 1 < C) dbias[threadIdx.x - 1] = (float)tot;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // sigmoid(raw) vs y: per-block partial (sum (y-s)^2, sum y, sum y^2), then one block adds them onto acc3
 __global__ __launch_bounds__(256) void sigmoid_sse(const float* __restrict__ raw, const float* __restrict__ y, size_t n,
                                                    double* __restrict__ partial) {
@@ -724,7 +847,8 @@ __global__ void sigmoid_only(const float* __restrict__ raw, float* __restrict__ 
 }
 
 // ---- Adam (torch.optim.Adam defaults, :131,250) over the flat parameter arena ---------------------------------
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+template <bool CLEAR_G>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t n4, float b1, float b2, float eps,
                                                    float step_size, float bc2_sqrt) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -738,6 +862,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             pp[j] = pp[j] - step_size * (mm[j] / denom);
         }
         ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V;
+        if (CLEAR_G) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -1000,6 +1125,13 @@ extern "C" int favae_colsum(const void* x, long long R, int C, float* out, doubl
                               : run_colreduce<1>(R, C, scratch, scratch_doubles, ColsumF<bf16_t>{(const bf16_t*)x, C, out}, ST);
 }
 
+extern "C" int favae_colsum_cast(const float* x, void* y, long long R, int C, float* out, double* scratch, size_t scratch_doubles,
+                                 int dtype, void* stream) {
+    FAVAE_CHECK_ARG(x && y && out && scratch && R > 0 && R < (1LL << 31) && C > 0, "favae_colsum_cast: bad argument");
+    return dtype == FAVAE_F32 ? run_colreduce<1>(R, C, scratch, scratch_doubles, ColsumCastF<float>{x, (float*)y, C, out}, ST)
+                              : run_colreduce<1>(R, C, scratch, scratch_doubles, ColsumCastF<bf16_t>{x, (bf16_t*)y, C, out}, ST);
+}
+
 extern "C" int favae_reparam_kl_fwd(const float* fc, const float* eps, const double* prior, const int* idx, float tau, int B,
                                     int z, void* zlat, float* stdq, double* kl_out, int dtype, void* stream) {
     FAVAE_CHECK_ARG(fc && eps && zlat && stdq && kl_out && B > 0 && z > 0 && tau > 0, "favae_reparam_kl_fwd: bad argument");
@@ -1019,6 +1151,19 @@ extern "C" int favae_reparam_kl_bwd(const float* fc, const float* eps, const dou
         hipLaunchKernelGGL(reparam_kl_bwd<float>, dim3(grid), dim3(256), 0, ST, fc, eps, prior, idx, stdq, dz, tau, beta, B, z, (float*)dfc);
     else
         hipLaunchKernelGGL(reparam_kl_bwd<bf16_t>, dim3(grid), dim3(256), 0, ST, fc, eps, prior, idx, stdq, dz, tau, beta, B, z, (bf16_t*)dfc);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_reparam_kl_bwd_bias(const float* fc, const float* eps, const double* prior, const int* idx,
+                                         const float* stdq, const float* dz, float tau, float beta, int B, int z, void* dfc,
+                                         float* dbias, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(fc && eps && stdq && dz && dfc && dbias && B > 0 && z > 0 && 2 * z <= 256 && (long long)B * 2 * z <= RKB_MAX,
+                    "favae_reparam_kl_bwd_bias: bad argument (z <= 128, B * 2z <= 8192)");
+    if (dtype == FAVAE_F32)
+        hipLaunchKernelGGL(reparam_kl_bwd_bias<float>, dim3(1), dim3(RKB_THREADS), 0, ST, fc, eps, prior, idx, stdq, dz, tau, beta, B, z, (float*)dfc, dbias);
+    else
+        hipLaunchKernelGGL(reparam_kl_bwd_bias<bf16_t>, dim3(1), dim3(RKB_THREADS), 0, ST, fc, eps, prior, idx, stdq, dz, tau, beta, B, z, (bf16_t*)dfc, dbias);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }
@@ -1047,6 +1192,28 @@ extern "C" int favae_sigmoid_ll(const float* raw, const float* x, int B, long lo
     return FAVAE_OK;
 }
 
+extern "C" int favae_sigmoid_ll_bias(const float* raw, const float* x, int B, long long D, int C, float var_x, void* draw,
+                                     double* rec_err, float* dbias, double* scratch, size_t scratch_doubles, int dtype,
+                                     void* stream) {
+    FAVAE_CHECK_ARG(raw && x && draw && rec_err && scratch && B > 0 && D > 0 && var_x > 0, "favae_sigmoid_ll_bias: bad argument");
+    FAVAE_CHECK_ARG(C >= 1 && C <= 4 && D % C == 0, "favae_sigmoid_ll_bias: 1..4 interleaved channels");
+    const size_t n = (size_t)B * D;
+    const int grid = (int)std::min<size_t>(256, (n + 255) / 256);   // one batch of partial loads per thread of the last block
+    FAVAE_CHECK_ARG((size_t)grid * 5 <= scratch_doubles, "favae_sigmoid_ll_bias: scratch too small");
+    unsigned* ticket = nullptr;
+    int trc = ticket_base(1, &ticket);
+    if (trc) return trc;
+    const float ivb = 1.f / (var_x * (float)B);
+    if (dtype == FAVAE_F32)
+        hipLaunchKernelGGL(sigmoid_ll_bias<float>, dim3(grid), dim3(256), 0, ST, raw, x, n, C, ivb, (float*)draw, scratch, ticket,
+                           (double)D, (double)var_x, (double)B, rec_err, dbias);
+    else
+        hipLaunchKernelGGL(sigmoid_ll_bias<bf16_t>, dim3(grid), dim3(256), 0, ST, raw, x, n, C, ivb, (bf16_t*)draw, scratch, ticket,
+                           (double)D, (double)var_x, (double)B, rec_err, dbias);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
 extern "C" int favae_sigmoid_sse(const float* raw, const float* y, long long n, double* acc3, double* scratch,
                                  size_t scratch_doubles, void* stream) {
     FAVAE_CHECK_ARG(raw && y && acc3 && scratch && n > 0, "favae_sigmoid_sse: bad argument");
@@ -1071,7 +1238,17 @@ extern "C" int favae_adam_step(float* p, const float* g, float* m, float* v, lon
     FAVAE_CHECK_ARG(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "favae_adam_step: bad argument (n must be a multiple of 4)");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid((size_t)n / 4)), dim3(256), 0, ST, p, g, m, v, (size_t)n / 4, beta1, beta2, eps, step_size, bc2_sqrt);
+    hipLaunchKernelGGL(adam_kernel<false>, dim3(ew_grid((size_t)n / 4)), dim3(256), 0, ST, p, (float*)g, m, v, (size_t)n / 4, beta1, beta2, eps, step_size, bc2_sqrt);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_adam_step_clear(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                                     float eps, long long step, void* stream) {
+    FAVAE_CHECK_ARG(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "favae_adam_step_clear: bad argument (n must be a multiple of 4)");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adam_kernel<true>, dim3(ew_grid((size_t)n / 4)), dim3(256), 0, ST, p, g, m, v, (size_t)n / 4, beta1, beta2, eps, step_size, bc2_sqrt);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

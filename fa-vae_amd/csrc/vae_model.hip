@@ -89,9 +89,15 @@ struct Vae {
     double *sbins[NL], *gbins[NL];
     bool stats_fused[NL], grad_fused[NL];
     // weight gradients run on a second stream next to the dgrad -> BN-backward chain of the main stream
-    hipStream_t side; hipEvent_t ev_fork[NL]; hipEvent_t ev_join; bool overlap;
+    // and the layer-wise optimiser steps of an epoch on a third (side2), behind the weight gradient of their layer
+    hipStream_t side, side2; hipEvent_t ev_fork[NL]; hipEvent_t ev_dg[NL]; hipEvent_t ev_wg[NL]; hipEvent_t ev_join; bool overlap;
     // single-device epochs: Adam + weight re-layout of a layer follow its weight gradient on the side stream
-    struct { bool on; float lr, b1, b2, eps; long long step; int pending; } ada;
+    // epoch: steps of one epoch run back to back: Adam clears the gradients it has consumed (no memset per step) and the
+    // main stream joins the side stream only when the next step's forward pass is about to read the weights
+    struct { bool on; float lr, b1, b2, eps; long long step; int pending; bool epoch; } ada;
+    bool join_pending; bool dg_all;
+    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast
+    float* xf_alt; char* xt_alt;   // second batch buffer: the next gather must not overwrite what wgrad(encoder.0) still reads
     const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(SH + L[l].wc_off * esz); }
     const void* Wt(int l) const { return (const void*)(SH + L[l].wt_off * esz); }
     long long rows(int l, int B) const { return (long long)B * L[l].Hout * L[l].Hout; }
@@ -159,6 +165,8 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
     const size_t img = (size_t)B * 64 * 64 * v.ch;
     v.xf = (float*)c.take(img * 4);
     v.xt = (char*)c.take(img * v.esz);
+    v.xf_alt = (float*)c.take(img * 4);
+    v.xt_alt = (char*)c.take(img * v.esz);
     v.zlat = (char*)c.take((size_t)B * v.z * v.esz);
     v.stdq = (float*)c.take((size_t)B * v.z * 4);
     v.s1s2 = (float*)c.take(2 * 1024 * 4);
@@ -183,7 +191,7 @@ int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false
     const int sk = (pooled && v.raw_pooled[l]) ? -1 : 0;
     const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_OUT_BF16 : 0);
     v.stats_fused[l] = false;
-    if (pooled && v.sbins[l] && !v.raw_bf[l] && L.kind != LINEAR) {
+    if (pooled && (v.fuse & 1u) && v.sbins[l] && !v.raw_bf[l] && L.kind != LINEAR) {
         // training step: the zero pool (and with it sbins) was cleared at the start of the step; take the BN statistics
         // in the GEMM epilogue where this shape runs unsplit
         const int scatter = L.kind == CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
@@ -232,8 +240,11 @@ int encoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false) {
 }
 
 int decoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false) {
-    RC(conv_fwd(v, L_DI, v.zlat, B, st, pooled));
-    RC(favae_cast(v.raw[L_DI], v.act[L_DI], (long long)B * 4096, v.dtype, st));
+    {   // decoder_input (:41-45) has no BN / activation: the GEMM stores its result in the dtype the next layer reads
+        const Layer& L = v.L[L_DI];
+        RC(favae_conv_igemm(v.zlat, v.Wf(L_DI), v.P + L.b_off, (float*)v.act[L_DI], B, 1, 1, L.Cin, 1, 1, L.Cout, 1, 1, 0, 0, 0,
+                            v.dtype | (v.dtype == FAVAE_BF16 ? FAVAE_OUT_BF16 : 0), st));
+    }
     const void* in = v.act[L_DI];
     for (int l = 7; l <= 11; ++l) {
         RC(conv_fwd(v, l, in, B, st, pooled));
@@ -266,20 +277,39 @@ int wgrad(Vae& v, int l, const void* in, int B, void* st) {
     if (!v.overlap) return wgrad_launch(v, l, in, B, st);
     FAVAE_HIP(hipEventRecord(v.ev_fork[l], (hipStream_t)st));
     FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_fork[l], 0));
-    // Layer-wise optimiser step on the side stream.  The layer whose weight gradient was queued before this one may be
-    // updated now: this fork event was recorded after its input-gradient GEMM (the last reader of its weight shadows)
-    // was queued on the main stream, and its BN / bias gradients were complete before its own fork.
-    if (v.ada.on && v.ada.pending >= 0) RC(adam_layer(v, v.ada.pending, (void*)v.side));
     RC(wgrad_launch(v, l, in, B, (void*)v.side));
-    if (v.ada.on) v.ada.pending = l;
+    if (!v.ada.on) return FAVAE_OK;
+    FAVAE_HIP(hipEventRecord(v.ev_wg[l], v.side));
+    // Layer-wise optimiser step on the third stream.  The layer whose weight gradient was queued before this one may be
+    // updated once that gradient is complete (ev_wg) and its input-gradient GEMM, the last reader of its weight shadows,
+    // has run: this fork event was recorded after that GEMM was queued on the main stream.  Its BN / bias gradients
+    // were complete before its own fork.
+    if (v.ada.pending >= 0) {
+        FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_fork[l], 0));
+        FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[v.ada.pending], 0));
+        RC(adam_layer(v, v.ada.pending, (void*)v.side2));
+        v.ada.pending = -1;
+    }
+    if (!(v.dg_all || l == 1)) v.ada.pending = l;
     return FAVAE_OK;
+}
+
+// after the input-gradient GEMM of layer l is queued on the main stream: layers that do not wait for the next fork
+// (encoder.1, whose update would otherwise sit between the last weight gradient and the end of the step) get an event
+int after_dgrad(Vae& v, int l, void* st) {
+    if (!(v.overlap && v.ada.on && (v.dg_all || l == 1))) return FAVAE_OK;
+    FAVAE_HIP(hipEventRecord(v.ev_dg[l], (hipStream_t)st));
+    FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_dg[l], 0));
+    FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[l], 0));
+    return adam_layer(v, l, (void*)v.side2);
 }
 
 // Adam over the arena slice of layer l (weights, bias, BN affine) + its dtype shadows
 int adam_layer(Vae& v, int l, void* st) {
     const Layer& L = v.L[l];
     const long long lo = L.w_off, hi = l + 1 < NL ? v.L[l + 1].w_off : v.nparam;
-    RC(favae_adam_step(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, st));
+    if (v.ada.epoch) RC(favae_adam_step_clear(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, st));
+    else RC(favae_adam_step(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, st));
     void* c = L.wc_off >= 0 ? v.SH + L.wc_off * v.esz : nullptr;
     void* t = L.wt_off >= 0 ? v.SH + L.wt_off * v.esz : nullptr;
     if (c || t) RC(favae_weight_prep(v.P + L.w_off, c, t, L.Cout, L.taps, L.Cin, v.dtype, st));
@@ -307,7 +337,7 @@ int dgrad(Vae& v, int l, float* out, int B, void* st, bool out_zeroed, bool out_
     const Layer& L = v.L[l];
     const int sk = out_zeroed ? -1 : 0;
     const int dt = v.dtype | (out_bf ? FAVAE_OUT_BF16 : 0);
-    if (o >= 0 && v.gbins[o] && !out_bf && !v.raw_bf[o] && L.kind != LINEAR) {
+    if (o >= 0 && (v.fuse & (l == L_OUT ? 4u : 2u)) && v.gbins[o] && !out_bf && !v.raw_bf[o] && L.kind != LINEAR) {
         const int scatter = L.kind != CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
         int fused = 0;
         RC(favae_conv_igemm_red(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, stride, 1, scatter,
@@ -391,10 +421,21 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     const char* e = getenv("FAVAE_SINGLE_STREAM");
     v.overlap = !(e && e[0] == '1');
     v.side = nullptr;
-    v.ada = {false, 0.f, 0.f, 0.f, 0.f, 0, -1};
+    v.side2 = nullptr;
+    v.ada = {false, 0.f, 0.f, 0.f, 0.f, 0, -1, false};
+    v.join_pending = false;
+    {
+        const char* d = getenv("FAVAE_DG_EVENTS");
+        v.dg_all = d && d[0] == '1';
+        const char* f = getenv("FAVAE_FUSE_MASK");
+        v.fuse = f ? (unsigned)strtoul(f, nullptr, 0) : 0x3bu;   // 4 (thin-input path) measured slower: the prefetch costs occupancy
+    }
     if (v.overlap) {
         bool ok = hipStreamCreateWithFlags(&v.side, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&v.side2, hipStreamNonBlocking) == hipSuccess;
+        for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_wg[l], hipEventDisableTiming) == hipSuccess;
         for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_fork[l], hipEventDisableTiming) == hipSuccess;
+        for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_dg[l], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&v.ev_join, hipEventDisableTiming) == hipSuccess;
         if (!ok) {
             delete h;
@@ -409,7 +450,9 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
 extern "C" int favae_vae_destroy(favae_vae* h) {
     if (h && h->v.overlap && h->v.side) {
         (void)hipStreamSynchronize(h->v.side);
-        for (int l = 0; l < NL; ++l) (void)hipEventDestroy(h->v.ev_fork[l]);
+        (void)hipStreamSynchronize(h->v.side2);
+        for (int l = 0; l < NL; ++l) { (void)hipEventDestroy(h->v.ev_fork[l]); (void)hipEventDestroy(h->v.ev_dg[l]); (void)hipEventDestroy(h->v.ev_wg[l]); }
+        (void)hipStreamDestroy(h->v.side2);
         (void)hipEventDestroy(h->v.ev_join);
         (void)hipStreamDestroy(h->v.side);
     }
@@ -441,45 +484,79 @@ extern "C" int favae_vae_train_fwdbwd(favae_vae* h, const float* data_nhwc, cons
     FAVAE_CHECK_ARG(h && data_nhwc && eps && metrics2_out, "favae_vae_train_fwdbwd: null pointer");
     Vae& v = h->v;
     FAVAE_CHECK_ARG(B >= 1 && B <= v.Bmax, "favae_vae_train_fwdbwd: batch %d outside [1, %d]", B, v.Bmax);
-    FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));
+    const bool epoch = v.overlap && v.ada.on && v.ada.epoch;
+    if (!epoch) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));
     FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, (hipStream_t)st));
+    if (epoch) { std::swap(v.xf, v.xf_alt); std::swap(v.xt, v.xt_alt); }
     RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, v.xf, v.xt, v.dtype, st));
+    if (v.join_pending) {   // the previous step's weight gradients / updates, still running next to the two launches above
+        FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_join, 0));
+        v.join_pending = false;
+    }
     RC(encoder_fwd(v, B, true, st, true));
     RC(favae_reparam_kl_fwd(v.raw[L_FC], eps, prior, idx, tau, B, v.z, v.zlat, v.stdq, metrics2_out + 1, v.dtype, st));
     RC(decoder_fwd(v, B, true, st, true));
     const long long D = (long long)64 * 64 * v.ch;
-    RC(favae_sigmoid_ll(v.raw[L_OUT], v.xf, B, D, var_x, v.draw[L_OUT], metrics2_out, v.scratch, v.scratch_doubles, v.dtype, st));
+    if (v.fuse & 8u) {
+        RC(favae_sigmoid_ll_bias(v.raw[L_OUT], v.xf, B, D, v.ch, var_x, v.draw[L_OUT], metrics2_out, v.G + v.L[L_OUT].b_off, v.scratch,
+                                 v.scratch_doubles, v.dtype, st));
+    } else {
+        RC(favae_sigmoid_ll(v.raw[L_OUT], v.xf, B, D, var_x, v.draw[L_OUT], metrics2_out, v.scratch, v.scratch_doubles, v.dtype, st));
+        RC(favae_colsum(v.draw[L_OUT], v.rows(L_OUT, B), v.ch, v.G + v.L[L_OUT].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
+    }
     // ---- backward ----
-    RC(favae_colsum(v.draw[L_OUT], v.rows(L_OUT, B), v.ch, v.G + v.L[L_OUT].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
     RC(wgrad(v, L_OUT, v.act[11], B, st));
     RC(dgrad(v, L_OUT, v.dact[11], B, st, v.dact_pooled[11], v.dact_bf[11], 11));
+    RC(after_dgrad(v, L_OUT, st));
     for (int l = 11; l >= 7; --l) {
         RC(bn_bwd(v, l, B, st));
         RC(wgrad(v, l, v.act[l - 1], B, st));
         RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1], v.dact_bf[l - 1], l > 7 ? l - 1 : -1));
+        RC(after_dgrad(v, l, st));
     }
-    RC(favae_cast(v.dact[L_DI], v.draw[L_DI], (long long)B * 4096, v.dtype, st));
-    RC(favae_colsum(v.draw[L_DI], B, 4096, v.G + v.L[L_DI].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
+    if (v.fuse & 32u) {
+        RC(favae_colsum_cast(v.dact[L_DI], v.draw[L_DI], B, 4096, v.G + v.L[L_DI].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
+    } else {
+        RC(favae_cast(v.dact[L_DI], v.draw[L_DI], (long long)B * 4096, v.dtype, st));
+        RC(favae_colsum(v.draw[L_DI], B, 4096, v.G + v.L[L_DI].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
+    }
     RC(wgrad(v, L_DI, v.zlat, B, st));
     RC(dgrad(v, L_DI, v.dz, B, st, true));
-    RC(favae_reparam_kl_bwd(v.raw[L_FC], eps, prior, idx, v.stdq, v.dz, tau, beta, B, v.z, v.draw[L_FC], v.dtype, st));
-    RC(favae_colsum(v.draw[L_FC], B, 2 * v.z, v.G + v.L[L_FC].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
+    RC(after_dgrad(v, L_DI, st));
+    if ((v.fuse & 16u) && 2 * v.z <= 256 && (long long)B * 2 * v.z <= 8192) {
+        RC(favae_reparam_kl_bwd_bias(v.raw[L_FC], eps, prior, idx, v.stdq, v.dz, tau, beta, B, v.z, v.draw[L_FC],
+                                     v.G + v.L[L_FC].b_off, v.dtype, st));
+    } else {
+        RC(favae_reparam_kl_bwd(v.raw[L_FC], eps, prior, idx, v.stdq, v.dz, tau, beta, B, v.z, v.draw[L_FC], v.dtype, st));
+        RC(favae_colsum(v.draw[L_FC], B, 2 * v.z, v.G + v.L[L_FC].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
+    }
     RC(wgrad(v, L_FC, v.act[4], B, st));
     RC(dgrad(v, L_FC, v.dact[4], B, st, v.dact_pooled[4]));
+    RC(after_dgrad(v, L_FC, st));
     for (int l = 4; l >= 1; --l) {
         RC(bn_bwd(v, l, B, st));
         RC(wgrad(v, l, v.act[l - 1], B, st));
         RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1], v.dact_bf[l - 1], l - 1));
+        RC(after_dgrad(v, l, st));
     }
     RC(bn_bwd(v, 0, B, st));
     RC(wgrad(v, 0, v.xt, B, st));
     if (v.overlap) {
-        if (v.ada.on && v.ada.pending >= 0) {
-            RC(adam_layer(v, v.ada.pending, (void*)v.side));   // encoder.0: no input gradient reads its shadows
+        if (v.ada.on) {   // encoder.0: no input gradient reads its shadows
+            if (v.ada.pending >= 0 && v.ada.pending != 0) {
+                FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[v.ada.pending], 0));
+                RC(adam_layer(v, v.ada.pending, (void*)v.side2));
+            }
+            FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[0], 0));
+            RC(adam_layer(v, 0, (void*)v.side2));
             v.ada.pending = -1;
+            // every weight gradient of the side stream is awaited by the update of its layer, so side2 ends the step
+            FAVAE_HIP(hipEventRecord(v.ev_join, v.side2));
+        } else {
+            FAVAE_HIP(hipEventRecord(v.ev_join, v.side));
         }
-        FAVAE_HIP(hipEventRecord(v.ev_join, v.side));
-        FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_join, 0));
+        if (epoch) v.join_pending = true;   // favae_vae_train_epoch joins before the next forward pass / at its end
+        else FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_join, 0));
     }
     return FAVAE_OK;
 }
@@ -500,12 +577,18 @@ extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const
     FAVAE_CHECK_ARG(h && perm && metrics && n >= 1 && batch >= 1, "favae_vae_train_epoch: bad argument");
     Vae& v = h->v;
     long long s = 0;
+    if (v.overlap) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));   // the steps keep it cleared
     for (long long o = 0; o < n; o += batch, ++s) {
         const int B = (int)std::min<long long>(batch, n - o);
         if (v.overlap) {   // optimiser step layer by layer behind the weight gradients (same arithmetic, see adam_layer)
-            v.ada = {true, lr, 0.9f, 0.999f, 1e-8f, step0 + s + 1, -1};
+            v.ada = {true, lr, 0.9f, 0.999f, 1e-8f, step0 + s + 1, -1, true};
             const int rc = favae_vae_train_fwdbwd(h, data_nhwc, perm + o, B, eps + o * v.z, prior, tau, beta, var_x, metrics + 2 * s, st);
             v.ada.on = false;
+            v.ada.epoch = false;
+            if (rc != FAVAE_OK || o + batch >= n) {   // last step (or failure): the caller's stream waits for the side stream
+                if (v.join_pending) (void)hipStreamWaitEvent((hipStream_t)st, v.ev_join, 0);
+                v.join_pending = false;
+            }
             RC(rc);
         } else {
             RC(favae_vae_train_fwdbwd(h, data_nhwc, perm + o, B, eps + o * v.z, prior, tau, beta, var_x, metrics + 2 * s, st));

@@ -118,6 +118,9 @@ int favae_bn_lrelu_bwd_bins(const float* dact, const void* act, const float* raw
 /* out[c] = sum_r x[r][c]  (bias gradients of layers without BN). */
 int favae_colsum(const void* x, long long R, int C, float* out, double* scratch, size_t scratch_doubles, int dtype,
                  void* stream);
+/* favae_colsum of an fp32 matrix x that is stored as dtype into y on the way (y = x when dtype is fp32). */
+int favae_colsum_cast(const float* x, void* y, long long R, int C, float* out, double* scratch, size_t scratch_doubles,
+                      int dtype, void* stream);
 /* Fused reparameterisation + KL against the FA prior (:86-92 encoder head, :89-92 reparameterize, :137-150 kl_div,
  * :231-232 prior std).  fc [B][2z] = (mu | log_var_raw); eps [B][z]; prior [N][z] fp64 rows selected by idx[b]
  * (NULL prior = N(0,I), :213-214; NULL idx = identity); tau as the fp32 the reference casts it to (:210).
@@ -127,12 +130,21 @@ int favae_reparam_kl_fwd(const float* fc, const float* eps, const double* prior,
 /* Gradient of (rec + beta*KL) w.r.t. fc given dz = d rec / d zlat; dfc [B][2z] (dtype). */
 int favae_reparam_kl_bwd(const float* fc, const float* eps, const double* prior, const int* idx, const float* stdq,
                          const float* dz, float tau, float beta, int B, int z, void* dfc, int dtype, void* stream);
+/* favae_reparam_kl_bwd that also sums the columns of dfc: dbias [2z] = bias gradient of fc_mu | fc_var (z <= 128, B * 2z <= 8192). */
+int favae_reparam_kl_bwd_bias(const float* fc, const float* eps, const double* prior, const int* idx, const float* stdq,
+                              const float* dz, float tau, float beta, int B, int z, void* dfc, float* dbias, int dtype,
+                              void* stream);
 /* update_x head (:348-354): X.mean = mu, X.cov = std^2 as float64 rows. */
 int favae_encode_head(const float* fc, int B, int z, double* xmean, double* xcov, void* stream);
 /* Sigmoid (:77) + -mean_b gaussian_LL (:152-171) + gradient w.r.t. the pre-sigmoid output (dtype).
  * raw, x: [B][D] fp32; *rec_err (fp64) = reconstruction_error of :238. scratch >= 1024 doubles. */
 int favae_sigmoid_ll(const float* raw, const float* x, int B, long long D, float var_x, void* draw, double* rec_err,
                      double* scratch, size_t scratch_doubles, int dtype, void* stream);
+/* favae_sigmoid_ll in one launch that also returns the bias gradient of the output conv: dbias[c] = sum over pixels of
+ * the gradient written to draw, for C <= 4 interleaved channels (D = pixels * C per sample); dbias may be NULL.
+ * scratch >= 5 * 1024 doubles. */
+int favae_sigmoid_ll_bias(const float* raw, const float* x, int B, long long D, int C, float var_x, void* draw,
+                          double* rec_err, float* dbias, double* scratch, size_t scratch_doubles, int dtype, void* stream);
 int favae_sigmoid(const float* raw, float* out, long long n, void* stream);
 /* acc3 += (sum (y - sigmoid(raw))^2, sum y, sum y^2). scratch >= 3*1024 doubles. */
 int favae_sigmoid_sse(const float* raw, const float* y, long long n, double* acc3, double* scratch, size_t scratch_doubles,
@@ -140,6 +152,10 @@ int favae_sigmoid_sse(const float* raw, const float* y, long long n, double* acc
 /* torch.optim.Adam step (defaults, no weight decay; :131,250) over a flat fp32 arena of n (multiple of 4) floats. */
 int favae_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                     float eps, long long step, void* stream);
+/* The same step, and the gradient arena is cleared behind it: optim.step() (:250) fused with the optim.zero_grad() (:246)
+ * of the iteration that follows, so that an epoch of steps needs no memset of the gradients. */
+int favae_adam_step_clear(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                          float eps, long long step, void* stream);
 /* master fp32 [Co][taps][Ci] -> dtype copy (same layout, may be NULL) and dtype transpose [Ci][taps][Co] (may be NULL). */
 /* The same for n weight tensors in one launch (host arrays of device pointers / shapes; n <= 16). */
 int favae_weight_prep_batch(int n, const float* const* w, void* const* w_copy, void* const* w_transposed, const int* Co,

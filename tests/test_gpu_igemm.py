@@ -289,3 +289,30 @@ def test_epilogue_sums_feed_batchnorm_backward(dt, tol, kind, Nb, Cin, Cout, H):
     assert_close(dg1.cpu(), dg0.cpu(), 1e-6)
     assert_close(db1.cpu(), db0.cpu(), 1e-6)
     assert_close(draw1.float().cpu(), draw0.float().cpu(), 1e-6 if dt == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("dt,tol", DT)
+def test_thin_input_gradient_takes_batchnorm_backward_sums(dt, tol):
+    """Input gradient of final_layer.3 (3 -> 64 channels, one thread per pixel) with the BN-backward sums of the layer
+    before it taken while the result is stored (favae_conv_igemm_red mode 2 on the thin-input path)."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(77)
+    Nb, H, C = 40, 64, 64          # >= 131072 pixels: the thin-input kernel
+    dy = q(torch.randn(Nb, H, H, 3, generator=g), dt)
+    wt = q(torch.randn(C, 9, 3, generator=g) * 0.1, dt)
+    R = Nb * H * H
+    raw = (torch.randn(R, C, generator=g) * 2 + 0.3).cuda()
+    act = torch.nn.functional.leaky_relu(torch.randn(R, C, generator=g), 0.01).to(dt).cuda()
+    mean, invstd = torch.randn(C, generator=g).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    dyd, wtd = dy.to(dt).cuda(), wt.to(dt).cuda()
+    out0 = torch.empty(Nb, H, H, C, device="cuda")
+    lib.conv_igemm(dyd, wtd, None, out0, 3, 1, 1, 1, 0)
+    bins = torch.zeros(32, 2, C, dtype=torch.float64, device="cuda")
+    out1 = torch.empty_like(out0)
+    assert lib.conv_igemm_red(dyd, wtd, None, out1, 3, 1, 1, 1, bins, 2, act=act, raw=raw, mean=mean, invstd=invstd)
+    assert torch.equal(out1, out0)
+    dd = out0.view(R, C).double() * torch.where(act.double() > 0, 1.0, 0.01)
+    xh = ((raw - mean) * invstd).double()      # fp32 arithmetic as in the kernel
+    tot = bins.sum(0)
+    assert_close(tot[0].cpu(), dd.sum(0).cpu(), 1e-7)
+    assert_close(tot[1].cpu(), (dd * xh).sum(0).cpu(), 1e-6)

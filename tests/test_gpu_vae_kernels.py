@@ -101,6 +101,26 @@ def test_reparam_kl_forward_backward(with_prior):
     L.check(raw_.favae_reparam_kl_bwd(L.ptr(fcd), L.ptr(epsd), L.ptr(pd), L.ptr(idd), L.ptr(stdq), L.ptr(dzd), f_(tau), f_(beta),
                                       i_(B), i_(z), L.ptr(dfc), i_(0), L.stream_ptr()))
     assert _err(dfc, fc.grad) < 1e-5
+    # one-block form that also returns the bias gradient of the encoder head (column sums of dfc)
+    dfc2, dbias = torch.zeros(B, 2 * z, device=dev), torch.zeros(2 * z, device=dev)
+    L.check(raw_.favae_reparam_kl_bwd_bias(L.ptr(fcd), L.ptr(epsd), L.ptr(pd), L.ptr(idd), L.ptr(stdq), L.ptr(dzd), f_(tau), f_(beta),
+                                           i_(B), i_(z), L.ptr(dfc2), L.ptr(dbias), i_(0), L.stream_ptr()))
+    assert _err(dfc2, dfc) < 1e-6
+    assert _err(dbias, fc.grad.sum(0)) < 1e-5
+
+
+def test_colsum_cast():
+    L = _L()
+    raw_ = L.raw()
+    for R, C, dt in [(64, 4096, torch.bfloat16), (64, 4096, torch.float32), (1000, 40, torch.bfloat16)]:
+        x = torch.randn(R, C, generator=torch.Generator().manual_seed(R + C)).cuda()
+        y = torch.zeros(R, C, dtype=dt, device="cuda")
+        out = torch.zeros(C, device="cuda")
+        scratch = torch.zeros(2 * 1024 * 64 + 4096, dtype=torch.float64, device="cuda")
+        L.check(raw_.favae_colsum_cast(L.ptr(x), L.ptr(y), ll_(R), i_(C), L.ptr(out), L.ptr(scratch), sz_(scratch.numel()),
+                                       i_(0 if dt == torch.float32 else 1), L.stream_ptr()))
+        assert torch.equal(y, x.to(dt))
+        assert _err(out, x.double().sum(0)) < 1e-6
 
 
 def test_sigmoid_ll_and_gradient():
@@ -121,6 +141,15 @@ def test_sigmoid_ll_and_gradient():
                                   L.ptr(scratch), sz_(scratch.numel()), i_(0), L.stream_ptr()))
     assert abs(rec.item() + ll.item()) < 1e-6 * abs(ll.item())
     assert _err(draw, r.grad) < 1e-5
+    # one-launch form with the bias gradient of the 3-channel output conv (pixels x 3 interleaved)
+    for reps in range(2):   # twice: the ticket slot must be left clean
+        draw2, rec2, dbias = torch.zeros(B, D, device=dev), torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(3, device=dev)
+        scratch2 = torch.zeros(5 * 1024, dtype=torch.float64, device=dev)
+        L.check(raw_.favae_sigmoid_ll_bias(L.ptr(rd), L.ptr(xd), i_(B), ll_(D), i_(3), f_(0.01), L.ptr(draw2), L.ptr(rec2), L.ptr(dbias),
+                                           L.ptr(scratch2), sz_(scratch2.numel()), i_(0), L.stream_ptr()))
+        assert abs(rec2.item() + ll.item()) < 1e-6 * abs(ll.item())
+        assert torch.equal(draw2, draw)
+        assert _err(dbias, r.grad.view(B, D // 3, 3).sum((0, 1))) < 1e-5
 
 
 def test_adam_matches_torch_optim():
