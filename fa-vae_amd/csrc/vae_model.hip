@@ -96,6 +96,7 @@ struct Vae {
     // main stream joins the side stream only when the next step's forward pass is about to read the weights
     struct { bool on; float lr, b1, b2, eps; long long step; int pending; bool epoch; } ada;
     bool join_pending; bool dg_all;
+    hipEvent_t ev_fence[2]; bool ev_fence_ok;
     unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast
     float* xf_alt; char* xt_alt;   // second batch buffer: the next gather must not overwrite what wgrad(encoder.0) still reads
     const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(SH + L[l].wc_off * esz); }
@@ -424,6 +425,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.side2 = nullptr;
     v.ada = {false, 0.f, 0.f, 0.f, 0.f, 0, -1, false};
     v.join_pending = false;
+    v.ev_fence_ok = false;
     {
         const char* d = getenv("FAVAE_DG_EVENTS");
         v.dg_all = d && d[0] == '1';
@@ -448,6 +450,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
 }
 
 extern "C" int favae_vae_destroy(favae_vae* h) {
+    if (h && h->v.ev_fence_ok) { (void)hipEventDestroy(h->v.ev_fence[0]); (void)hipEventDestroy(h->v.ev_fence[1]); }
     if (h && h->v.overlap && h->v.side) {
         (void)hipStreamSynchronize(h->v.side);
         (void)hipStreamSynchronize(h->v.side2);
@@ -477,71 +480,80 @@ extern "C" int favae_vae_refresh_weights(favae_vae* h, void* st) {
     return n ? favae_weight_prep_batch(n, w, wc, wt, Co, taps, Ci, v.dtype, st) : FAVAE_OK;
 }
 
-/* One forward + backward of the training step (cA/celeba_deepvanilla_vae.py:229-249): gradients land in the grads
- * arena; metrics2_out (device, 2 doubles) receives (reconstruction_error, kl_div).  No optimiser step. */
-extern "C" int favae_vae_train_fwdbwd(favae_vae* h, const float* data_nhwc, const int* idx, int B, const float* eps,
-                                      const double* prior, float tau, float beta, float var_x, double* metrics2_out, void* st) {
-    FAVAE_CHECK_ARG(h && data_nhwc && eps && metrics2_out, "favae_vae_train_fwdbwd: null pointer");
-    Vae& v = h->v;
-    FAVAE_CHECK_ARG(B >= 1 && B <= v.Bmax, "favae_vae_train_fwdbwd: batch %d outside [1, %d]", B, v.Bmax);
+namespace {
+// Backward stages in execution order: 0 final conv, 1-5 final_layer.0 / dec.3..dec.0, 6 decoder_input, 7 fc_mu|fc_var,
+// 8-12 enc.4..enc.0.  A training step = forward (with stage_lo == 0) + stages [stage_lo, stage_hi) + the join of the
+// side streams (with stage_hi == N_STAGES).
+constexpr int N_STAGES = 13;
+
+int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const float* eps, const double* prior, float tau,
+                 float beta, float var_x, double* metrics2_out, int stage_lo, int stage_hi, void* st) {
     const bool epoch = v.overlap && v.ada.on && v.ada.epoch;
-    if (!epoch) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));
-    FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, (hipStream_t)st));
-    if (epoch) { std::swap(v.xf, v.xf_alt); std::swap(v.xt, v.xt_alt); }
-    RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, v.xf, v.xt, v.dtype, st));
-    if (v.join_pending) {   // the previous step's weight gradients / updates, still running next to the two launches above
-        FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_join, 0));
-        v.join_pending = false;
+    if (stage_lo == 0) {
+        if (!epoch) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));
+        FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, (hipStream_t)st));
+        if (epoch) { std::swap(v.xf, v.xf_alt); std::swap(v.xt, v.xt_alt); }
+        RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, v.xf, v.xt, v.dtype, st));
+        if (v.join_pending) {   // the previous step's weight gradients / updates, still running next to the two launches above
+            FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_join, 0));
+            v.join_pending = false;
+        }
+        RC(encoder_fwd(v, B, true, st, true));
+        RC(favae_reparam_kl_fwd(v.raw[L_FC], eps, prior, idx, tau, B, v.z, v.zlat, v.stdq, metrics2_out + 1, v.dtype, st));
+        RC(decoder_fwd(v, B, true, st, true));
+        const long long D = (long long)64 * 64 * v.ch;
+        if (v.fuse & 8u) {
+            RC(favae_sigmoid_ll_bias(v.raw[L_OUT], v.xf, B, D, v.ch, var_x, v.draw[L_OUT], metrics2_out, v.G + v.L[L_OUT].b_off, v.scratch,
+                                     v.scratch_doubles, v.dtype, st));
+        } else {
+            RC(favae_sigmoid_ll(v.raw[L_OUT], v.xf, B, D, var_x, v.draw[L_OUT], metrics2_out, v.scratch, v.scratch_doubles, v.dtype, st));
+            RC(favae_colsum(v.draw[L_OUT], v.rows(L_OUT, B), v.ch, v.G + v.L[L_OUT].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
+        }
     }
-    RC(encoder_fwd(v, B, true, st, true));
-    RC(favae_reparam_kl_fwd(v.raw[L_FC], eps, prior, idx, tau, B, v.z, v.zlat, v.stdq, metrics2_out + 1, v.dtype, st));
-    RC(decoder_fwd(v, B, true, st, true));
-    const long long D = (long long)64 * 64 * v.ch;
-    if (v.fuse & 8u) {
-        RC(favae_sigmoid_ll_bias(v.raw[L_OUT], v.xf, B, D, v.ch, var_x, v.draw[L_OUT], metrics2_out, v.G + v.L[L_OUT].b_off, v.scratch,
-                                 v.scratch_doubles, v.dtype, st));
-    } else {
-        RC(favae_sigmoid_ll(v.raw[L_OUT], v.xf, B, D, var_x, v.draw[L_OUT], metrics2_out, v.scratch, v.scratch_doubles, v.dtype, st));
-        RC(favae_colsum(v.draw[L_OUT], v.rows(L_OUT, B), v.ch, v.G + v.L[L_OUT].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
+    for (int sg = stage_lo; sg < stage_hi; ++sg) {
+        if (sg == 0) {
+            RC(wgrad(v, L_OUT, v.act[11], B, st));
+            RC(dgrad(v, L_OUT, v.dact[11], B, st, v.dact_pooled[11], v.dact_bf[11], 11));
+            RC(after_dgrad(v, L_OUT, st));
+        } else if (sg <= 5) {
+            const int l = 12 - sg;   // 11 .. 7
+            RC(bn_bwd(v, l, B, st));
+            RC(wgrad(v, l, v.act[l - 1], B, st));
+            RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1], v.dact_bf[l - 1], l > 7 ? l - 1 : -1));
+            RC(after_dgrad(v, l, st));
+        } else if (sg == 6) {
+            if (v.fuse & 32u) {
+                RC(favae_colsum_cast(v.dact[L_DI], v.draw[L_DI], B, 4096, v.G + v.L[L_DI].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
+            } else {
+                RC(favae_cast(v.dact[L_DI], v.draw[L_DI], (long long)B * 4096, v.dtype, st));
+                RC(favae_colsum(v.draw[L_DI], B, 4096, v.G + v.L[L_DI].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
+            }
+            RC(wgrad(v, L_DI, v.zlat, B, st));
+            RC(dgrad(v, L_DI, v.dz, B, st, true));
+            RC(after_dgrad(v, L_DI, st));
+        } else if (sg == 7) {
+            if ((v.fuse & 16u) && 2 * v.z <= 256 && (long long)B * 2 * v.z <= 8192) {
+                RC(favae_reparam_kl_bwd_bias(v.raw[L_FC], eps, prior, idx, v.stdq, v.dz, tau, beta, B, v.z, v.draw[L_FC],
+                                             v.G + v.L[L_FC].b_off, v.dtype, st));
+            } else {
+                RC(favae_reparam_kl_bwd(v.raw[L_FC], eps, prior, idx, v.stdq, v.dz, tau, beta, B, v.z, v.draw[L_FC], v.dtype, st));
+                RC(favae_colsum(v.draw[L_FC], B, 2 * v.z, v.G + v.L[L_FC].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
+            }
+            RC(wgrad(v, L_FC, v.act[4], B, st));
+            RC(dgrad(v, L_FC, v.dact[4], B, st, v.dact_pooled[4]));
+            RC(after_dgrad(v, L_FC, st));
+        } else if (sg <= 11) {
+            const int l = 12 - sg;   // 4 .. 1
+            RC(bn_bwd(v, l, B, st));
+            RC(wgrad(v, l, v.act[l - 1], B, st));
+            RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1], v.dact_bf[l - 1], l - 1));
+            RC(after_dgrad(v, l, st));
+        } else {
+            RC(bn_bwd(v, 0, B, st));
+            RC(wgrad(v, 0, v.xt, B, st));
+        }
     }
-    // ---- backward ----
-    RC(wgrad(v, L_OUT, v.act[11], B, st));
-    RC(dgrad(v, L_OUT, v.dact[11], B, st, v.dact_pooled[11], v.dact_bf[11], 11));
-    RC(after_dgrad(v, L_OUT, st));
-    for (int l = 11; l >= 7; --l) {
-        RC(bn_bwd(v, l, B, st));
-        RC(wgrad(v, l, v.act[l - 1], B, st));
-        RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1], v.dact_bf[l - 1], l > 7 ? l - 1 : -1));
-        RC(after_dgrad(v, l, st));
-    }
-    if (v.fuse & 32u) {
-        RC(favae_colsum_cast(v.dact[L_DI], v.draw[L_DI], B, 4096, v.G + v.L[L_DI].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
-    } else {
-        RC(favae_cast(v.dact[L_DI], v.draw[L_DI], (long long)B * 4096, v.dtype, st));
-        RC(favae_colsum(v.draw[L_DI], B, 4096, v.G + v.L[L_DI].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
-    }
-    RC(wgrad(v, L_DI, v.zlat, B, st));
-    RC(dgrad(v, L_DI, v.dz, B, st, true));
-    RC(after_dgrad(v, L_DI, st));
-    if ((v.fuse & 16u) && 2 * v.z <= 256 && (long long)B * 2 * v.z <= 8192) {
-        RC(favae_reparam_kl_bwd_bias(v.raw[L_FC], eps, prior, idx, v.stdq, v.dz, tau, beta, B, v.z, v.draw[L_FC],
-                                     v.G + v.L[L_FC].b_off, v.dtype, st));
-    } else {
-        RC(favae_reparam_kl_bwd(v.raw[L_FC], eps, prior, idx, v.stdq, v.dz, tau, beta, B, v.z, v.draw[L_FC], v.dtype, st));
-        RC(favae_colsum(v.draw[L_FC], B, 2 * v.z, v.G + v.L[L_FC].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
-    }
-    RC(wgrad(v, L_FC, v.act[4], B, st));
-    RC(dgrad(v, L_FC, v.dact[4], B, st, v.dact_pooled[4]));
-    RC(after_dgrad(v, L_FC, st));
-    for (int l = 4; l >= 1; --l) {
-        RC(bn_bwd(v, l, B, st));
-        RC(wgrad(v, l, v.act[l - 1], B, st));
-        RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1], v.dact_bf[l - 1], l - 1));
-        RC(after_dgrad(v, l, st));
-    }
-    RC(bn_bwd(v, 0, B, st));
-    RC(wgrad(v, 0, v.xt, B, st));
-    if (v.overlap) {
+    if (stage_hi == N_STAGES && v.overlap) {
         if (v.ada.on) {   // encoder.0: no input gradient reads its shadows
             if (v.ada.pending >= 0 && v.ada.pending != 0) {
                 FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[v.ada.pending], 0));
@@ -557,6 +569,52 @@ extern "C" int favae_vae_train_fwdbwd(favae_vae* h, const float* data_nhwc, cons
         }
         if (epoch) v.join_pending = true;   // favae_vae_train_epoch joins before the next forward pass / at its end
         else FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_join, 0));
+    }
+    return FAVAE_OK;
+}
+}  // namespace
+
+/* One forward + backward of the training step (cA/celeba_deepvanilla_vae.py:229-249): gradients land in the grads
+ * arena; metrics2_out (device, 2 doubles) receives (reconstruction_error, kl_div).  No optimiser step. */
+extern "C" int favae_vae_train_fwdbwd(favae_vae* h, const float* data_nhwc, const int* idx, int B, const float* eps,
+                                      const double* prior, float tau, float beta, float var_x, double* metrics2_out, void* st) {
+    FAVAE_CHECK_ARG(h && data_nhwc && eps && metrics2_out, "favae_vae_train_fwdbwd: null pointer");
+    Vae& v = h->v;
+    FAVAE_CHECK_ARG(B >= 1 && B <= v.Bmax, "favae_vae_train_fwdbwd: batch %d outside [1, %d]", B, v.Bmax);
+    return train_stages(v, data_nhwc, idx, B, eps, prior, tau, beta, var_x, metrics2_out, 0, N_STAGES, st);
+}
+
+/* The same step in pieces, for data-parallel training that all-reduces gradient buckets while later layers are still in
+ * their backward pass (RCCL over xGMI next to the kernels): stage_lo == 0 runs the forward pass first; backward stages
+ * [stage_lo, stage_hi) follow (0 final conv, 1-5 final_layer.0 / dec.3..dec.0, 6 decoder_input, 7 fc_mu|fc_var,
+ * 8-12 enc.4..enc.0; the gradients of a stage's layer are complete once favae_vae_fence has ordered a stream behind
+ * it); stage_hi == 13 ends the step (the caller's stream then waits for the weight-gradient stream).  Call with the same
+ * arguments and ascending, gap-free stage ranges. */
+extern "C" int favae_vae_train_stages(favae_vae* h, const float* data_nhwc, const int* idx, int B, const float* eps,
+                                      const double* prior, float tau, float beta, float var_x, double* metrics2_out,
+                                      int stage_lo, int stage_hi, void* st) {
+    FAVAE_CHECK_ARG(h && data_nhwc && eps && metrics2_out, "favae_vae_train_stages: null pointer");
+    Vae& v = h->v;
+    FAVAE_CHECK_ARG(B >= 1 && B <= v.Bmax, "favae_vae_train_stages: batch %d outside [1, %d]", B, v.Bmax);
+    FAVAE_CHECK_ARG(stage_lo >= 0 && stage_lo <= stage_hi && stage_hi <= N_STAGES, "favae_vae_train_stages: stages [%d, %d)", stage_lo, stage_hi);
+    return train_stages(v, data_nhwc, idx, B, eps, prior, tau, beta, var_x, metrics2_out, stage_lo, stage_hi, st);
+}
+
+/* Orders `waiting` behind everything queued so far on `st` (the stream the step is issued on) and on the internal
+ * weight-gradient stream, without blocking either: the collective of a gradient bucket is enqueued on `waiting`. */
+extern "C" int favae_vae_fence(favae_vae* h, void* st, void* waiting) {
+    FAVAE_CHECK_ARG(h && waiting, "favae_vae_fence: null pointer");
+    Vae& v = h->v;
+    if (!v.ev_fence_ok) {
+        FAVAE_HIP(hipEventCreateWithFlags(&v.ev_fence[0], hipEventDisableTiming));
+        FAVAE_HIP(hipEventCreateWithFlags(&v.ev_fence[1], hipEventDisableTiming));
+        v.ev_fence_ok = true;
+    }
+    FAVAE_HIP(hipEventRecord(v.ev_fence[0], (hipStream_t)st));
+    FAVAE_HIP(hipStreamWaitEvent((hipStream_t)waiting, v.ev_fence[0], 0));
+    if (v.overlap) {
+        FAVAE_HIP(hipEventRecord(v.ev_fence[1], v.side));
+        FAVAE_HIP(hipStreamWaitEvent((hipStream_t)waiting, v.ev_fence[1], 0));
     }
     return FAVAE_OK;
 }

@@ -5,8 +5,15 @@ import torch
 import torch.distributed as td
 
 
+import os
+
+
 def active():
-    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+    # FAVAE_FORCE_DP=1: take the multi-rank code path in a one-rank group as well (rehearsal of the RCCL stream logic on
+    # one GPU, tools/dp_rehearsal.py)
+    if not (td.is_available() and td.is_initialized()):
+        return False
+    return td.get_world_size() > 1 or os.environ.get("FAVAE_FORCE_DP") == "1"
 
 
 def world_size():
@@ -43,6 +50,21 @@ def mean_(t):
         else:
             _staged(t, lambda x: (td.all_reduce(x, op=td.ReduceOp.SUM), x.div_(td.get_world_size())))
     return t
+
+
+def mean_async(t, engine, comm_stream):
+    """Mean over ranks of a gradient bucket whose producers (main + weight-gradient stream of `engine`) may still be running:
+    RCCL: the all-reduce is enqueued behind them on `comm_stream` and returns a work handle (wait() orders the current
+    stream behind it); other backends: blocking, staged through the host, returns None."""
+    if not active():
+        return None
+    if td.get_backend() == "nccl":
+        engine.fence(comm_stream)
+        with torch.cuda.stream(comm_stream):
+            return td.all_reduce(t, op=td.ReduceOp.AVG, async_op=True)
+    engine.fence(torch.cuda.current_stream())
+    _staged(t, lambda x: (td.all_reduce(x, op=td.ReduceOp.SUM), x.div_(td.get_world_size())))
+    return None
 
 
 def broadcast_(t, src=0):

@@ -215,6 +215,24 @@ class VaeEngine:
                                             _f(beta), _f(var_x), L.ptr(m), L.stream_ptr()))
         return m
 
+    N_STAGES = 13
+
+    def train_stages(self, data, idx, B, eps, prior, tau, beta, var_x, metrics, lo, hi):
+        """The step of train_fwdbwd in pieces (favae_vae_train_stages): forward with lo == 0, backward stages [lo, hi)."""
+        L.check(_raw.favae_vae_train_stages(self.h, L.ptr(data), L.ptr(idx), _i(B), L.ptr(eps), L.ptr(prior), _f(tau),
+                                            _f(beta), _f(var_x), L.ptr(metrics), _i(lo), _i(hi), L.stream_ptr()))
+
+    def fence(self, waiting):
+        """Order torch stream `waiting` behind everything queued so far on the current and the weight-gradient stream."""
+        L.check(_raw.favae_vae_fence(self.h, L.stream_ptr(), ctypes.c_void_p(waiting.cuda_stream)))
+
+    def grad_buckets(self):
+        """(arena_lo, arena_hi, stage_hi): the gradient slice that is complete once backward stages < stage_hi have run.
+        Decoder first (its gradients are ready while the encoder is still in its backward pass), then enc.3-4 + heads,
+        then the small first encoder layers."""
+        w = [d["w"] for d in self.layers]
+        return [(w[6], self.nparam, 7), (w[3], w[6], 10), (0, w[3], self.N_STAGES)]
+
     def adam(self, lr):
         self.step += 1
         L.check(_raw.favae_vae_adam(self.h, _f(lr), _f(0.9), _f(0.999), _f(1e-8), _ll(self.step), L.stream_ptr()))

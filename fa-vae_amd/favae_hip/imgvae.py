@@ -259,11 +259,23 @@ class ImgVAE(VAE):
             else:
                 # data parallel over the N shards: every rank runs its own mini-batch of 64, gradients are averaged over
                 # RCCL before the (replicated) Adam step; BN batch statistics stay per rank (group size 64, as :218)
+                # The gradient arena is averaged in three buckets; the all-reduce of a bucket runs on a communication
+                # stream while the layers behind it are still in their backward pass (decoder bucket under the whole
+                # encoder backward).
+                if getattr(self, "_comm_stream", None) is None:
+                    self._comm_stream = torch.cuda.Stream(device=self.device)
+                buckets = e.grad_buckets()
                 for si, s in enumerate(range(0, n, self.BATCH)):
                     bsz = min(self.BATCH, n - s)
-                    e.train_fwdbwd(data, perm_d[s:s + bsz], bsz, eps_d[s:s + bsz], prior, tau_f, float(beta), float(self.var_x),
-                                   metrics[si])
-                    dist.mean_(e.G)
+                    works, lo = [], 0
+                    for a, b_, hi in buckets:
+                        e.train_stages(data, perm_d[s:s + bsz], bsz, eps_d[s:s + bsz], prior, tau_f, float(beta),
+                                       float(self.var_x), metrics[si], lo, hi)
+                        works.append(dist.mean_async(e.G[a:b_], e, self._comm_stream))
+                        lo = hi
+                    for w in works:
+                        if w is not None:
+                            w.wait()
                     e.adam(float(self.lr))
                 dist.mean_(metrics)
                 dist.mean_(e.BUF)

@@ -191,6 +191,17 @@ int favae_vae_refresh_weights(favae_vae* h, void* stream);
 /* forward + loss + backward of one mini-batch (:229-249); metrics2_out (device) = (reconstruction_error, kl_div). */
 int favae_vae_train_fwdbwd(favae_vae* h, const float* data_nhwc, const int* idx, int B, const float* eps,
                            const double* prior, float tau, float beta, float var_x, double* metrics2_out, void* stream);
+/* The same step in pieces, for data-parallel training that all-reduces gradient buckets (RCCL over xGMI) while later
+ * layers are still in their backward pass: stage_lo == 0 runs the forward pass first; backward stages
+ * [stage_lo, stage_hi) follow (0 final conv, 1-5 final_layer.0 / dec.3..dec.0, 6 decoder_input, 7 fc_mu|fc_var,
+ * 8-12 enc.4..enc.0); stage_hi == 13 ends the step.  Same arguments on every call of a step, ascending gap-free ranges.
+ * No reference counterpart (the reference is single-device; loss.backward() :249 is one call). */
+int favae_vae_train_stages(favae_vae* h, const float* data_nhwc, const int* idx, int B, const float* eps,
+                           const double* prior, float tau, float beta, float var_x, double* metrics2_out, int stage_lo,
+                           int stage_hi, void* stream);
+/* Orders stream `waiting` behind everything queued so far on `stream` and on the handle's weight-gradient stream (the
+ * gradients of the stages issued so far are complete for work enqueued on `waiting` afterwards).  Blocks nothing. */
+int favae_vae_fence(favae_vae* h, void* stream, void* waiting);
 /* optim.step() (:250) + weight re-layout. */
 int favae_vae_adam(favae_vae* h, float lr, float beta1, float beta2, float eps, long long step, void* stream);
 /* all mini-batches of one epoch (:227-255) on one device. perm [n], eps [n][z] in visiting order, metrics [steps][2]. */

@@ -102,6 +102,44 @@ def test_training_steps_match_oracle(dtype, tol_loss, tol_bulk, min_cos):
                 assert _rel(got[k].numpy(), Bf[k].numpy()) <= 1e-4, (step, k)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_staged_step_equals_the_whole_step(dtype):
+    """favae_vae_train_stages in the three pieces the data-parallel trainloop uses, with a fence before each gradient
+    bucket is read on another stream (as the RCCL all-reduce does), gives the gradients of favae_vae_train_fwdbwd.
+    Same kernels, same order; only split-K / binned atomics reorder sums, hence 1e-4 (fp32) / 5e-3 (bf16) of scale."""
+    z, Bn = 20, 64
+    torch.manual_seed(0)
+    P, Bf = vt.init_state(z, 3)
+    sd = {k: v.detach().clone() for k, v in P.items()}
+    sd.update({k: v.clone() for k, v in Bf.items()})
+    eng = _engine(z, dtype)
+    eng.load_state_dict(sd)
+    img, _ = img_inputs(Bn)
+    data = eng.upload_images(img)
+    idx = torch.arange(Bn, dtype=torch.int32, device="cuda")
+    eps = torch.randn(Bn, z, generator=torch.Generator().manual_seed(3)).cuda()
+    prior = torch.from_numpy(np.random.RandomState(7).randn(Bn, z) * 0.5).cuda()
+    m0 = eng.train_fwdbwd(data, idx, Bn, eps, prior, 1.7, 1.0, 0.01).clone()
+    g0 = eng.G.clone()
+    eng.load_state_dict(sd)                      # BN running statistics back to the start
+    other = torch.cuda.Stream()
+    m1 = torch.zeros(2, dtype=torch.float64, device="cuda")
+    got = torch.zeros_like(g0)
+    lo = 0
+    for a, b, hi in eng.grad_buckets():
+        eng.train_stages(data, idx, Bn, eps, prior, 1.7, 1.0, 0.01, m1, lo, hi)
+        eng.fence(other)
+        with torch.cuda.stream(other):
+            got[a:b].copy_(eng.G[a:b])           # what an all-reduce of this bucket would read
+        lo = hi
+    assert lo == eng.N_STAGES
+    torch.cuda.synchronize()
+    assert torch.allclose(m1, m0, rtol=1e-6, atol=0)
+    tol = 1e-4 if dtype == "f32" else 5e-3
+    assert _rel(got.cpu().numpy(), g0.cpu().numpy()) <= tol
+    assert _rel(eng.G.cpu().numpy(), g0.cpu().numpy()) <= tol
+
+
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("bf16", 2e-2)])
 def test_eval_encoder_and_decoder_match_oracle(dtype, tol):
     z, Bn = 8, 24
