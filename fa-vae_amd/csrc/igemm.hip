@@ -441,6 +441,7 @@ struct PmParams {
     float* dw;
     int Rc, Cc, r_large, c_large;
     int Nb, Hs, Ws, Hl, Wl, ks, stride, pad, splitk, ntn, K;
+    int Rst, Cst;   // rows / columns of dw that exist (<= Rc, Cc: operands padded to whole vectors, see favae_conv_wgrad_folded)
 };
 
 template <class T, int BM, int BN, int WM, int WN>
@@ -573,14 +574,14 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = r0 + wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row >= p.Rc) continue;
+            if (row >= p.Rst) continue;
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
                 const int col = c0 + wn * WTN + b * 32 + (lane & 31);
-                if (col < p.Cc) {
+                if (col < p.Cst) {
                     // one block per output element when the reduction is not split: add without an atomic (the
                     // gradient arena is zeroed per step; chip-wide float atomics run at ~1.3 TB/s, plain stores at 6)
-                    float* dst = p.dw + ((size_t)row * ntaps + tap) * p.Cc + col;
+                    float* dst = p.dw + ((size_t)row * ntaps + tap) * p.Cst + col;
                     if (p.splitk > 1) atomicAdd(dst, acc[a][b][r]); else *dst += acc[a][b][r];
                 }
             }
@@ -750,7 +751,48 @@ extern "C" int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const 
     PmParams p;
     p.rp = rows; p.cp = cols; p.dw = dw; p.Rc = Rc; p.Cc = Cc; p.r_large = rows_large; p.c_large = cols_large;
     p.Nb = Nb; p.Hs = Hs; p.Ws = Ws; p.Hl = Hl; p.Wl = Wl; p.ks = ks; p.stride = stride; p.pad = pad;
-    p.splitk = splitk; p.ntn = 1; p.K = Nb * Hs * Ws;
+    p.splitk = splitk; p.ntn = 1; p.K = Nb * Hs * Ws; p.Rst = Rc; p.Cst = Cc;
+    return dtype == FAVAE_F32 ? dispatch_pm<float>(p, st) : dispatch_pm<bf16_t>(p, st);
+}
+
+extern "C" size_t favae_conv_wgrad_folded_scratch(int Nb, int Hl, int Wl, int dtype) {
+    return (size_t)Nb * Hl * Wl * 32 * (dtype == FAVAE_F32 ? 4 : 2) + 256;
+}
+
+extern "C" int favae_conv_wgrad_folded(const void* rows, int Rc, const void* cols, int Cc, float* dw, int Nb, int Hs, int Ws,
+                                       int Hl, int Wl, int stride, int splitk, int dtype, void* scratch, size_t scratch_bytes,
+                                       void* stream) {
+    FAVAE_CHECK_ARG(rows && cols && dw && scratch, "favae_conv_wgrad_folded: null pointer");
+    FAVAE_CHECK_ARG(Nb > 0 && Hs > 0 && Ws > 0 && Rc > 0 && Cc > 0, "favae_conv_wgrad_folded: bad shape");
+    FAVAE_CHECK_ARG(stride == 1 || stride == 2, "favae_conv_wgrad_folded: stride");
+    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_conv_wgrad_folded: dtype");
+    FAVAE_CHECK_ARG(Hs == (Hl + 2 - 3) / stride + 1 && Ws == (Wl + 2 - 3) / stride + 1, "favae_conv_wgrad_folded: small/large size mismatch");
+    FAVAE_CHECK_ARG((size_t)Nb * Hl * Wl < (1u << 31), "favae_conv_wgrad_folded: too many pixels");
+    const bool fold_cols = Cc <= 3, fold_rows = !fold_cols && Rc <= 3 && stride == 1;
+    FAVAE_CHECK_ARG(fold_cols || fold_rows, "favae_conv_wgrad_folded: needs <= 3 channels on the image side (cols) or, at stride 1, on rows");
+    FAVAE_CHECK_ARG(((uintptr_t)scratch % 16) == 0 && ((uintptr_t)(fold_cols ? rows : cols) % 16) == 0, "favae_conv_wgrad_folded: 16-byte alignment");
+    FAVAE_CHECK_ARG((fold_cols ? Rc : Cc) % (dtype == FAVAE_F32 ? 4 : 8) == 0, "favae_conv_wgrad_folded: wide channel count must fill 16-byte vectors");
+    hipStream_t st = (hipStream_t)stream;
+    const int esz = dtype == FAVAE_F32 ? 4 : 2;
+    PmParams p;
+    p.dw = dw; p.r_large = 0; p.c_large = 0; p.Nb = Nb; p.ks = 1; p.stride = 1; p.pad = 0; p.splitk = splitk; p.ntn = 1;
+    if (fold_cols) {
+        // dw[r][tap][c] = sum_pix rows[pix][r] * cols[nb(pix, tap)][c]: columns (tap, c) gathered once into [pix][32]
+        const size_t need = (size_t)Nb * Hs * Ws * 32 * esz;
+        FAVAE_CHECK_ARG(need <= scratch_bytes, "favae_conv_wgrad_folded: scratch %zu < %zu", scratch_bytes, need);
+        int rc = fold_taps_launch(cols, scratch, Nb, Hs, Ws, Hl, Wl, Cc, stride, 0, dtype, st);
+        if (rc) return rc;
+        p.rp = rows; p.cp = scratch; p.Rc = Rc; p.Cc = 32; p.Rst = Rc; p.Cst = 9 * Cc;
+        p.Hs = Hs; p.Ws = Ws; p.Hl = Hs; p.Wl = Ws; p.K = Nb * Hs * Ws;
+    } else {
+        // stride 1: the same sum over the pixels of the wide operand, the narrow one shifted: rows (r, tap) into [pix'][32]
+        const size_t need = (size_t)Nb * Hl * Wl * 32 * esz;
+        FAVAE_CHECK_ARG(need <= scratch_bytes, "favae_conv_wgrad_folded: scratch %zu < %zu", scratch_bytes, need);
+        int rc = fold_taps_launch(rows, scratch, Nb, Hl, Wl, Hs, Ws, Rc, 1, 1, dtype, st);
+        if (rc) return rc;
+        p.rp = scratch; p.cp = cols; p.Rc = 32; p.Cc = Cc; p.Rst = 9 * Rc; p.Cst = Cc;
+        p.Hs = Hl; p.Ws = Wl; p.Hl = Hl; p.Wl = Wl; p.K = Nb * Hl * Wl;
+    }
     return dtype == FAVAE_F32 ? dispatch_pm<float>(p, st) : dispatch_pm<bf16_t>(p, st);
 }
 

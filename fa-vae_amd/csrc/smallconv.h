@@ -11,3 +11,10 @@ bool thin_in_applicable(int Cs, int Co, int ks, int stride, int scatter);
 struct ThinRed { double* bins; int nbin; const void* act; const float *raw, *mean, *invstd; };
 int thin_in_launch(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cs, int Ho, int Wo,
                    int Co, int stride, int scatter, int dtype, int out_bf16, const ThinRed& red, hipStream_t st);
+
+// Gather of the 3x3 neighbourhood of a <= 3-channel NHWC tensor into rows of 32 values (zero padded), one row per
+// pixel of the (Hq x Wq) grid the caller's reduction runs over.
+//   shifted = 0: dst[pix][tap*Cs + c] = src[n][s*y - 1 + kh][s*x - 1 + kw][c]      (src on the Hn x Wn grid, stride s)
+//   shifted = 1: dst[pix][c*9 + tap] = src[n][y + 1 - kh][x + 1 - kw][c]          (stride 1, same grid)
+int fold_taps_launch(const void* src, void* dst, int Nb, int Hq, int Wq, int Hn, int Wn, int Cs, int stride, int shifted,
+                     int dtype, hipStream_t st);

@@ -302,3 +302,53 @@ int thin_in_launch(const void* in, const void* w, const float* bias, float* out,
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Tap folding for the weight gradients with an image-sized channel count on one side (encoder.0, final_layer.3):
+// the 9 taps x <= 3 channels of the narrow operand become the 27 (padded to 32) columns of a plain [pixels][32] matrix,
+// after which the weight gradient is ONE pixel-major GEMM over the pixels (igemm.hip) that reads the wide operand
+// exactly once, instead of 9 shifted passes.  One thread per pixel, 64 or 128 B written per thread.
+namespace {
+template <class T, int CS>
+__global__ __launch_bounds__(256) void fold_taps(const T* __restrict__ src, T* __restrict__ dst, int Hq, int Wq, int Hn, int Wn,
+                                                 int stride, int shifted, int total) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= total) return;
+    const int n = pix / (Hq * Wq), rem = pix - n * Hq * Wq, y = rem / Wq, x = rem - y * Wq;
+    T v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = (T)0;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int sy = shifted ? y + 1 - kh : y * stride - 1 + kh, sx = shifted ? x + 1 - kw : x * stride - 1 + kw;
+            if (sy < 0 || sy >= Hn || sx < 0 || sx >= Wn) continue;
+            const T* s = src + ((size_t)(n * Hn + sy) * Wn + sx) * CS;
+#pragma unroll
+            for (int c = 0; c < CS; ++c) {
+                if (shifted) v[c * 9 + kh * 3 + kw] = s[c];
+                else v[(kh * 3 + kw) * CS + c] = s[c];
+            }
+        }
+    uint4* out = (uint4*)(dst + (size_t)pix * 32);
+    const uint4* vv = (const uint4*)v;
+#pragma unroll
+    for (int i = 0; i < (int)(32 * sizeof(T) / 16); ++i) out[i] = vv[i];
+}
+}  // namespace
+
+int fold_taps_launch(const void* src, void* dst, int Nb, int Hq, int Wq, int Hn, int Wn, int Cs, int stride, int shifted,
+                     int dtype, hipStream_t st) {
+    FAVAE_CHECK_ARG(Cs >= 1 && Cs <= 3, "fold_taps: 1..3 channels");
+    const int total = Nb * Hq * Wq;
+#define FT_CASE(T_, CS_) hipLaunchKernelGGL((fold_taps<T_, CS_>), dim3(cdiv(total, 256)), dim3(256), 0, st, (const T_*)src, (T_*)dst, Hq, Wq, Hn, Wn, stride, shifted, total)
+    if (dtype == FAVAE_F32) {
+        switch (Cs) { case 1: FT_CASE(float, 1); break; case 2: FT_CASE(float, 2); break; default: FT_CASE(float, 3); }
+    } else {
+        switch (Cs) { case 1: FT_CASE(bf16_t, 1); break; case 2: FT_CASE(bf16_t, 2); break; default: FT_CASE(bf16_t, 3); }
+    }
+#undef FT_CASE
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}

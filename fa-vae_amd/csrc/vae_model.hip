@@ -97,8 +97,9 @@ struct Vae {
     struct { bool on; float lr, b1, b2, eps; long long step; int pending; bool epoch; } ada;
     bool join_pending; bool dg_all;
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
-    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast
-    float* xf_alt; char* xt_alt;   // second batch buffer: the next gather must not overwrite what wgrad(encoder.0) still reads
+    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients
+    float* xf_alt; char* xt_alt;
+    char* fold; size_t fold_bytes;   // [pixels][32] tap-folded operand of the two image-side weight gradients (side stream only)   // second batch buffer: the next gather must not overwrite what wgrad(encoder.0) still reads
     const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(SH + L[l].wc_off * esz); }
     const void* Wt(int l) const { return (const void*)(SH + L[l].wt_off * esz); }
     long long rows(int l, int B) const { return (long long)B * L[l].Hout * L[l].Hout; }
@@ -168,6 +169,8 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
     v.xt = (char*)c.take(img * v.esz);
     v.xf_alt = (float*)c.take(img * 4);
     v.xt_alt = (char*)c.take(img * v.esz);
+    v.fold_bytes = favae_conv_wgrad_folded_scratch(B, 64, 64, v.dtype);
+    v.fold = (char*)c.take(v.fold_bytes);
     v.zlat = (char*)c.take((size_t)B * v.z * v.esz);
     v.stdq = (float*)c.take((size_t)B * v.z * 4);
     v.s1s2 = (float*)c.take(2 * 1024 * 4);
@@ -320,6 +323,9 @@ int adam_layer(Vae& v, int l, void* st) {
 int wgrad_launch(Vae& v, int l, const void* in, int B, void* st) {
     const Layer& L = v.L[l];
     float* dw = v.G + L.w_off;
+    if ((v.fuse & 64u) && v.ch <= 3 && (l == 0 || l == L_OUT))   // image-sized channel count on one side: one GEMM over folded taps
+        return favae_conv_wgrad_folded(v.draw[l], L.Cout, in, L.Cin, dw, B, L.Hout, L.Hout, L.Hin, L.Hin, l == 0 ? 2 : 1, 0, v.dtype,
+                                       v.fold, v.fold_bytes, st);
     switch (L.kind) {
     case CONV_S2:
         return favae_conv_wgrad(v.draw[l], L.Cout, 0, in, L.Cin, 1, dw, B, L.Hout, L.Hout, L.Hin, L.Hin, 3, 2, 1, 0, v.dtype, st);
@@ -430,7 +436,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
         const char* d = getenv("FAVAE_DG_EVENTS");
         v.dg_all = d && d[0] == '1';
         const char* f = getenv("FAVAE_FUSE_MASK");
-        v.fuse = f ? (unsigned)strtoul(f, nullptr, 0) : 0x3bu;   // 4 (thin-input path) measured slower: the prefetch costs occupancy
+        v.fuse = f ? (unsigned)strtoul(f, nullptr, 0) : 0x7bu;   // 4 (thin-input path) measured slower: the prefetch costs occupancy
     }
     if (v.overlap) {
         bool ok = hipStreamCreateWithFlags(&v.side, hipStreamNonBlocking) == hipSuccess;

@@ -97,3 +97,17 @@ def conv_wgrad(rows, rows_large, cols, cols_large, dw, Nb, Hs, Ws, Hl, Wl, ks, s
                                 _i(Hs), _i(Ws), _i(Hl), _i(Wl), _i(ks), _i(stride), _i(pad), _i(splitk),
                                 _i(dtype_code(rows)), stream_ptr()))
     return dw
+
+
+def conv_wgrad_folded(rows, cols, dw, Nb, Hs, Ws, Hl, Wl, stride, splitk=0):
+    """favae_conv_wgrad_folded: 3x3 / pad 1 weight gradient with <= 3 channels on one side as one GEMM over folded taps."""
+    Rc, Cc = rows.shape[-1], cols.shape[-1]
+    assert rows.dtype == cols.dtype and dw.dtype == torch.float32
+    _lib.favae_conv_wgrad_folded_scratch.restype = ctypes.c_size_t
+    nbytes = _lib.favae_conv_wgrad_folded_scratch(_i(Nb), _i(Hl), _i(Wl), _i(dtype_code(rows)))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=rows.device)
+    check(_lib.favae_conv_wgrad_folded(ptr(rows), _i(Rc), ptr(cols), _i(Cc), ptr(dw), _i(Nb), _i(Hs), _i(Ws), _i(Hl), _i(Wl),
+                                       _i(stride), _i(splitk), _i(dtype_code(rows)), ptr(scratch), ctypes.c_size_t(nbytes),
+                                       stream_ptr()))
+    torch.cuda.current_stream().synchronize()     # scratch is freed on return
+    return dw

@@ -71,6 +71,16 @@ int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const void* cols,
                      int Nb, int Hs, int Ws, int Hl, int Wl, int ks, int stride, int pad, int splitk, int dtype,
                      void* stream);
 
+/* The same weight gradient (ks 3, pad 1) for the two layers with an image-sized channel count on one side, as ONE GEMM
+ * over the pixels: the 9 taps x <= 3 channels of the narrow operand are gathered into a [pixels][32] matrix in `scratch`
+ * first, so the wide operand is read once instead of under 9 shifted windows.
+ *   Cc <= 3 (encoder.0, :31-33): rows = dout [Nb,Hs,Ws,Rc], cols = the layer input [Nb,Hl,Wl,Cc], stride 1 or 2;
+ *   Rc <= 3, stride 1 (final_layer.3, :74-76): rows = dout [Nb,Hs,Ws,Rc], cols = the layer input [Nb,Hl,Wl,Cc], Hs = Hl.
+ * dw [Rc][9][Cc] += ... (fp32 atomics, caller zeroes dw); scratch >= favae_conv_wgrad_folded_scratch(Nb, Hl, Wl, dtype). */
+size_t favae_conv_wgrad_folded_scratch(int Nb, int Hl, int Wl, int dtype);
+int favae_conv_wgrad_folded(const void* rows, int Rc, const void* cols, int Cc, float* dw, int Nb, int Hs, int Ws, int Hl,
+                            int Wl, int stride, int splitk, int dtype, void* scratch, size_t scratch_bytes, void* stream);
+
 /* Live HIP-event timing of the GEMM launches (measurement only; no reference counterpart). Every stride-th launch of
  * each kernel class is timed on its launch stream; collect() synchronises and returns [16][3] = launches, seconds,
  * algorithmic flops per class (classes: see csrc/igemm.hip). */

@@ -316,3 +316,36 @@ def test_thin_input_gradient_takes_batchnorm_backward_sums(dt, tol):
     tot = bins.sum(0)
     assert_close(tot[0].cpu(), dd.sum(0).cpu(), 1e-7)
     assert_close(tot[1].cpu(), (dd * xh).sum(0).cpu(), 1e-6)
+
+
+@pytest.mark.parametrize("dt,tol", DT)
+@pytest.mark.parametrize("Nb,H,Cs", [(3, 64, 3), (5, 20, 1), (64, 64, 3)])
+def test_folded_weight_gradient_encoder0(dt, tol, Nb, H, Cs):
+    """encoder.0 (Conv2d Cs -> 64, k3 s2 p1): favae_conv_wgrad_folded against autograd."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(51 + H)
+    Cout = 64
+    x = q(torch.rand(Nb, Cs, H, H, generator=g), dt)
+    w = torch.randn(Cout, Cs, 3, 3, generator=g, requires_grad=True)
+    dy = q(torch.randn(Nb, Cout, H // 2, H // 2, generator=g), dt)
+    F.conv2d(x, w, None, stride=2, padding=1).backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, 9, Cs)
+    dw = torch.zeros(Cout, 9, Cs, device="cuda")
+    lib.conv_wgrad_folded(nhwc(dy).to(dt).cuda(), nhwc(x).to(dt).cuda(), dw, Nb, H // 2, H // 2, H, H, 2)
+    assert_close(dw.cpu(), ref, tol)
+
+
+@pytest.mark.parametrize("dt,tol", DT)
+@pytest.mark.parametrize("Nb,H,Co", [(2, 64, 3), (3, 18, 2), (64, 64, 3)])
+def test_folded_weight_gradient_final_conv(dt, tol, Nb, H, Co):
+    """final_layer.3 (Conv2d 64 -> Co, k3 s1 p1): the narrow operand is the output gradient, shifted per tap."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(61 + H)
+    Cin = 64
+    x = q(torch.randn(Nb, Cin, H, H, generator=g), dt)
+    w = torch.randn(Co, Cin, 3, 3, generator=g, requires_grad=True)
+    dy = q(torch.randn(Nb, Co, H, H, generator=g), dt)
+    F.conv2d(x, w, None, stride=1, padding=1).backward(dy)
+    dw = torch.zeros(Co, 9, Cin, device="cuda")
+    lib.conv_wgrad_folded(nhwc(dy).to(dt).cuda(), nhwc(x).to(dt).cuda(), dw, Nb, H, H, H, H, 1)
+    assert_close(dw.cpu(), w.grad.permute(0, 2, 3, 1).reshape(Co, 9, Cin), tol)

@@ -134,7 +134,7 @@ def test_staged_step_equals_the_whole_step(dtype):
         lo = hi
     assert lo == eng.N_STAGES
     torch.cuda.synchronize()
-    assert torch.allclose(m1, m0, rtol=1e-6, atol=0)
+    assert torch.allclose(m1, m0, rtol=1e-6 if dtype == "f32" else 1e-4, atol=0)   # bf16: a last-bit change of a split-K sum can flip a rounding
     tol = 1e-4 if dtype == "f32" else 5e-3
     assert _rel(got.cpu().numpy(), g0.cpu().numpy()) <= tol
     assert _rel(eng.G.cpu().numpy(), g0.cpu().numpy()) <= tol
