@@ -866,6 +866,79 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     }
 }
 
+// ---- Adam + weight re-layout of one layer in one pass ---------------------------------------------------------
+// Blocks [0, ntiles): a 64 (co) x 64 (ci) tile of the weight tensor at one tap: update p/m/v (16-B accesses along ci),
+// write the dtype copy wc and, through LDS, the transpose wt [Ci][taps][Co] in whole 128-B rows.  Blocks >= ntiles: plain
+// Adam over the rest of the layer's arena slice (bias, BN affine).  Saves the re-read of the fresh weights and a launch
+// per layer compared with adam_kernel + wprep_kernel; needs Ci % 4 == 0 and Co % 4 == 0.
+template <class T, bool CLEAR_G>
+__global__ __launch_bounds__(256) void adam_wprep_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, int Co, int taps, int Ci, T* __restrict__ wc,
+                                                         T* __restrict__ wt, int ntiles, size_t tail_lo4, size_t tail_n4, float b1,
+                                                         float b2, float eps, float step_size, float bc2_sqrt) {
+    auto upd = [&](float4& P, const float4& G, float4& M, float4& V) {
+        float* pp = (float*)&P; const float* gg = (const float*)&G; float* mm = (float*)&M; float* vv = (float*)&V;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mm[j] = mm[j] + (1.f - b1) * (gg[j] - mm[j]);
+            vv[j] = vv[j] * b2 + (1.f - b2) * gg[j] * gg[j];
+            const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+            pp[j] = pp[j] - step_size * (mm[j] / denom);
+        }
+    };
+    if ((int)blockIdx.x >= ntiles) {
+        const size_t nb = gridDim.x - ntiles;
+        for (size_t i = (size_t)(blockIdx.x - ntiles) * 256 + threadIdx.x; i < tail_n4; i += nb * 256) {
+            const size_t k = tail_lo4 + i;
+            float4 P = ((float4*)p)[k], G = ((const float4*)g)[k], M = ((float4*)m)[k], V = ((float4*)v)[k];
+            upd(P, G, M, V);
+            ((float4*)p)[k] = P; ((float4*)m)[k] = M; ((float4*)v)[k] = V;
+            if (CLEAR_G) ((float4*)g)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    __shared__ float tile[64][65];
+    int b = blockIdx.x;
+    const int nci = (Ci + 63) / 64, nco = (Co + 63) / 64;
+    const int ci0 = (b % nci) * 64; b /= nci;
+    const int co0 = (b % nco) * 64;
+    const int tap = b / nco;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int ci = ci0 + tx * 4;
+    float4 P[4], G[4], M[4], V[4];
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = co0 + ty + 16 * i;
+        ok[i] = co < Co && ci < Ci;
+        if (ok[i]) {
+            const size_t o = (((size_t)co * taps + tap) * Ci + ci) / 4;
+            P[i] = ((float4*)p)[o]; G[i] = ((const float4*)g)[o]; M[i] = ((float4*)m)[o]; V[i] = ((float4*)v)[o];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = ty + 16 * i;
+        if (ok[i]) {
+            const size_t o = ((size_t)(co0 + row) * taps + tap) * Ci + ci;
+            upd(P[i], G[i], M[i], V[i]);
+            ((float4*)p)[o / 4] = P[i]; ((float4*)m)[o / 4] = M[i]; ((float4*)v)[o / 4] = V[i];
+            if (CLEAR_G) ((float4*)g)[o / 4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (wc) store4<T>(wc + o, P[i].x, P[i].y, P[i].z, P[i].w);
+            tile[row][tx * 4 + 0] = P[i].x; tile[row][tx * 4 + 1] = P[i].y; tile[row][tx * 4 + 2] = P[i].z; tile[row][tx * 4 + 3] = P[i].w;
+        }
+    }
+    if (!wt) return;   // uniform
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cil = ty + 16 * i, co = co0 + tx * 4;
+        if (ci0 + cil < Ci && co < Co)
+            store4<T>(wt + ((size_t)(ci0 + cil) * taps + tap) * Co + co, tile[tx * 4 + 0][cil], tile[tx * 4 + 1][cil], tile[tx * 4 + 2][cil],
+                      tile[tx * 4 + 3][cil]);
+    }
+}
+
 // ---- weight re-layout: master fp32 [Co][taps][Ci] -> T copy (same layout) and T transpose [Ci][taps][Co] -----
 template <class T>
 __global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w, T* __restrict__ wc, T* __restrict__ wt, int Co,
@@ -1249,6 +1322,31 @@ extern "C" int favae_adam_step_clear(float* p, float* g, float* m, float* v, lon
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
     hipLaunchKernelGGL(adam_kernel<true>, dim3(ew_grid((size_t)n / 4)), dim3(256), 0, ST, p, g, m, v, (size_t)n / 4, beta1, beta2, eps, step_size, bc2_sqrt);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_adam_wprep(float* p, float* g, float* m, float* v, long long n, int Co, int taps, int Ci, void* w_copy,
+                                void* w_transposed, int clear_grad, float lr, float beta1, float beta2, float eps, long long step,
+                                int dtype, void* stream) {
+    FAVAE_CHECK_ARG(p && g && m && v && step >= 1 && Co > 0 && taps > 0 && Ci > 0, "favae_adam_wprep: bad argument");
+    FAVAE_CHECK_ARG(Ci % 4 == 0 && Co % 4 == 0 && n % 4 == 0, "favae_adam_wprep: Ci, Co and n must be multiples of 4");
+    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_adam_wprep: dtype");
+    const long long nw = (long long)Co * taps * Ci;
+    FAVAE_CHECK_ARG(n >= nw, "favae_adam_wprep: slice shorter than the weight tensor");
+    FAVAE_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
+                    ((uintptr_t)w_copy % 16) == 0 && ((uintptr_t)w_transposed % 16) == 0, "favae_adam_wprep: 16-byte alignment");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    const int ntiles = cdiv(Ci, 64) * cdiv(Co, 64) * taps;
+    const size_t tail_lo4 = (size_t)nw / 4, tail_n4 = (size_t)(n - nw) / 4;
+    const int tail_blocks = tail_n4 ? (int)std::min<size_t>(64, (tail_n4 + 255) / 256) : 0;
+#define AW_LAUNCH(T_, CG_)                                                                                                   \
+    hipLaunchKernelGGL((adam_wprep_kernel<T_, CG_>), dim3(ntiles + tail_blocks), dim3(256), 0, ST, p, g, m, v, Co, taps, Ci,  \
+                       (T_*)w_copy, (T_*)w_transposed, ntiles, tail_lo4, tail_n4, beta1, beta2, eps, step_size, bc2_sqrt)
+    if (dtype == FAVAE_F32) { if (clear_grad) AW_LAUNCH(float, true); else AW_LAUNCH(float, false); }
+    else { if (clear_grad) AW_LAUNCH(bf16_t, true); else AW_LAUNCH(bf16_t, false); }
+#undef AW_LAUNCH
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

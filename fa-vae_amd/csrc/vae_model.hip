@@ -97,7 +97,7 @@ struct Vae {
     struct { bool on; float lr, b1, b2, eps; long long step; int pending; bool epoch; } ada;
     bool join_pending; bool dg_all;
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
-    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients
+    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients, 128 Adam + weight re-layout in one pass
     float* xf_alt; char* xt_alt;
     char* fold; size_t fold_bytes;   // [pixels][32] tap-folded operand of the two image-side weight gradients (side stream only)   // second batch buffer: the next gather must not overwrite what wgrad(encoder.0) still reads
     const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(SH + L[l].wc_off * esz); }
@@ -312,10 +312,13 @@ int after_dgrad(Vae& v, int l, void* st) {
 int adam_layer(Vae& v, int l, void* st) {
     const Layer& L = v.L[l];
     const long long lo = L.w_off, hi = l + 1 < NL ? v.L[l + 1].w_off : v.nparam;
-    if (v.ada.epoch) RC(favae_adam_step_clear(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, st));
-    else RC(favae_adam_step(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, st));
     void* c = L.wc_off >= 0 ? v.SH + L.wc_off * v.esz : nullptr;
     void* t = L.wt_off >= 0 ? v.SH + L.wt_off * v.esz : nullptr;
+    if ((v.fuse & 128u) && L.Cin % 4 == 0 && L.Cout % 4 == 0 && (c || t))   // one pass: update + dtype copy + transpose
+        return favae_adam_wprep(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, L.Cout, L.taps, L.Cin, c, t, v.ada.epoch ? 1 : 0,
+                                v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, v.dtype, st);
+    if (v.ada.epoch) RC(favae_adam_step_clear(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, st));
+    else RC(favae_adam_step(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, st));
     if (c || t) RC(favae_weight_prep(v.P + L.w_off, c, t, L.Cout, L.taps, L.Cin, v.dtype, st));
     return FAVAE_OK;
 }
@@ -436,7 +439,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
         const char* d = getenv("FAVAE_DG_EVENTS");
         v.dg_all = d && d[0] == '1';
         const char* f = getenv("FAVAE_FUSE_MASK");
-        v.fuse = f ? (unsigned)strtoul(f, nullptr, 0) : 0x7bu;   // 4 (thin-input path) measured slower: the prefetch costs occupancy
+        v.fuse = f ? (unsigned)strtoul(f, nullptr, 0) : 0x7bu;   // 128 (fused Adam) measured slower in the step: its bandwidth bursts sit on the main chain   // 4 (thin-input path) measured slower: the prefetch costs occupancy
     }
     if (v.overlap) {
         bool ok = hipStreamCreateWithFlags(&v.side, hipStreamNonBlocking) == hipSuccess;

@@ -166,6 +166,12 @@ int favae_adam_step(float* p, const float* g, float* m, float* v, long long n, f
  * of the iteration that follows, so that an epoch of steps needs no memset of the gradients. */
 int favae_adam_step_clear(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                           float eps, long long step, void* stream);
+/* Adam step over the arena slice of ONE layer (n floats starting with its weight tensor [Co][taps][Ci], then bias / BN
+ * affine) fused with the re-layout of the fresh weights (favae_weight_prep): the weights are read and written once.
+ * clear_grad != 0 also zeroes the consumed gradients (see favae_adam_step_clear).  Ci, Co, n multiples of 4. */
+int favae_adam_wprep(float* p, float* g, float* m, float* v, long long n, int Co, int taps, int Ci, void* w_copy,
+                     void* w_transposed, int clear_grad, float lr, float beta1, float beta2, float eps, long long step,
+                     int dtype, void* stream);
 /* master fp32 [Co][taps][Ci] -> dtype copy (same layout, may be NULL) and dtype transpose [Ci][taps][Co] (may be NULL). */
 /* The same for n weight tensors in one launch (host arrays of device pointers / shapes; n <= 16). */
 int favae_weight_prep_batch(int n, const float* const* w, void* const* w_copy, void* const* w_transposed, const int* Co,

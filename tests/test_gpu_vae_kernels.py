@@ -184,3 +184,30 @@ def test_weight_prep(dt, Co, taps, Ci):
                                    L.stream_ptr()))
     assert torch.equal(wc.cpu(), w.to(dt))
     assert torch.equal(wt.cpu(), w.to(dt).permute(2, 1, 0).contiguous())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Co,taps,Ci,extra", [(128, 9, 64, 384), (40, 1, 4096, 40), (4096, 1, 20, 4096), (512, 9, 1024, 1536), (64, 9, 64, 0)])
+def test_adam_fused_with_weight_prep(dt, Co, taps, Ci, extra):
+    """favae_adam_wprep == favae_adam_step(_clear) followed by favae_weight_prep, bit for bit (same arithmetic per element)."""
+    L = _L()
+    raw_ = L.raw()
+    dev = "cuda"
+    nw = Co * taps * Ci
+    n = nw + extra
+    g = torch.Generator().manual_seed(Co + Ci)
+    p0, g0 = torch.randn(n, generator=g).to(dev), (torch.randn(n, generator=g) * 0.1).to(dev)
+    m0, v0 = (torch.randn(n, generator=g) * 0.01).to(dev), (torch.rand(n, generator=g) * 1e-3).to(dev)
+    code = 0 if dt == torch.float32 else 1
+    pa, ga, ma, va = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    L.check(raw_.favae_adam_step_clear(L.ptr(pa), L.ptr(ga), L.ptr(ma), L.ptr(va), ll_(n), f_(1e-3), f_(0.9), f_(0.999), f_(1e-8), ll_(7),
+                                       L.stream_ptr()))
+    wca, wta = torch.zeros(nw, dtype=dt, device=dev), torch.zeros(nw, dtype=dt, device=dev)
+    L.check(raw_.favae_weight_prep(L.ptr(pa), L.ptr(wca), L.ptr(wta), i_(Co), i_(taps), i_(Ci), i_(code), L.stream_ptr()))
+    pb, gb, mb, vb = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    wcb, wtb = torch.zeros(nw, dtype=dt, device=dev), torch.zeros(nw, dtype=dt, device=dev)
+    L.check(raw_.favae_adam_wprep(L.ptr(pb), L.ptr(gb), L.ptr(mb), L.ptr(vb), ll_(n), i_(Co), i_(taps), i_(Ci), L.ptr(wcb), L.ptr(wtb),
+                                  i_(1), f_(1e-3), f_(0.9), f_(0.999), f_(1e-8), ll_(7), i_(code), L.stream_ptr()))
+    for a, b in ((pa, pb), (ma, mb), (va, vb), (ga, gb), (wca, wcb), (wta, wtb)):
+        assert torch.equal(a, b)
+    assert float(gb.abs().max()) == 0.0
