@@ -816,6 +816,141 @@ __global__ __launch_bounds__(256) void sigmoid_ll_bias(const float* __restrict__
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- final_layer.3-4 + loss in one launch (:74-77, 152-171, 238) ------------------------------------------------
+// Conv2d(64 -> CO <= 4, k3 s1 p1) + Sigmoid + Gaussian log-likelihood + its gradient + the conv's bias gradient.  The
+// output is CO values per pixel, so the layer is a 576-long dot product per pixel and channel: one thread owns a pixel,
+// the weights are wave-uniform (scalar loads), the input row of a tap is 8 x 16 B per thread (shared with the neighbouring
+// pixels through L1/L2), and nothing of the CO-channel result has to travel through memory before the loss.
+// wk: [9][CO][64] fp32 (conv_out_wprep).  Reduction of (SSE, gradient sums) as in sigmoid_ll_bias.
+template <class T, int CO>
+__global__ __launch_bounds__(256) void conv_out_ll(const T* __restrict__ act, const float* __restrict__ wk, const float* __restrict__ bias,
+                                                   const float* __restrict__ x, int H, int W, int total, float inv_var_B,
+                                                   float* __restrict__ raw, T* __restrict__ draw, double* __restrict__ partial,
+                                                   unsigned* __restrict__ ticket, double D, double var_x, double B,
+                                                   double* __restrict__ rec_err, float* __restrict__ dbias) {
+    constexpr int CI = 64, VE = 16 / sizeof(T), NV = CI / VE;
+    __shared__ double sm[5 * 4];
+    __shared__ int is_last;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = gid < total;
+    const int pix = min(gid, total - 1);
+    const int n = pix / (H * W), rem = pix - n * H * W, y = rem / W, xx = rem - y * W;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = bias ? bias[c] : 0.f;
+    // taps two at a time from two register buffers: the 8 loads of the next tap are in flight under the 3 * 64 FMAs of
+    // the current one (a fully unrolled tap loop lets the compiler hoist all 72 loads and spill)
+    auto load_tap = [&](int t, uint4 (&v)[NV]) -> float {
+        const int kh = t / 3, kw = t - kh * 3;
+        const int iy = y - 1 + kh, ix = xx - 1 + kw;
+        const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+        const uint4* src = (const uint4*)(act + ((size_t)(n * H + cy) * W + cx) * CI);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = src[i];
+        return (iy >= 0 && iy < H && ix >= 0 && ix < W) ? 1.f : 0.f;
+    };
+    auto fma_tap = [&](int t, const uint4 (&v)[NV], float m) {
+        float p[CO];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) p[c] = 0.f;
+        const float* wt = wk + t * CO * CI;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float f[VE];
+            if constexpr (sizeof(T) == 2) {
+                f[0] = __uint_as_float(v[i].x << 16); f[1] = __uint_as_float(v[i].x & 0xffff0000u);
+                f[2] = __uint_as_float(v[i].y << 16); f[3] = __uint_as_float(v[i].y & 0xffff0000u);
+                f[4] = __uint_as_float(v[i].z << 16); f[5] = __uint_as_float(v[i].z & 0xffff0000u);
+                f[6] = __uint_as_float(v[i].w << 16); f[7] = __uint_as_float(v[i].w & 0xffff0000u);
+            } else {
+                f[0] = __uint_as_float(v[i].x); f[1] = __uint_as_float(v[i].y); f[2] = __uint_as_float(v[i].z); f[3] = __uint_as_float(v[i].w);
+            }
+#pragma unroll
+            for (int e = 0; e < VE; ++e)
+#pragma unroll
+                for (int c = 0; c < CO; ++c) p[c] += f[e] * wt[c * CI + i * VE + e];
+        }
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[c] += m * p[c];
+    };
+    uint4 va[NV], vb[NV];
+    float ma = load_tap(0, va), mb = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < 8; t += 2) {
+        mb = load_tap(t + 1, vb);
+        fma_tap(t, va, ma);
+        ma = load_tap(t + 2, va);
+        fma_tap(t + 1, vb, mb);
+    }
+    fma_tap(8, va, ma);
+    double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            const size_t o = (size_t)pix * CO + c;
+            const float s = 1.f / (1.f + expf(-acc[c]));
+            const float d = s - x[o];
+            const float g = d * inv_var_B * s * (1.f - s);
+            raw[o] = acc[c];
+            draw[o] = from_f32<T>(g);
+            a[0] += (double)d * d;
+            a[1 + c] += g;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        a[k] = wave_sum(a[k]);
+        if (lane == 0) sm[k * 4 + wave] = a[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5)
+        __hip_atomic_store(&partial[(size_t)blockIdx.x * 5 + threadIdx.x],
+                           (sm[threadIdx.x * 4] + sm[threadIdx.x * 4 + 1]) + (sm[threadIdx.x * 4 + 2] + sm[threadIdx.x * 4 + 3]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    double t[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (unsigned b0 = 0; b0 < gridDim.x; b0 += 1024) {   // 4 blocks' partials in flight per thread
+        double q[4][5];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned b = b0 + threadIdx.x + 256 * u;
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                q[u][k] = b < gridDim.x ? __hip_atomic_load(&partial[(size_t)b * 5 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) t[k] += q[u][k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        t[k] = wave_sum(t[k]);
+        if (lane == 0) sm[k * 4 + wave] = t[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const double tot = (sm[threadIdx.x * 4] + sm[threadIdx.x * 4 + 1]) + (sm[threadIdx.x * 4 + 2] + sm[threadIdx.x * 4 + 3]);
+        if (threadIdx.x == 0) *rec_err = 0.5 * (D * log(2.0 * M_PI) + D * log(var_x)) + 0.5 * tot / (var_x * B);
+        else if (dbias && (int)threadIdx.x - 1 < CO) dbias[threadIdx.x - 1] = (float)tot;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// w [CO][9][64] (dtype) -> wk [9][CO][64] fp32
+template <class T>
+__global__ void conv_out_wprep(const T* __restrict__ w, float* __restrict__ wk, int CO) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 9 * CO * 64) return;
+    const int ci = i & 63, q = i >> 6, co = q % CO, tap = q / CO;
+    wk[i] = to_f32<T>(w[((size_t)co * 9 + tap) * 64 + ci]);
+}
+
 // sigmoid(raw) vs y: per-block partial (sum (y-s)^2, sum y, sum y^2), then one block adds them onto acc3
 __global__ __launch_bounds__(256) void sigmoid_sse(const float* __restrict__ raw, const float* __restrict__ y, size_t n,
                                                    double* __restrict__ partial) {
@@ -1283,6 +1418,42 @@ extern "C" int favae_sigmoid_ll_bias(const float* raw, const float* x, int B, lo
     else
         hipLaunchKernelGGL(sigmoid_ll_bias<bf16_t>, dim3(grid), dim3(256), 0, ST, raw, x, n, C, ivb, (bf16_t*)draw, scratch, ticket,
                            (double)D, (double)var_x, (double)B, rec_err, dbias);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_conv_out_wprep(const void* w, float* wk, int Cout, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(w && wk && Cout >= 1 && Cout <= 4 && (dtype == FAVAE_F32 || dtype == FAVAE_BF16), "favae_conv_out_wprep: bad argument");
+    const int n = 9 * Cout * 64;
+    if (dtype == FAVAE_F32) hipLaunchKernelGGL(conv_out_wprep<float>, dim3(cdiv(n, 256)), dim3(256), 0, ST, (const float*)w, wk, Cout);
+    else hipLaunchKernelGGL(conv_out_wprep<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, ST, (const bf16_t*)w, wk, Cout);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_conv_out_ll(const void* act, const float* wk, const float* bias, const float* x, int Nb, int H, int W,
+                                 int Cout, float var_x, float* raw, void* draw, double* rec_err, float* dbias, double* scratch,
+                                 size_t scratch_doubles, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(act && wk && x && raw && draw && rec_err && scratch && Nb > 0 && H > 0 && W > 0 && var_x > 0, "favae_conv_out_ll: bad argument");
+    FAVAE_CHECK_ARG(Cout >= 1 && Cout <= 4, "favae_conv_out_ll: 1..4 output channels");
+    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_conv_out_ll: dtype");
+    FAVAE_CHECK_ARG(((uintptr_t)act % 16) == 0 && (size_t)Nb * H * W < (1u << 31), "favae_conv_out_ll: alignment / size");
+    const int total = Nb * H * W, grid = cdiv(total, 256);
+    FAVAE_CHECK_ARG((size_t)grid * 5 <= scratch_doubles, "favae_conv_out_ll: scratch too small (%zu < %zu doubles)", scratch_doubles, (size_t)grid * 5);
+    unsigned* ticket = nullptr;
+    int trc = ticket_base(1, &ticket);
+    if (trc) return trc;
+    const float ivb = 1.f / (var_x * (float)Nb);
+    const double D = (double)H * W * Cout;
+#define CO_LAUNCH(T_, CO_)                                                                                                   \
+    hipLaunchKernelGGL((conv_out_ll<T_, CO_>), dim3(grid), dim3(256), 0, ST, (const T_*)act, wk, bias, x, H, W, total, ivb, raw, \
+                       (T_*)draw, scratch, ticket, D, (double)var_x, (double)Nb, rec_err, dbias)
+    if (dtype == FAVAE_F32) {
+        switch (Cout) { case 1: CO_LAUNCH(float, 1); break; case 2: CO_LAUNCH(float, 2); break; case 3: CO_LAUNCH(float, 3); break; default: CO_LAUNCH(float, 4); }
+    } else {
+        switch (Cout) { case 1: CO_LAUNCH(bf16_t, 1); break; case 2: CO_LAUNCH(bf16_t, 2); break; case 3: CO_LAUNCH(bf16_t, 3); break; default: CO_LAUNCH(bf16_t, 4); }
+    }
+#undef CO_LAUNCH
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

@@ -97,8 +97,9 @@ struct Vae {
     struct { bool on; float lr, b1, b2, eps; long long step; int pending; bool epoch; } ada;
     bool join_pending; bool dg_all;
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
-    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients, 128 Adam + weight re-layout in one pass
+    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients, 128 Adam + weight re-layout in one pass, 256 final conv + loss in one launch
     float* xf_alt; char* xt_alt;
+    float* wk_out;   // [9][ch][64] fp32 weights of final_layer.3 for favae_conv_out_ll (rebuilt whenever the layer changes)
     char* fold; size_t fold_bytes;   // [pixels][32] tap-folded operand of the two image-side weight gradients (side stream only)   // second batch buffer: the next gather must not overwrite what wgrad(encoder.0) still reads
     const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(SH + L[l].wc_off * esz); }
     const void* Wt(int l) const { return (const void*)(SH + L[l].wt_off * esz); }
@@ -169,6 +170,7 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
     v.xt = (char*)c.take(img * v.esz);
     v.xf_alt = (float*)c.take(img * 4);
     v.xt_alt = (char*)c.take(img * v.esz);
+    v.wk_out = (float*)c.take(9 * 4 * 64 * 4);
     v.fold_bytes = favae_conv_wgrad_folded_scratch(B, 64, 64, v.dtype);
     v.fold = (char*)c.take(v.fold_bytes);
     v.zlat = (char*)c.take((size_t)B * v.z * v.esz);
@@ -243,7 +245,7 @@ int encoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false) {
     return conv_fwd(v, L_FC, in, B, st, pooled);
 }
 
-int decoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false) {
+int decoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false, bool skip_out = false) {
     {   // decoder_input (:41-45) has no BN / activation: the GEMM stores its result in the dtype the next layer reads
         const Layer& L = v.L[L_DI];
         RC(favae_conv_igemm(v.zlat, v.Wf(L_DI), v.P + L.b_off, (float*)v.act[L_DI], B, 1, 1, L.Cin, 1, 1, L.Cout, 1, 1, 0, 0, 0,
@@ -255,7 +257,7 @@ int decoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false) {
         RC(bn_fwd(v, l, B, train, st));
         in = v.act[l];
     }
-    return conv_fwd(v, L_OUT, in, B, st, pooled);
+    return skip_out ? FAVAE_OK : conv_fwd(v, L_OUT, in, B, st, pooled);
 }
 
 int bn_bwd(Vae& v, int l, int B, void* st) {
@@ -314,12 +316,13 @@ int adam_layer(Vae& v, int l, void* st) {
     const long long lo = L.w_off, hi = l + 1 < NL ? v.L[l + 1].w_off : v.nparam;
     void* c = L.wc_off >= 0 ? v.SH + L.wc_off * v.esz : nullptr;
     void* t = L.wt_off >= 0 ? v.SH + L.wt_off * v.esz : nullptr;
-    if ((v.fuse & 128u) && L.Cin % 4 == 0 && L.Cout % 4 == 0 && (c || t))   // one pass: update + dtype copy + transpose
+    if ((v.fuse & 128u) && L.Cin % 4 == 0 && L.Cout % 4 == 0 && (c || t))   // one pass: update + dtype copy + transpose (never L_OUT: Cout <= 4)
         return favae_adam_wprep(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, L.Cout, L.taps, L.Cin, c, t, v.ada.epoch ? 1 : 0,
                                 v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, v.dtype, st);
     if (v.ada.epoch) RC(favae_adam_step_clear(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, st));
     else RC(favae_adam_step(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, st));
     if (c || t) RC(favae_weight_prep(v.P + L.w_off, c, t, L.Cout, L.taps, L.Cin, v.dtype, st));
+    if (l == L_OUT) RC(favae_conv_out_wprep(v.Wf(L_OUT), v.wk_out, v.ch, v.dtype, st));
     return FAVAE_OK;
 }
 
@@ -439,7 +442,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
         const char* d = getenv("FAVAE_DG_EVENTS");
         v.dg_all = d && d[0] == '1';
         const char* f = getenv("FAVAE_FUSE_MASK");
-        v.fuse = f ? (unsigned)strtoul(f, nullptr, 0) : 0x7bu;   // 128 (fused Adam) measured slower in the step: its bandwidth bursts sit on the main chain   // 4 (thin-input path) measured slower: the prefetch costs occupancy
+        v.fuse = f ? (unsigned)strtoul(f, nullptr, 0) : 0x17bu;   // 128 (fused Adam) measured slower in the step: its bandwidth bursts sit on the main chain   // 4 (thin-input path) measured slower: the prefetch costs occupancy
     }
     if (v.overlap) {
         bool ok = hipStreamCreateWithFlags(&v.side, hipStreamNonBlocking) == hipSuccess;
@@ -486,7 +489,8 @@ extern "C" int favae_vae_refresh_weights(favae_vae* h, void* st) {
         w[n] = v.P + L.w_off; wc[n] = c; wt[n] = t; Co[n] = L.Cout; taps[n] = L.taps; Ci[n] = L.Cin;
         ++n;
     }
-    return n ? favae_weight_prep_batch(n, w, wc, wt, Co, taps, Ci, v.dtype, st) : FAVAE_OK;
+    if (n) RC(favae_weight_prep_batch(n, w, wc, wt, Co, taps, Ci, v.dtype, st));
+    return favae_conv_out_wprep(v.Wf(L_OUT), v.wk_out, v.ch, v.dtype, st);
 }
 
 namespace {
@@ -509,9 +513,13 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
         }
         RC(encoder_fwd(v, B, true, st, true));
         RC(favae_reparam_kl_fwd(v.raw[L_FC], eps, prior, idx, tau, B, v.z, v.zlat, v.stdq, metrics2_out + 1, v.dtype, st));
-        RC(decoder_fwd(v, B, true, st, true));
+        const bool out_ll = (v.fuse & 0x100u) != 0;
+        RC(decoder_fwd(v, B, true, st, true, out_ll));
         const long long D = (long long)64 * 64 * v.ch;
-        if (v.fuse & 8u) {
+        if (out_ll) {   // final conv + sigmoid + log-likelihood + gradient + bias gradient in one launch
+            RC(favae_conv_out_ll(v.act[11], v.wk_out, v.P + v.L[L_OUT].b_off, v.xf, B, 64, 64, v.ch, var_x, v.raw[L_OUT], v.draw[L_OUT],
+                                 metrics2_out, v.G + v.L[L_OUT].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
+        } else if (v.fuse & 8u) {
             RC(favae_sigmoid_ll_bias(v.raw[L_OUT], v.xf, B, D, v.ch, var_x, v.draw[L_OUT], metrics2_out, v.G + v.L[L_OUT].b_off, v.scratch,
                                      v.scratch_doubles, v.dtype, st));
         } else {

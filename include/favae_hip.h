@@ -155,6 +155,15 @@ int favae_sigmoid_ll(const float* raw, const float* x, int B, long long D, float
  * scratch >= 5 * 1024 doubles. */
 int favae_sigmoid_ll_bias(const float* raw, const float* x, int B, long long D, int C, float var_x, void* draw,
                           double* rec_err, float* dbias, double* scratch, size_t scratch_doubles, int dtype, void* stream);
+/* final_layer.3-4 + the loss in one launch (:74-77 Conv2d(64 -> Cout <= 4, k3 s1 p1) + Sigmoid, :152-171 gaussian_LL,
+ * :238): raw [Nb,H,W,Cout] = conv output (fp32), draw (dtype) = gradient w.r.t. raw, *rec_err, dbias [Cout] = bias
+ * gradient.  act [Nb,H,W,64] dtype; wk = favae_conv_out_wprep of the [Cout][9][64] dtype weights ([9][Cout][64] fp32);
+ * x [Nb,H,W,Cout] fp32 targets.  scratch >= 5 * ceil(Nb*H*W / 256) doubles.  Same results as favae_conv_igemm +
+ * favae_sigmoid_ll_bias up to fp32 summation order. */
+int favae_conv_out_wprep(const void* w, float* wk, int Cout, int dtype, void* stream);
+int favae_conv_out_ll(const void* act, const float* wk, const float* bias, const float* x, int Nb, int H, int W, int Cout,
+                      float var_x, float* raw, void* draw, double* rec_err, float* dbias, double* scratch,
+                      size_t scratch_doubles, int dtype, void* stream);
 int favae_sigmoid(const float* raw, float* out, long long n, void* stream);
 /* acc3 += (sum (y - sigmoid(raw))^2, sum y, sum y^2). scratch >= 3*1024 doubles. */
 int favae_sigmoid_sse(const float* raw, const float* y, long long n, double* acc3, double* scratch, size_t scratch_doubles,

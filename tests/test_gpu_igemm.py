@@ -349,3 +349,43 @@ def test_folded_weight_gradient_final_conv(dt, tol, Nb, H, Co):
     dw = torch.zeros(Co, 9, Cin, device="cuda")
     lib.conv_wgrad_folded(nhwc(dy).to(dt).cuda(), nhwc(x).to(dt).cuda(), dw, Nb, H, H, H, H, 1)
     assert_close(dw.cpu(), w.grad.permute(0, 2, 3, 1).reshape(Co, 9, Cin), tol)
+
+
+@pytest.mark.parametrize("dt,tol", DT)
+@pytest.mark.parametrize("Nb,H,Co", [(3, 64, 3), (5, 10, 1), (64, 64, 3)])
+def test_final_conv_with_loss_in_one_launch(dt, tol, Nb, H, Co):
+    """favae_conv_out_ll: Conv2d(64 -> Co, k3 s1 p1) + Sigmoid + gaussian_LL + gradient + bias gradient
+    (celeba_deepvanilla_vae.py:74-77, 152-171, 238) against torch autograd of the same expression."""
+    import ctypes
+    lib = _lib()
+    rawl = lib.raw()
+    g = torch.Generator().manual_seed(71 + H)
+    Cin, var_x = 64, 0.01
+    a = q(torch.randn(Nb, Cin, H, H, generator=g), dt)
+    w = q(torch.randn(Co, Cin, 3, 3, generator=g) * 0.05, dt)
+    b = (torch.randn(Co, generator=g) * 0.1).requires_grad_(True)
+    x = torch.rand(Nb, Co, H, H, generator=g)
+    y = F.conv2d(a.double(), w.double(), b.double(), stride=1, padding=1)
+    y.retain_grad()
+    sg = torch.sigmoid(y)
+    D = Co * H * H
+    ll = (-0.5 * (D * np.log(2 * np.pi) + D * np.log(var_x) + ((x.double() - sg) ** 2 / var_x).flatten(1).sum(-1))).mean()
+    (-ll).backward()
+    i_, f_, sz_ = ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+    wd = w.permute(0, 2, 3, 1).reshape(Co, 9, Cin).contiguous().to(dt).cuda()
+    wk = torch.zeros(9, Co, 64, device="cuda")
+    lib.check(rawl.favae_conv_out_wprep(lib.ptr(wd), lib.ptr(wk), i_(Co), i_(lib.dtype_code(wd)), lib.stream_ptr()))
+    assert torch.equal(wk.cpu(), w.permute(2, 3, 0, 1).reshape(9, Co, Cin).float())
+    ad, xd, bd = nhwc(a).to(dt).cuda(), nhwc(x).cuda(), b.detach().cuda()
+    raw = torch.zeros(Nb, H, H, Co, device="cuda")
+    draw = torch.zeros(Nb, H, H, Co, device="cuda", dtype=dt)
+    rec, dbias = torch.zeros(1, dtype=torch.float64, device="cuda"), torch.zeros(Co, device="cuda")
+    scratch = torch.zeros(5 * ((Nb * H * H + 255) // 256) + 8, dtype=torch.float64, device="cuda")
+    for _ in range(2):   # twice: the ticket must be left clean
+        lib.check(rawl.favae_conv_out_ll(lib.ptr(ad), lib.ptr(wk), lib.ptr(bd), lib.ptr(xd), i_(Nb), i_(H), i_(H), i_(Co), f_(var_x),
+                                         lib.ptr(raw), lib.ptr(draw), lib.ptr(rec), lib.ptr(dbias), lib.ptr(scratch), sz_(scratch.numel()),
+                                         i_(lib.dtype_code(ad)), lib.stream_ptr()))
+        assert_close(raw.cpu(), nhwc(y.detach()), tol)
+        assert abs(rec.item() + ll.item()) <= 1e-5 * abs(ll.item())
+        assert_close(draw.float().cpu(), nhwc(y.grad), 1e-4 if dt == torch.float32 else 8e-3)
+        assert_close(dbias.cpu(), b.grad, 1e-4)
