@@ -818,86 +818,46 @@ __global__ __launch_bounds__(256) void sigmoid_ll_bias(const float* __restrict__
 
 // ---- final_layer.3-4 + loss in one launch (:74-77, 152-171, 238) ------------------------------------------------
 // Conv2d(64 -> CO <= 4, k3 s1 p1) + Sigmoid + Gaussian log-likelihood + its gradient + the conv's bias gradient.  The
-// output is CO values per pixel, so the layer is a 576-long dot product per pixel and channel: one thread owns a pixel,
-// the weights are wave-uniform (scalar loads), the input row of a tap is 8 x 16 B per thread (shared with the neighbouring
-// pixels through L1/L2), and nothing of the CO-channel result has to travel through memory before the loss.
-// wk: [9][CO][64] fp32 (conv_out_wprep).  Reduction of (SSE, gradient sums) as in sigmoid_ll_bias.
+// output is CO values per pixel, i.e. a 576-long dot product per pixel and channel: a lane loads the 64 input channels
+// of its own pixel per tap (8 x 16 B, shared with the neighbouring pixels through L1/L2) and feeds them, as they are, to
+// the 4x4x4 MFMA (16 independent blocks of 4 pixels x 4 output channels per wave; 4x4x1 for fp32), whose B operand (the
+// weights of the tap, 4 KB in LDS) is the same for every block.  Nothing of the CO-channel result travels through memory
+// before the loss.  wk: [9][16][4][4] dtype = (tap, k/4, cout, k%4), zero for cout >= CO (conv_out_wprep).
+// Reduction of (SSE, gradient sums) as in sigmoid_ll_bias.
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+// Shared tail of the two conv_out_ll kernels: acc = D[i][j] of the lane's MFMA block (j = lane & 3 output channel, i = pixel
+// 4 * (lane / 4) + i of the wave); sigmoid, log-likelihood, gradient, bias gradient and the ticketed reduction.
 template <class T, int CO>
-__global__ __launch_bounds__(256) void conv_out_ll(const T* __restrict__ act, const float* __restrict__ wk, const float* __restrict__ bias,
-                                                   const float* __restrict__ x, int H, int W, int total, float inv_var_B,
-                                                   float* __restrict__ raw, T* __restrict__ draw, double* __restrict__ partial,
-                                                   unsigned* __restrict__ ticket, double D, double var_x, double B,
-                                                   double* __restrict__ rec_err, float* __restrict__ dbias) {
-    constexpr int CI = 64, VE = 16 / sizeof(T), NV = CI / VE;
-    __shared__ double sm[5 * 4];
-    __shared__ int is_last;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    const bool valid = gid < total;
-    const int pix = min(gid, total - 1);
-    const int n = pix / (H * W), rem = pix - n * H * W, y = rem / W, xx = rem - y * W;
-    float acc[CO];
-#pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = bias ? bias[c] : 0.f;
-    // taps two at a time from two register buffers: the 8 loads of the next tap are in flight under the 3 * 64 FMAs of
-    // the current one (a fully unrolled tap loop lets the compiler hoist all 72 loads and spill)
-    auto load_tap = [&](int t, uint4 (&v)[NV]) -> float {
-        const int kh = t / 3, kw = t - kh * 3;
-        const int iy = y - 1 + kh, ix = xx - 1 + kw;
-        const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
-        const uint4* src = (const uint4*)(act + ((size_t)(n * H + cy) * W + cx) * CI);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = src[i];
-        return (iy >= 0 && iy < H && ix >= 0 && ix < W) ? 1.f : 0.f;
-    };
-    auto fma_tap = [&](int t, const uint4 (&v)[NV], float m) {
-        float p[CO];
-#pragma unroll
-        for (int c = 0; c < CO; ++c) p[c] = 0.f;
-        const float* wt = wk + t * CO * CI;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            float f[VE];
-            if constexpr (sizeof(T) == 2) {
-                f[0] = __uint_as_float(v[i].x << 16); f[1] = __uint_as_float(v[i].x & 0xffff0000u);
-                f[2] = __uint_as_float(v[i].y << 16); f[3] = __uint_as_float(v[i].y & 0xffff0000u);
-                f[4] = __uint_as_float(v[i].z << 16); f[5] = __uint_as_float(v[i].z & 0xffff0000u);
-                f[6] = __uint_as_float(v[i].w << 16); f[7] = __uint_as_float(v[i].w & 0xffff0000u);
-            } else {
-                f[0] = __uint_as_float(v[i].x); f[1] = __uint_as_float(v[i].y); f[2] = __uint_as_float(v[i].z); f[3] = __uint_as_float(v[i].w);
-            }
-#pragma unroll
-            for (int e = 0; e < VE; ++e)
-#pragma unroll
-                for (int c = 0; c < CO; ++c) p[c] += f[e] * wt[c * CI + i * VE + e];
-        }
-#pragma unroll
-        for (int c = 0; c < CO; ++c) acc[c] += m * p[c];
-    };
-    uint4 va[NV], vb[NV];
-    float ma = load_tap(0, va), mb = 0.f;
-#pragma unroll 1
-    for (int t = 0; t < 8; t += 2) {
-        mb = load_tap(t + 1, vb);
-        fma_tap(t, va, ma);
-        ma = load_tap(t + 2, va);
-        fma_tap(t + 1, vb, mb);
-    }
-    fma_tap(8, va, ma);
-    double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    if (valid) {
-#pragma unroll
-        for (int c = 0; c < CO; ++c) {
-            const size_t o = (size_t)pix * CO + c;
-            const float s = 1.f / (1.f + expf(-acc[c]));
-            const float d = s - x[o];
-            const float g = d * inv_var_B * s * (1.f - s);
-            raw[o] = acc[c];
-            draw[o] = from_f32<T>(g);
-            a[0] += (double)d * d;
-            a[1 + c] += g;
-        }
-    }
+__device__ __forceinline__ void conv_out_ll_tail(const float4v acc, const float* __restrict__ bias, const float* __restrict__ x, int total,
+                                                 float inv_var_B, float* __restrict__ raw, T* __restrict__ draw,
+                                                 double* __restrict__ partial, unsigned* __restrict__ ticket, double D, double var_x,
+                                                 double B, double* __restrict__ rec_err, float* __restrict__ dbias, double* sm,
+                                                 int* is_last_p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // this lane: output channel j of the 4 pixels of its block
+    const int j = lane & 3, p0 = blockIdx.x * 256 + wave * 64 + (lane >> 2) * 4;
+    double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (j < CO) {
+        const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = p0 + i;
+            if (p < total) {
+                const size_t o = (size_t)p * CO + j;
+                const float r = acc[i] + bj;
+                const float s = 1.f / (1.f + expf(-r));
+                const float d = s - x[o];
+                const float g = d * inv_var_B * s * (1.f - s);
+                raw[o] = r;
+                draw[o] = from_f32<T>(g);
+                a[0] += (double)d * d;
+#pragma unroll
+                for (int c = 0; c < CO; ++c) a[1 + c] += (j == c) ? g : 0.f;
+            }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         a[k] = wave_sum(a[k]);
@@ -910,9 +870,9 @@ __global__ __launch_bounds__(256) void conv_out_ll(const T* __restrict__ act, co
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    if (threadIdx.x == 0) *is_last_p = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
-    if (!is_last) return;
+    if (!*is_last_p) return;
     double t[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     for (unsigned b0 = 0; b0 < gridDim.x; b0 += 1024) {   // 4 blocks' partials in flight per thread
         double q[4][5];
@@ -942,13 +902,149 @@ __global__ __launch_bounds__(256) void conv_out_ll(const T* __restrict__ act, co
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// w [CO][9][64] (dtype) -> wk [9][CO][64] fp32
+template <class T, int CO>
+__global__ __launch_bounds__(256) void conv_out_ll(const T* __restrict__ act, const T* __restrict__ wk, const float* __restrict__ bias,
+                                                   const float* __restrict__ x, int H, int W, int total, float inv_var_B,
+                                                   float* __restrict__ raw, T* __restrict__ draw, double* __restrict__ partial,
+                                                   unsigned* __restrict__ ticket, double D, double var_x, double B,
+                                                   double* __restrict__ rec_err, float* __restrict__ dbias) {
+    constexpr int CI = 64, VE = 16 / sizeof(T), NV = CI / VE;
+    __shared__ __attribute__((aligned(16))) T wl[9 * 16 * 4 * 4];
+    __shared__ double sm[5 * 4];
+    __shared__ int is_last;
+    for (int i = threadIdx.x; i < (int)(9 * 16 * 16 * sizeof(T) / 16); i += 256) ((uint4*)wl)[i] = ((const uint4*)wk)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int pix = min(gid, total - 1);
+    const int n = pix / (H * W), rem = pix - n * H * W, y = rem / W, xx = rem - y * W;
+    // taps two at a time from two register buffers: the 8 loads of the next tap are in flight under the MFMAs of the
+    // current one (a fully unrolled tap loop lets the compiler hoist all 72 loads and spill)
+    auto load_tap = [&](int t, uint4 (&v)[NV]) -> bool {
+        const int kh = t / 3, kw = t - kh * 3;
+        const int iy = y - 1 + kh, ix = xx - 1 + kw;
+        const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+        const uint4* src = (const uint4*)(act + ((size_t)(n * H + cy) * W + cx) * CI);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = src[i];
+        return iy >= 0 && iy < H && ix >= 0 && ix < W;
+    };
+    float4v acc = {0.f, 0.f, 0.f, 0.f};   // D[i][j]: j = lane & 3 (output channel), i = register (pixel 4 * (lane / 4) + i of the wave)
+    auto mma_tap = [&](int t, const uint4 (&v)[NV], bool ok) {
+        const T* wt = wl + (size_t)t * 16 * 16 + (lane & 3) * 4;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const uint4 u = make_uint4(ok ? v[i].x : 0u, ok ? v[i].y : 0u, ok ? v[i].z : 0u, ok ? v[i].w : 0u);
+            if constexpr (sizeof(T) == 2) {
+                union { uint2 q; short4v s; } a0, a1, b0, b1;
+                a0.q = make_uint2(u.x, u.y); a1.q = make_uint2(u.z, u.w);
+                b0.q = *(const uint2*)(wt + (i * 2 + 0) * 16); b1.q = *(const uint2*)(wt + (i * 2 + 1) * 16);
+                acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a0.s, b0.s, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a1.s, b1.s, acc, 0, 0, 0);
+            } else {
+                const float4 bw = *(const float4*)(wt + i * 16);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(__uint_as_float(u.x), bw.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(__uint_as_float(u.y), bw.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(__uint_as_float(u.z), bw.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(__uint_as_float(u.w), bw.w, acc, 0, 0, 0);
+            }
+        }
+    };
+    uint4 va[NV], vb[NV];
+    bool ma = load_tap(0, va), mb = false;
+#pragma unroll 1
+    for (int t = 0; t < 8; t += 2) {
+        mb = load_tap(t + 1, vb);
+        mma_tap(t, va, ma);
+        ma = load_tap(t + 2, va);
+        mma_tap(t + 1, vb, mb);
+    }
+    mma_tap(8, va, ma);
+    conv_out_ll_tail<T, CO>(acc, bias, x, total, inv_var_B, raw, draw, partial, ticket, D, var_x, B, rec_err, dbias, sm, &is_last);
+}
+
+// The same layer for bf16 images whose width is a multiple of 64: a wave owns 64 consecutive pixels of ONE image row, so
+// the 66-pixel input segment of a kernel row is loaded once, coalesced (whole 128-B lines, 1 KB per instruction instead of
+// 64 separate lines), parked in LDS, and read back per lane for the three horizontal taps.  Rows outside the image are
+// skipped as a whole, columns outside are zero in LDS.
+template <int CO>
+__global__ __launch_bounds__(256) void conv_out_ll_rows(const bf16_t* __restrict__ act, const bf16_t* __restrict__ wk,
+                                                        const float* __restrict__ bias, const float* __restrict__ x, int H, int W,
+                                                        int total, float inv_var_B, float* __restrict__ raw, bf16_t* __restrict__ draw,
+                                                        double* __restrict__ partial, unsigned* __restrict__ ticket, double D,
+                                                        double var_x, double B, double* __restrict__ rec_err, float* __restrict__ dbias) {
+    constexpr int SEG = 66, RV = 9;                    // pixels per segment, uint4 per LDS pixel row (8 data + 1 pad)
+    constexpr int NQ = (SEG * 8 + 63) / 64;            // coalesced 16-B loads per lane and segment
+    __shared__ __attribute__((aligned(16))) bf16_t wl[9 * 16 * 4 * 4];
+    __shared__ uint4 rowbuf[4][SEG * RV];
+    __shared__ double sm[5 * 4];
+    __shared__ int is_last;
+    for (int i = threadIdx.x; i < 9 * 16 * 16 * 2 / 16; i += 256) ((uint4*)wl)[i] = ((const uint4*)wk)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pw0 = min(blockIdx.x * 256 + wave * 64, total - 64);   // total % 64 == 0 (host); a surplus wave redoes the last segment
+    const bool live = blockIdx.x * 256 + wave * 64 < total;
+    const int n = pw0 / (H * W), rem = pw0 - n * H * W, y = rem / W, x0 = rem - y * W;
+    uint4* rb = rowbuf[wave];
+    auto load_seg = [&](int kh, uint4 (&v)[NQ]) -> bool {
+        const int iy = y - 1 + kh;
+        if (iy < 0 || iy >= H) return false;           // wave-uniform
+        const uint4* src = (const uint4*)(act + ((size_t)(n * H + iy) * W) * 64);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = lane + 64 * q, px = e >> 3, part = e & 7, gx = x0 - 1 + px;
+            const bool ok = e < SEG * 8 && gx >= 0 && gx < W;
+            const uint4 t = src[(size_t)min(max(gx, 0), W - 1) * 8 + part];
+            v[q] = make_uint4(ok ? t.x : 0u, ok ? t.y : 0u, ok ? t.z : 0u, ok ? t.w : 0u);
+        }
+        return true;
+    };
+    float4v acc = {0.f, 0.f, 0.f, 0.f};
+    uint4 va[NQ], vb[NQ];
+    bool oka = load_seg(0, va), okb = false;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        uint4 (&cur)[NQ] = (kh & 1) ? vb : va;
+        uint4 (&nxt)[NQ] = (kh & 1) ? va : vb;
+        const bool okc = (kh & 1) ? okb : oka;
+        bool okn = false;
+        if (kh < 2) okn = load_seg(kh + 1, nxt);       // in flight under this row's LDS round trip and MFMAs
+        if (kh & 1) oka = okn; else okb = okn;
+        if (!okc) continue;                            // wave-uniform
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = lane + 64 * q, px = e >> 3, part = e & 7;
+            if (e < SEG * 8) rb[px * RV + part] = cur[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const bf16_t* wt = wl + (size_t)(kh * 3 + kw) * 16 * 16 + (lane & 3) * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint4 u = rb[(lane + kw) * RV + i];
+                union { uint2 q; short4v s; } a0, a1, b0, b1;
+                a0.q = make_uint2(u.x, u.y); a1.q = make_uint2(u.z, u.w);
+                b0.q = *(const uint2*)(wt + (i * 2 + 0) * 16); b1.q = *(const uint2*)(wt + (i * 2 + 1) * 16);
+                acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a0.s, b0.s, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a1.s, b1.s, acc, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!live) acc = float4v{0.f, 0.f, 0.f, 0.f};     // its pixels are >= total in the tail, nothing is stored or summed
+    conv_out_ll_tail<bf16_t, CO>(acc, bias, x, total, inv_var_B, raw, draw, partial, ticket, D, var_x, B, rec_err, dbias, sm, &is_last);
+}
+
+// w [CO][9][64] (dtype) -> wk [9][16][4][4] (dtype): (tap, k / 4, cout (zero for cout >= CO), k % 4)
 template <class T>
-__global__ void conv_out_wprep(const T* __restrict__ w, float* __restrict__ wk, int CO) {
+__global__ void conv_out_wprep(const T* __restrict__ w, T* __restrict__ wk, int CO) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 9 * CO * 64) return;
-    const int ci = i & 63, q = i >> 6, co = q % CO, tap = q / CO;
-    wk[i] = to_f32<T>(w[((size_t)co * 9 + tap) * 64 + ci]);
+    if (i >= 9 * 16 * 16) return;
+    const int kk = i & 3, co = (i >> 2) & 3, kg = (i >> 4) & 15, tap = i >> 8;
+    wk[i] = co < CO ? w[((size_t)co * 9 + tap) * 64 + kg * 4 + kk] : (T)0;
 }
 
 // sigmoid(raw) vs y: per-block partial (sum (y-s)^2, sum y, sum y^2), then one block adds them onto acc3
@@ -1422,22 +1518,23 @@ extern "C" int favae_sigmoid_ll_bias(const float* raw, const float* x, int B, lo
     return FAVAE_OK;
 }
 
-extern "C" int favae_conv_out_wprep(const void* w, float* wk, int Cout, int dtype, void* stream) {
+extern "C" int favae_conv_out_wprep(const void* w, void* wk, int Cout, int dtype, void* stream) {
     FAVAE_CHECK_ARG(w && wk && Cout >= 1 && Cout <= 4 && (dtype == FAVAE_F32 || dtype == FAVAE_BF16), "favae_conv_out_wprep: bad argument");
-    const int n = 9 * Cout * 64;
-    if (dtype == FAVAE_F32) hipLaunchKernelGGL(conv_out_wprep<float>, dim3(cdiv(n, 256)), dim3(256), 0, ST, (const float*)w, wk, Cout);
-    else hipLaunchKernelGGL(conv_out_wprep<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, ST, (const bf16_t*)w, wk, Cout);
+    FAVAE_CHECK_ARG(((uintptr_t)wk % 16) == 0, "favae_conv_out_wprep: 16-byte alignment");
+    const int n = 9 * 16 * 16;
+    if (dtype == FAVAE_F32) hipLaunchKernelGGL(conv_out_wprep<float>, dim3(cdiv(n, 256)), dim3(256), 0, ST, (const float*)w, (float*)wk, Cout);
+    else hipLaunchKernelGGL(conv_out_wprep<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, ST, (const bf16_t*)w, (bf16_t*)wk, Cout);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }
 
-extern "C" int favae_conv_out_ll(const void* act, const float* wk, const float* bias, const float* x, int Nb, int H, int W,
+extern "C" int favae_conv_out_ll(const void* act, const void* wk, const float* bias, const float* x, int Nb, int H, int W,
                                  int Cout, float var_x, float* raw, void* draw, double* rec_err, float* dbias, double* scratch,
                                  size_t scratch_doubles, int dtype, void* stream) {
     FAVAE_CHECK_ARG(act && wk && x && raw && draw && rec_err && scratch && Nb > 0 && H > 0 && W > 0 && var_x > 0, "favae_conv_out_ll: bad argument");
     FAVAE_CHECK_ARG(Cout >= 1 && Cout <= 4, "favae_conv_out_ll: 1..4 output channels");
     FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_conv_out_ll: dtype");
-    FAVAE_CHECK_ARG(((uintptr_t)act % 16) == 0 && (size_t)Nb * H * W < (1u << 31), "favae_conv_out_ll: alignment / size");
+    FAVAE_CHECK_ARG(((uintptr_t)act % 16) == 0 && ((uintptr_t)wk % 16) == 0 && (size_t)Nb * H * W < (1u << 31), "favae_conv_out_ll: alignment / size");
     const int total = Nb * H * W, grid = cdiv(total, 256);
     FAVAE_CHECK_ARG((size_t)grid * 5 <= scratch_doubles, "favae_conv_out_ll: scratch too small (%zu < %zu doubles)", scratch_doubles, (size_t)grid * 5);
     unsigned* ticket = nullptr;
@@ -1446,13 +1543,19 @@ extern "C" int favae_conv_out_ll(const void* act, const float* wk, const float* 
     const float ivb = 1.f / (var_x * (float)Nb);
     const double D = (double)H * W * Cout;
 #define CO_LAUNCH(T_, CO_)                                                                                                   \
-    hipLaunchKernelGGL((conv_out_ll<T_, CO_>), dim3(grid), dim3(256), 0, ST, (const T_*)act, wk, bias, x, H, W, total, ivb, raw, \
+    hipLaunchKernelGGL((conv_out_ll<T_, CO_>), dim3(grid), dim3(256), 0, ST, (const T_*)act, (const T_*)wk, bias, x, H, W, total, ivb, raw, \
                        (T_*)draw, scratch, ticket, D, (double)var_x, (double)Nb, rec_err, dbias)
+#define CO_ROWS(CO_)                                                                                                         \
+    hipLaunchKernelGGL((conv_out_ll_rows<CO_>), dim3(grid), dim3(256), 0, ST, (const bf16_t*)act, (const bf16_t*)wk, bias, x, H, W, total, \
+                       ivb, raw, (bf16_t*)draw, scratch, ticket, D, (double)var_x, (double)Nb, rec_err, dbias)
     if (dtype == FAVAE_F32) {
         switch (Cout) { case 1: CO_LAUNCH(float, 1); break; case 2: CO_LAUNCH(float, 2); break; case 3: CO_LAUNCH(float, 3); break; default: CO_LAUNCH(float, 4); }
+    } else if (W % 64 == 0) {   // a wave = 64 consecutive pixels of one image row
+        switch (Cout) { case 1: CO_ROWS(1); break; case 2: CO_ROWS(2); break; case 3: CO_ROWS(3); break; default: CO_ROWS(4); }
     } else {
         switch (Cout) { case 1: CO_LAUNCH(bf16_t, 1); break; case 2: CO_LAUNCH(bf16_t, 2); break; case 3: CO_LAUNCH(bf16_t, 3); break; default: CO_LAUNCH(bf16_t, 4); }
     }
+#undef CO_ROWS
 #undef CO_LAUNCH
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;

@@ -99,7 +99,7 @@ struct Vae {
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
     unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients, 128 Adam + weight re-layout in one pass, 256 final conv + loss in one launch
     float* xf_alt; char* xt_alt;
-    float* wk_out;   // [9][ch][64] fp32 weights of final_layer.3 for favae_conv_out_ll (rebuilt whenever the layer changes)
+    char* wk_out;   // weights of final_layer.3 in the MFMA operand order for favae_conv_out_ll (rebuilt whenever the layer changes)
     char* fold; size_t fold_bytes;   // [pixels][32] tap-folded operand of the two image-side weight gradients (side stream only)   // second batch buffer: the next gather must not overwrite what wgrad(encoder.0) still reads
     const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(SH + L[l].wc_off * esz); }
     const void* Wt(int l) const { return (const void*)(SH + L[l].wt_off * esz); }
@@ -170,7 +170,7 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
     v.xt = (char*)c.take(img * v.esz);
     v.xf_alt = (float*)c.take(img * 4);
     v.xt_alt = (char*)c.take(img * v.esz);
-    v.wk_out = (float*)c.take(9 * 4 * 64 * 4);
+    v.wk_out = (char*)c.take(9 * 16 * 16 * 4);
     v.fold_bytes = favae_conv_wgrad_folded_scratch(B, 64, 64, v.dtype);
     v.fold = (char*)c.take(v.fold_bytes);
     v.zlat = (char*)c.take((size_t)B * v.z * v.esz);

@@ -157,11 +157,12 @@ int favae_sigmoid_ll_bias(const float* raw, const float* x, int B, long long D, 
                           double* rec_err, float* dbias, double* scratch, size_t scratch_doubles, int dtype, void* stream);
 /* final_layer.3-4 + the loss in one launch (:74-77 Conv2d(64 -> Cout <= 4, k3 s1 p1) + Sigmoid, :152-171 gaussian_LL,
  * :238): raw [Nb,H,W,Cout] = conv output (fp32), draw (dtype) = gradient w.r.t. raw, *rec_err, dbias [Cout] = bias
- * gradient.  act [Nb,H,W,64] dtype; wk = favae_conv_out_wprep of the [Cout][9][64] dtype weights ([9][Cout][64] fp32);
+ * gradient.  act [Nb,H,W,64] dtype; wk = favae_conv_out_wprep of the [Cout][9][64] dtype weights (2304 dtype values in
+ * the operand order of the 4x4x4 MFMA: tap, k/4, cout padded to 4, k%4);
  * x [Nb,H,W,Cout] fp32 targets.  scratch >= 5 * ceil(Nb*H*W / 256) doubles.  Same results as favae_conv_igemm +
  * favae_sigmoid_ll_bias up to fp32 summation order. */
-int favae_conv_out_wprep(const void* w, float* wk, int Cout, int dtype, void* stream);
-int favae_conv_out_ll(const void* act, const float* wk, const float* bias, const float* x, int Nb, int H, int W, int Cout,
+int favae_conv_out_wprep(const void* w, void* wk, int Cout, int dtype, void* stream);
+int favae_conv_out_ll(const void* act, const void* wk, const float* bias, const float* x, int Nb, int H, int W, int Cout,
                       float var_x, float* raw, void* draw, double* rec_err, float* dbias, double* scratch,
                       size_t scratch_doubles, int dtype, void* stream);
 int favae_sigmoid(const float* raw, float* out, long long n, void* stream);

@@ -373,9 +373,11 @@ def test_final_conv_with_loss_in_one_launch(dt, tol, Nb, H, Co):
     (-ll).backward()
     i_, f_, sz_ = ctypes.c_int, ctypes.c_float, ctypes.c_size_t
     wd = w.permute(0, 2, 3, 1).reshape(Co, 9, Cin).contiguous().to(dt).cuda()
-    wk = torch.zeros(9, Co, 64, device="cuda")
+    wk = torch.zeros(9, 16, 4, 4, device="cuda", dtype=dt)
     lib.check(rawl.favae_conv_out_wprep(lib.ptr(wd), lib.ptr(wk), i_(Co), i_(lib.dtype_code(wd)), lib.stream_ptr()))
-    assert torch.equal(wk.cpu(), w.permute(2, 3, 0, 1).reshape(9, Co, Cin).float())
+    want = torch.zeros(9, 16, 4, 4)
+    want[:, :, :Co, :] = w.permute(2, 3, 0, 1).reshape(9, Co, 16, 4).permute(0, 2, 1, 3)
+    assert torch.equal(wk.float().cpu(), want)
     ad, xd, bd = nhwc(a).to(dt).cuda(), nhwc(x).cuda(), b.detach().cuda()
     raw = torch.zeros(Nb, H, H, Co, device="cuda")
     draw = torch.zeros(Nb, H, H, Co, device="cuda", dtype=dt)
