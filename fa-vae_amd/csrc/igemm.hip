@@ -132,7 +132,9 @@ struct KcParams {
     double* red_bins;
     int red_nbin, red_mode;
     const void* red_act;
-    const float *red_raw, *red_mean, *red_invstd;
+    const void* red_raw;   // fp32, or bf16 with red_raw_bf16
+    const float *red_mean, *red_invstd;
+    int red_raw_bf16;
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -370,7 +372,14 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
                         const float4 t = *(const float4*)((const float*)p.red_act + e);
                         a[0] = t.x; a[1] = t.y; a[2] = t.z; a[3] = t.w;
                     }
-                    const float4 x = *(const float4*)(p.red_raw + e);
+                    float4 x;
+                    if (p.red_raw_bf16) {
+                        const uint2 u = *(const uint2*)((const bf16_t*)p.red_raw + e);
+                        x = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                                        __uint_as_float(u.y & 0xffff0000u));
+                    } else {
+                        x = *(const float4*)((const float*)p.red_raw + e);
+                    }
                     const float d0 = v.x * (a[0] > 0.f ? 1.f : 0.01f), d1 = v.y * (a[1] > 0.f ? 1.f : 0.01f);
                     const float d2 = v.z * (a[2] > 0.f ? 1.f : 0.01f), d3 = v.w * (a[3] > 0.f ? 1.f : 0.01f);
                     rs[0] += d0; rs[1] += d1; rs[2] += d2; rs[3] += d3;
@@ -657,7 +666,7 @@ int dispatch_pm(PmParams p, hipStream_t st) {
 }  // namespace
 
 namespace {
-struct RedArgs { double* bins; int nbin, mode; const void* act; const float *raw, *mean, *invstd; int* fused; };
+struct RedArgs { double* bins; int nbin, mode; const void* act; const void* raw; const float *mean, *invstd; int* fused; int raw_bf16; };
 
 int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cin, int Ho,
                     int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk, int dtype, const RedArgs& red,
@@ -684,8 +693,8 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
     if (g_force_kc_tile < 0 && (long long)Nb * Ho * Wo >= 131072 && thin_in_applicable(Cin, Cout, ks, stride, scatter)) {
         ProfScope prof(14, 2.0 * Nb * Ho * Wo * (double)Cout * 9 * Cin, (hipStream_t)stream);
         ThinRed tr{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
-        if (red.bins && red.mode == 2 && !out_bf16) {   // the statistics form (mode 1) is not needed on this path
-            tr = ThinRed{red.bins, red.nbin, red.act, red.raw, red.mean, red.invstd};
+        if (red.bins && red.mode == 2 && !out_bf16 && !red.raw_bf16) {   // the statistics form (mode 1) is not needed on this path
+            tr = ThinRed{red.bins, red.nbin, red.act, (const float*)red.raw, red.mean, red.invstd};
             if (red.fused) *red.fused = 1;
         }
         return thin_in_launch(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, stride, scatter, dtype, out_bf16, tr, (hipStream_t)stream);
@@ -695,7 +704,7 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
     p.Nb = Nb; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
     p.ks = ks; p.stride = stride; p.pad = pad; p.ldw = ks * ks * Cin; p.splitk = splitk; p.out_bf16 = out_bf16;
     p.red_bins = red.bins; p.red_nbin = red.nbin; p.red_mode = red.mode; p.red_act = red.act; p.red_raw = red.raw;
-    p.red_mean = red.mean; p.red_invstd = red.invstd;
+    p.red_mean = red.mean; p.red_invstd = red.invstd; p.red_raw_bf16 = red.raw_bf16;
     int classes = 1;
     if (scatter && stride == 2) { classes = 4; p.HoC = Ho / 2; p.WoC = Wo / 2; }
     else { p.HoC = Ho; p.WoC = Wo; }
@@ -711,19 +720,20 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
 extern "C" int favae_conv_igemm(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi,
                                 int Cin, int Ho, int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk,
                                 int dtype, void* stream) {
-    const RedArgs none{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const RedArgs none{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     return conv_igemm_impl(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype, none, stream);
 }
 
 extern "C" int favae_conv_igemm_red(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi,
                                     int Cin, int Ho, int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk,
-                                    int dtype, double* bins, int nbins, int mode, const void* act, const float* raw,
+                                    int dtype, double* bins, int nbins, int mode, const void* act, const void* raw,
                                     const float* mean, const float* invstd, int* fused, void* stream) {
     FAVAE_CHECK_ARG(bins && fused && nbins >= 1 && nbins <= 256, "favae_conv_igemm_red: bins / fused / nbins");
     FAVAE_CHECK_ARG(mode == 1 || (mode == 2 && act && raw && mean && invstd), "favae_conv_igemm_red: mode 1, or mode 2 with act/raw/mean/invstd");
-    FAVAE_CHECK_ARG(!(dtype & FAVAE_OUT_BF16), "favae_conv_igemm_red: fp32 output only");
-    const RedArgs red{bins, nbins, mode, act, raw, mean, invstd, fused};
-    return conv_igemm_impl(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype, red, stream);
+    const int raw_bf16 = (dtype & FAVAE_RAW_BF16) != 0;
+    FAVAE_CHECK_ARG(!(raw_bf16 && (dtype & 0xF) != FAVAE_BF16), "favae_conv_igemm_red: FAVAE_RAW_BF16 needs FAVAE_BF16");
+    const RedArgs red{bins, nbins, mode, act, raw, mean, invstd, fused, raw_bf16};
+    return conv_igemm_impl(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype & ~FAVAE_RAW_BF16, red, stream);
 }
 
 extern "C" int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const void* cols, int Cc, int cols_large,

@@ -310,8 +310,8 @@ inline bool bins_applicable(int C) { return C % 4 == 0 && C <= 256 && (2 * C <= 
 
 // BN(train) + LeakyReLU forward whose statistics were accumulated by the producing GEMM's epilogue (sum, sum of squares
 // per channel in `bins`): every block derives mean / invstd itself, block 0 also publishes them and the running stats.
-template <class T>
-__global__ __launch_bounds__(256) void bn_lrelu_fwd_bins(const float* __restrict__ raw, const double* __restrict__ bins, int nbin,
+template <class T, class RT>
+__global__ __launch_bounds__(256) void bn_lrelu_fwd_bins(const RT* __restrict__ raw, const double* __restrict__ bins, int nbin,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          T* __restrict__ act, float* __restrict__ mean, float* __restrict__ invstd,
                                                          float* __restrict__ run_mean, float* __restrict__ run_var, size_t nvec,
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void bn_lrelu_fwd_bins(const float* __restrict
 #pragma unroll 4
     for (size_t i = i0; i < nvec; i += stride) {
         float x[4];
-        VecLoad<float, 4>::ld(raw + i * 4, x);
+        VecLoad<RT, 4>::ld(raw + i * 4, x);
         store4<T>(act + i * 4, lrelu(x[0] * a[0] + b[0]), lrelu(x[1] * a[1] + b[1]), lrelu(x[2] * a[2] + b[2]), lrelu(x[3] * a[3] + b[3]));
     }
 }
@@ -1343,25 +1343,31 @@ extern "C" int favae_bn_train_fwd(const void* raw, const float* gamma, const flo
     return favae_bn_lrelu_fwd(raw, mean, invstd, gamma, beta, act, R, C, 1, dtype, stream);
 }
 
-extern "C" int favae_bn_train_fwd_bins(const float* raw, const double* bins, int nbins, const float* gamma, const float* beta,
+extern "C" int favae_bn_train_fwd_bins(const void* raw, const double* bins, int nbins, const float* gamma, const float* beta,
                                        void* act, float* mean, float* invstd, float* run_mean, float* run_var, long long R,
                                        int C, float eps, float momentum, int dtype, void* stream) {
     FAVAE_CHECK_ARG(raw && bins && gamma && beta && act && mean && invstd && R > 0 && R < (1LL << 31) && nbins >= 1,
                     "favae_bn_train_fwd_bins: bad argument");
     FAVAE_CHECK_ARG(bins_applicable(C), "favae_bn_train_fwd_bins: C = %d not supported (64, 128, 256 ...)", C);
-    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_bn_train_fwd_bins: dtype");
+    FAVAE_CHECK_ARG(DT_BASE(dtype) == FAVAE_F32 || DT_BASE(dtype) == FAVAE_BF16, "favae_bn_train_fwd_bins: dtype");
+    FAVAE_CHECK_ARG(!(RAW_IS_BF16(dtype) && DT_BASE(dtype) != FAVAE_BF16), "favae_bn_train_fwd_bins: FAVAE_RAW_BF16 needs FAVAE_BF16");
     const size_t nvec = (size_t)R * C / 4;
     int c4 = C / 4, gg = c4, t = 256;
     while (t) { const int r = gg % t; gg = t; t = r; }
     const int mult = c4 / gg;
     long long grid = (long long)std::min<size_t>(2048, (nvec + 255) / 256);
     grid = std::max<long long>(mult, grid / mult * mult);
-    if (dtype == FAVAE_F32)
-        hipLaunchKernelGGL(bn_lrelu_fwd_bins<float>, dim3((unsigned)grid), dim3(256), 0, ST, raw, bins, nbins, gamma, beta, (float*)act,
+#define FB_ARGS bins, nbins, gamma, beta
+    if (DT_BASE(dtype) == FAVAE_F32)
+        hipLaunchKernelGGL((bn_lrelu_fwd_bins<float, float>), dim3((unsigned)grid), dim3(256), 0, ST, (const float*)raw, FB_ARGS, (float*)act,
+                           mean, invstd, run_mean, run_var, nvec, C, (double)R, eps, momentum);
+    else if (RAW_IS_BF16(dtype))
+        hipLaunchKernelGGL((bn_lrelu_fwd_bins<bf16_t, bf16_t>), dim3((unsigned)grid), dim3(256), 0, ST, (const bf16_t*)raw, FB_ARGS, (bf16_t*)act,
                            mean, invstd, run_mean, run_var, nvec, C, (double)R, eps, momentum);
     else
-        hipLaunchKernelGGL(bn_lrelu_fwd_bins<bf16_t>, dim3((unsigned)grid), dim3(256), 0, ST, raw, bins, nbins, gamma, beta, (bf16_t*)act,
+        hipLaunchKernelGGL((bn_lrelu_fwd_bins<bf16_t, float>), dim3((unsigned)grid), dim3(256), 0, ST, (const float*)raw, FB_ARGS, (bf16_t*)act,
                            mean, invstd, run_mean, run_var, nvec, C, (double)R, eps, momentum);
+#undef FB_ARGS
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }
@@ -1386,22 +1392,32 @@ static int bn_bwd_impl(const void* dact_, const void* act_, const void* raw_, co
                                                    nullptr, 0, nullptr, nullptr}, st);
 }
 
-extern "C" int favae_bn_lrelu_bwd_bins(const float* dact, const void* act, const float* raw, const float* mean,
+template <class T, class RT, class DT>
+static int bn_bwd_bins_impl(const void* dact, const void* act, const void* raw, const float* mean, const float* invstd,
+                            const float* gamma, const double* bins, int nbins, void* draw, float* dgamma, float* dbeta,
+                            float* dbias, long long R, int C, double* scratch, size_t cap, hipStream_t st) {
+    return run_colreduce<1>(R, C, scratch, cap,
+                            BnBwdApplyF<T, RT, DT>{(const DT*)dact, (const T*)act, (const RT*)raw, mean, invstd, gamma, nullptr, (T*)draw, C,
+                                                   (float)(1.0 / (double)R), dbias, bins, nbins, dgamma, dbeta}, st);
+}
+
+extern "C" int favae_bn_lrelu_bwd_bins(const void* dact, const void* act, const void* raw, const float* mean,
                                        const float* invstd, const float* gamma, const double* bins, int nbins, void* draw,
                                        float* dgamma, float* dbeta, float* dbias, long long R, int C, double* scratch,
                                        size_t scratch_doubles, int dtype, void* stream) {
     FAVAE_CHECK_ARG(dact && act && raw && mean && invstd && gamma && bins && draw && dgamma && dbeta && scratch && nbins >= 1,
                     "favae_bn_lrelu_bwd_bins: null pointer");
     FAVAE_CHECK_ARG(R > 0 && R < (1LL << 31) && C > 0, "favae_bn_lrelu_bwd_bins: bad shape");
-    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_bn_lrelu_bwd_bins: dtype");
-    const float invR = (float)(1.0 / (double)R);
-    if (dtype == FAVAE_F32)
-        return run_colreduce<1>(R, C, scratch, scratch_doubles,
-                                BnBwdApplyF<float, float, float>{dact, (const float*)act, raw, mean, invstd, gamma, nullptr, (float*)draw, C,
-                                                                 invR, dbias, bins, nbins, dgamma, dbeta}, ST);
-    return run_colreduce<1>(R, C, scratch, scratch_doubles,
-                            BnBwdApplyF<bf16_t, float, float>{dact, (const bf16_t*)act, raw, mean, invstd, gamma, nullptr, (bf16_t*)draw, C,
-                                                              invR, dbias, bins, nbins, dgamma, dbeta}, ST);
+    FAVAE_CHECK_ARG(DT_BASE(dtype) == FAVAE_F32 || DT_BASE(dtype) == FAVAE_BF16, "favae_bn_lrelu_bwd_bins: dtype");
+    FAVAE_CHECK_ARG(!((RAW_IS_BF16(dtype) || DACT_IS_BF16(dtype)) && (DT_BASE(dtype) != FAVAE_BF16 || C % 4 != 0)),
+                    "favae_bn_lrelu_bwd_bins: FAVAE_RAW_BF16 / FAVAE_DACT_BF16 need FAVAE_BF16 and C %% 4 == 0");
+#define BB_ARGS dact, act, raw, mean, invstd, gamma, bins, nbins, draw, dgamma, dbeta, dbias, R, C, scratch, scratch_doubles, ST
+    if (DT_BASE(dtype) == FAVAE_F32) return bn_bwd_bins_impl<float, float, float>(BB_ARGS);
+    if (RAW_IS_BF16(dtype) && DACT_IS_BF16(dtype)) return bn_bwd_bins_impl<bf16_t, bf16_t, bf16_t>(BB_ARGS);
+    if (RAW_IS_BF16(dtype)) return bn_bwd_bins_impl<bf16_t, bf16_t, float>(BB_ARGS);
+    if (DACT_IS_BF16(dtype)) return bn_bwd_bins_impl<bf16_t, float, bf16_t>(BB_ARGS);
+    return bn_bwd_bins_impl<bf16_t, float, float>(BB_ARGS);
+#undef BB_ARGS
 }
 
 extern "C" int favae_bn_lrelu_bwd(const void* dact, const void* act, const void* raw, const float* mean,

@@ -117,8 +117,11 @@ struct Carver {
 };
 
 void choose_storage(Vae& v) {
-    // Off by default: measured on MI355X the bf16 storage of raw/dact does not shorten the BN kernels of these layers (they
-    // are bound by launch geometry, not by bytes), so the extra rounding buys nothing.  FAVAE_BF16_RAW=1 turns it on.
+    // Optional (FAVAE_BF16_RAW=1, bf16 executor only): the conv output (raw) and the activation gradient (dact) of the BN
+    // layers with >= 4 M elements per batch are stored as bf16; the BN statistics / backward sums still come from the
+    // fp32 accumulators of the producing GEMM.  Off by default: measured on MI355X it shortens the step by 0.3 % only
+    // (these tensors live in the 256 MB Infinity Cache between producer and consumer, so halving their bytes buys little),
+    // which does not pay for the extra rounding.
     const char* e = getenv("FAVAE_BF16_RAW");
     const bool off = v.dtype != FAVAE_BF16 || !(e && e[0] == '1');
     for (int l = 0; l < NL; ++l) {
@@ -197,7 +200,7 @@ int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false
     const int sk = (pooled && v.raw_pooled[l]) ? -1 : 0;
     const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_OUT_BF16 : 0);
     v.stats_fused[l] = false;
-    if (pooled && (v.fuse & 1u) && v.sbins[l] && !v.raw_bf[l] && L.kind != LINEAR) {
+    if (pooled && (v.fuse & 1u) && v.sbins[l] && L.kind != LINEAR) {
         // training step: the zero pool (and with it sbins) was cleared at the start of the step; take the BN statistics
         // in the GEMM epilogue where this shape runs unsplit
         const int scatter = L.kind == CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
@@ -226,7 +229,7 @@ int bn_fwd(Vae& v, int l, int B, bool train, void* st) {
     if (train && v.stats_fused[l]) {
         v.stats_fused[l] = false;
         return favae_bn_train_fwd_bins(v.raw[l], v.sbins[l], bins_for(R), v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l],
-                                       v.invstd[l], v.BUF + L.rm_off, v.BUF + L.rv_off, R, L.Cout, 1e-5f, 0.1f, v.dtype, st);
+                                       v.invstd[l], v.BUF + L.rm_off, v.BUF + L.rv_off, R, L.Cout, 1e-5f, 0.1f, dt, st);
     }
     if (train)
         return favae_bn_train_fwd(v.raw[l], v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l], v.invstd[l], v.BUF + L.rm_off,
@@ -266,7 +269,8 @@ int bn_bwd(Vae& v, int l, int B, void* st) {
         v.grad_fused[l] = false;
         return favae_bn_lrelu_bwd_bins(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.gbins[l],
                                        bins_for(v.rows(l, B)), v.draw[l], v.G + L.g_off, v.G + L.be_off, v.G + L.b_off,
-                                       v.rows(l, B), L.Cout, v.scratch, v.scratch_doubles, v.dtype, st);
+                                       v.rows(l, B), L.Cout, v.scratch, v.scratch_doubles,
+                                       v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0) | (v.dact_bf[l] ? FAVAE_DACT_BF16 : 0), st);
     }
     return favae_bn_lrelu_bwd(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.draw[l], v.G + L.g_off,
                               v.G + L.be_off, v.G + L.b_off, v.rows(l, B), L.Cout, v.scratch, v.scratch_doubles, v.s1s2,
@@ -350,11 +354,12 @@ int dgrad(Vae& v, int l, float* out, int B, void* st, bool out_zeroed, bool out_
     const Layer& L = v.L[l];
     const int sk = out_zeroed ? -1 : 0;
     const int dt = v.dtype | (out_bf ? FAVAE_OUT_BF16 : 0);
-    if (o >= 0 && (v.fuse & (l == L_OUT ? 4u : 2u)) && v.gbins[o] && !out_bf && !v.raw_bf[o] && L.kind != LINEAR) {
+    if (o >= 0 && (v.fuse & (l == L_OUT ? 4u : 2u)) && v.gbins[o] && L.kind != LINEAR) {
         const int scatter = L.kind != CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
         int fused = 0;
         RC(favae_conv_igemm_red(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, stride, 1, scatter,
-                                sk, dt, v.gbins[o], bins_for(v.rows(o, B)), 2, v.act[o], v.raw[o], v.mean[o], v.invstd[o], &fused, st));
+                                sk, dt | (v.raw_bf[o] ? FAVAE_RAW_BF16 : 0), v.gbins[o], bins_for(v.rows(o, B)), 2, v.act[o], v.raw[o],
+                                v.mean[o], v.invstd[o], &fused, st));
         v.grad_fused[o] = fused != 0;
         return FAVAE_OK;
     }

@@ -56,10 +56,12 @@ int favae_conv_igemm(const void* in, const void* w, const float* bias, float* ou
  *           shape as out): bins[b][0][c] += sum dd, bins[b][1][c] += sum dd * (raw - mean) * invstd, dd = y * lrelu'(act).
  * bins: [nbins][2][Cout] doubles, zeroed by the caller; tiles spread over the bins (fp64 atomics), the consumer adds
  * them up (favae_bn_train_fwd_bins / favae_bn_lrelu_bwd_bins).  *fused = 1 if the launch took the sums, 0 if this shape
- * runs with a split reduction or a tile without that epilogue (then bins is untouched and the caller reduces itself). */
+ * runs with a split reduction or a tile without that epilogue (then bins is untouched and the caller reduces itself).
+ * dtype may carry FAVAE_OUT_BF16 (out stored as bf16; the sums are taken from the fp32 accumulators) and, for mode 2,
+ * FAVAE_RAW_BF16 (raw is stored as bf16). */
 int favae_conv_igemm_red(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cin,
                          int Ho, int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk, int dtype,
-                         double* bins, int nbins, int mode, const void* act, const float* raw, const float* mean,
+                         double* bins, int nbins, int mode, const void* act, const void* raw, const float* mean,
                          const float* invstd, int* fused, void* stream);
 
 /* Weight gradient  dw[r][tap][c] += sum_pixels rows[pix][r] * cols[pix'][c]  (fp32 atomics; caller zeroes dw).
@@ -109,8 +111,9 @@ int favae_bn_lrelu_fwd(const void* raw, const float* mean, const float* invstd, 
 int favae_bn_train_fwd(const void* raw, const float* gamma, const float* beta, void* act, float* mean, float* invstd,
                        float* run_mean, float* run_var, long long R, int C, float eps, float momentum, double* scratch,
                        size_t scratch_doubles, int dtype, void* stream);
-/* favae_bn_train_fwd with the statistics already summed by favae_conv_igemm_red (mode 1) into bins [nbins][2][C]. */
-int favae_bn_train_fwd_bins(const float* raw, const double* bins, int nbins, const float* gamma, const float* beta,
+/* favae_bn_train_fwd with the statistics already summed by favae_conv_igemm_red (mode 1) into bins [nbins][2][C]; raw fp32,
+ * or bf16 with FAVAE_RAW_BF16 in dtype. */
+int favae_bn_train_fwd_bins(const void* raw, const double* bins, int nbins, const float* gamma, const float* beta,
                             void* act, float* mean, float* invstd, float* run_mean, float* run_var, long long R, int C,
                             float eps, float momentum, int dtype, void* stream);
 /* backward of BN(train)+LeakyReLU (autograd of :34-35 under loss.backward() :249): draw (dtype) = d loss / d raw,
@@ -120,8 +123,8 @@ int favae_bn_lrelu_bwd(const void* dact, const void* act, const void* raw, const
                        const float* gamma, void* draw, float* dgamma, float* dbeta, float* dbias, long long R, int C,
                        double* scratch, size_t scratch_doubles, float* s1s2, int dtype, void* stream);
 /* favae_bn_lrelu_bwd with its two reductions already summed by favae_conv_igemm_red (mode 2) into bins [nbins][2][C]:
- * one pass (draw, dbias) instead of two; dact and raw fp32. */
-int favae_bn_lrelu_bwd_bins(const float* dact, const void* act, const float* raw, const float* mean, const float* invstd,
+ * one pass (draw, dbias) instead of two; dact / raw fp32, or bf16 with FAVAE_DACT_BF16 / FAVAE_RAW_BF16 in dtype. */
+int favae_bn_lrelu_bwd_bins(const void* dact, const void* act, const void* raw, const float* mean, const float* invstd,
                             const float* gamma, const double* bins, int nbins, void* draw, float* dgamma, float* dbeta,
                             float* dbias, long long R, int C, double* scratch, size_t scratch_doubles, int dtype,
                             void* stream);
