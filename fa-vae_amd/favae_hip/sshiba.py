@@ -77,7 +77,7 @@ class HyperParameters(object):
 
 
 class Qdistribution(object):
-    """reference :1883-2063 (non-sparse, no semi-supervision): containers + the two mean helpers."""
+    """reference :1883-2063 (non-sparse): containers + the two mean helpers; XS = X* of semi-supervised 'reg' views."""
 
     def __init__(self, X, n, n_max, d, Kc, m, hyper):
         self.n, self.n_max, self.d, self.Kc, self.m, self.X = n, n_max, d, Kc, m, X
@@ -87,7 +87,8 @@ class Qdistribution(object):
         blank = lambda: dict(mean=None, cov=None, prodT=None, LH=0, Elogp=0)
         self.W = [blank() for _ in range(m)]
         self.b = [blank() for _ in range(m)]
-        self.XS, self.tS = [blank() for _ in range(m)], [blank() for _ in range(m)]
+        self.XS, self.tS = [LazyDict(blank()) for _ in range(m)], [blank() for _ in range(m)]
+        self.tc = {}
         self.Z = LazyDict(blank())
         self.xi = [None] * m
 
@@ -139,7 +140,7 @@ class SSHIBA(object):
         d = self.d[m]
         xtx1 = dist.sum_(fa.atb(Xd, Xd, True, self.sc))
         prod = xtx1[:, :d].cpu().numpy()
-        if self.method[m] != "reg":
+        if self.method[m] != "reg" or self.SS[m]:
             csum = dist.sum_(fa.atb(X.dev("cov", self.dev), None, True, self.sc)).cpu().numpy().ravel()
             prod = prod + np.diag(csum)
         dict.__setitem__(X, "prodT", prod)
@@ -179,8 +180,8 @@ class SSHIBA(object):
             if arg.get("SV") is not None or arg.get("sparse") or meth not in ("reg", "img", "mult"):
                 raise NotImplementedError("view %d: kernel / sparse / '%s' views are outside the FA-VAE hot path" % (m, meth))
             self.n.append(int(arg["data"].shape[0]))
-            if self.n[m] != self.n_loc:
-                raise NotImplementedError("semi-supervised views (unequal N) are outside the FA-VAE hot path")
+            if self.n[m] != self.n_loc and (meth != "reg" or dist.active()):
+                raise NotImplementedError("views with fewer rows: only 'reg' views, single process (pass NaN rows instead)")
             if meth == "reg":
                 self.d.append(int(arg["data"].shape[1]))
             elif meth == "img":
@@ -197,11 +198,34 @@ class SSHIBA(object):
                             prodT=np.dot(mn.T, mn), LH=0, Elogp=0, sumlogdet=0, epochs=20)
             self.X.append(info)
             data = arg["data"] if meth == "img" else copy.deepcopy(arg["data"])      # images are read-only here
-            if meth == "reg":
+            if meth == "reg":                                                                        # :236-257
                 info["data"] = data
-                info["mean"] = np.copy(data).astype(np.float64)
-                info["cov"] = np.zeros(info["mean"].shape)
-                self.SS_mask[m] = np.isnan(info["mean"])
+                mean = np.copy(data).astype(np.float64)
+                if self.n_loc > self.n[m]:
+                    mean = np.vstack((mean, np.nan * np.ones((self.n_loc - self.n[m], d))))
+                mask = np.isnan(mean)
+                self.SS_mask[m] = mask
+                if dist.sum_scalar(float(mask.sum()), self.dev) > 0:                                 # semi-supervised view
+                    self.SS[m] = True
+                    if dist.active():
+                        raise NotImplementedError("semi-supervised 'reg' views: the initial imputation statistics (:251) are "
+                                                  "per data set, not per shard; single process only")
+                    for dd in range(d):
+                        cnt = int(np.sum(mask[:, dd]))
+                        if cnt == mask.shape[0]:
+                            mean[mask[:, dd], dd] = np.random.normal(0.0, 1.0, cnt)
+                        else:
+                            mean[mask[:, dd], dd] = np.random.normal(np.nanmean(mean[:, dd], axis=0), np.nanstd(mean[:, dd], axis=0), cnt)
+                    cov = np.copy(info["cov"])
+                    cov[~mask] = 0.0                                                                 # unobserved entries keep mn**2 (:179)
+                    info["mean"], info["cov"] = mean, cov
+                    self._ss_mask_dev = getattr(self, "_ss_mask_dev", {})
+                    self._ss_mask_dev[m] = torch.from_numpy(mask).to(self.dev)
+                    self._ss_count = getattr(self, "_ss_count", {})
+                    self._ss_count[m] = float(mask.sum())
+                else:
+                    info["mean"] = mean
+                    info["cov"] = np.zeros(mean.shape)
             elif meth == "img":
                 self.keep_training.append(True)
                 self.t[m] = dict(data=data, epochs=arg["epochs"], LH=0, Elogp=0, sumlogdet=0)
@@ -233,6 +257,13 @@ class SSHIBA(object):
         q.Z["prodT"] = q.Z["cov"] + self.n_max * q.Z["cov"]
         self._refresh_zstats()
         for m in range(self.m):
+            if self.SS[m]:                                                                           # :1963-1970, same draws
+                q.tc[m] = np.random.rand(self.n_loc, self.d[m])
+                q.tS[m]["mean"] = np.random.randint(2, size=[self.n_loc, self.d[m]])
+                q.tS[m]["cov"] = np.eye(self.d[m])
+                q.tS[m]["sumlogdet"] = 0
+                q.XS[m]["mean"] = np.random.normal(0.0, 1.0, self.n_loc * self.d[m]).reshape(self.n_loc, self.d[m])
+                q.XS[m]["cov"] = np.zeros((self.n_loc, self.d[m]))
             W = q.W[m]
             W["mean"] = np.random.normal(np.zeros((self.d[m], self.Kc)),
                                          1 / (np.repeat(q.alpha_mean(m).reshape(1, self.Kc), self.d[m], axis=0)))
@@ -241,7 +272,7 @@ class SSHIBA(object):
             W["cov"] = np.dot(W["mean"].T, W["mean"])
             W["prodT"] = np.dot(W["mean"].T, W["mean"]) + self.Kc * W["cov"]
             self._refresh_xstats(m)
-            self.update_b(m)                                                                         # :1986-1988
+            self.update_b(m, n=self.n[m] if self.n[m] != self.n_loc else None)                       # :1986-1988 (n[m], not n_max)
         if self.VARIANT == "A":
             if not kwargs["pretrained"]:                                                             # :378 (KeyError if absent)
                 self.fit_iterate(**kwargs)
@@ -283,6 +314,8 @@ class SSHIBA(object):
         for m in range(self.m):
             meth = self.method[m]
             if meth == "reg":
+                if self.SS[m]:
+                    self.update_xs(m)                                                                # :775-783
                 self.update_tau(m)
                 self.update_b(m)
             if meth == "img":
@@ -554,11 +587,27 @@ class SSHIBA(object):
                 q.Z["prodT_pred"].append(fa.axpby(1.0, zz, float(self.n_max), covs_pred[m]).cpu().numpy())
             q.Z["mean_pred"] = _PredList(q.Z, self.m)
 
-    def update_b(self, m):
-        """:1077-1092"""
+    def update_xs(self, m):
+        """X* of a semi-supervised 'reg' view (:1157-1174) and its write-back into X (:778-783): the unobserved entries take
+        Z W^T + b as mean and 1/tau as variance; the statistics of X are refreshed for update_tau / update_b / update_w."""
+        q = self.q_dist
+        X, XS = self.X[m], q.XS[m]
+        tau = self._tau(m)
+        xs = torch.empty(self.n_loc, self.d[m], dtype=F64, device=self.dev)
+        fa.rows_gemm(q.Z.dev("mean", self.dev), self._up(q.W[m]["mean"].T), self._up(np.ravel(q.b[m]["mean"])), 1.0, None, 0.0, xs)
+        XS.set_dev("mean", xs)
+        dict.__setitem__(XS, "cov", (1.0 / tau) * np.eye(self.d[m]))
+        mask = self._ss_mask_dev[m]
+        X.set_dev("mean", torch.where(mask, xs, X.dev("mean", self.dev)))                            # masked copy (data movement)
+        X.set_dev("cov", X.dev("cov", self.dev).masked_fill(mask, 1.0 / tau))
+        self._refresh_xstats(m)
+        dict.__setitem__(X, "sumlogdet", dist.sum_scalar(self._ss_count[m], self.dev) * math.log(1.0 / tau))   # :781-783
+
+    def update_b(self, m, n=None):
+        """:1077-1092 (n: the view's own row count for the initial b, :1986)"""
         q = self.q_dist
         bmean = torch.empty(self.d[m], dtype=F64, device=self.dev)
-        fa.b_update(self._xsum[m], self._zsum, self._up(q.W[m]["mean"]), self._tau(m), self.n_max, bmean, self.scal)
+        fa.b_update(self._xsum[m], self._zsum, self._up(q.W[m]["mean"]), self._tau(m), self.n_max if n is None else n, bmean, self.scal)
         sc = self.scal.cpu().numpy()
         b = q.b[m]
         b["cov"] = sc[0] * np.eye(self.d[m])
@@ -625,6 +674,10 @@ class SSHIBA(object):
                 H = 0.5 * self.X[m]["sumlogdet"]
                 dict.__setitem__(self.X[m], "LH", self.X[m]["LH"] if abs(H) == np.inf else H)
                 ent = ent + self.X[m]["LH"]
+            if self.SS[m] and self.method[m] == "reg":                                               # :1651-1653, 1666-1668
+                H = 0.5 * self.X[m]["sumlogdet"]
+                dict.__setitem__(q.XS[m], "LH", q.XS[m]["LH"] if abs(H) == np.inf else H)
+                ent = ent + q.XS[m]["LH"]
         q.Z["Elogp"] = -0.5 * np.trace(q.Z["prodT"])
         elogp = q.Z["Elogp"]
         for m in range(self.m):
@@ -687,7 +740,7 @@ class SSHIBA(object):
     # ---- pickling ----------------------------------------------------------------------------------------------------
     def __getstate__(self):
         st = self.__dict__.copy()
-        for k in ("sc", "scal", "_zsum", "_xsum", "dev"):
+        for k in ("sc", "scal", "_zsum", "_xsum", "dev", "_ss_mask_dev"):
             st.pop(k, None)
         if "q_dist" in st:
             xi = st["q_dist"].xi

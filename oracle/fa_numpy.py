@@ -3,7 +3,7 @@ oracle/__init__.py).  Citations are path:line under /root/reference; "cA" = cond
 "DA" = domain_adaptation.
 
 Only the branches the four reference trainers exercise are restated ('reg', 'mult', 'img' views; no sparse,
-kernel, categorical or semi-supervised paths -- SURVEY.md section 2 row 13).
+kernel, categorical or semi-supervised multilabel paths -- SURVEY.md section 2 row 13; semi-supervised 'reg' views are in).
 """
 import math
 import sys
@@ -62,10 +62,11 @@ class Hyper:
 
 
 class QDist:
-    """cA/favae.py:1883-2051, the parts reached with sparse=0, no SS, no *_init."""
+    """cA/favae.py:1883-2051, the parts reached with sparse=0, no *_init; SS = semi-supervised 'reg' views (:1963-1970)."""
 
-    def __init__(self, X, n, n_max, d, Kc, m, method, hyper):
+    def __init__(self, X, n, n_max, d, Kc, m, method, hyper, SS=None):
         self.n, self.n_max, self.d, self.Kc, self.m, self.X = n, n_max, d, Kc, m, X
+        self.SS = SS if SS is not None else [False] * m
         self.alpha = [dict(a=hyper.alpha_a[i], b=hyper.alpha_b[i] * np.ones(Kc), LH=None, ElogpWalp=None)
                       for i in range(m)]
         self.tau = [dict(a=hyper.tau_a[i], b=hyper.tau_b[i] * np.ones(1), LH=None, ElogpXtau=None)
@@ -74,12 +75,22 @@ class QDist:
         blank = lambda: dict(mean=None, cov=None, prodT=None, LH=0, Elogp=0)
         self.b = [blank() for _ in range(m)]
         self.W = [blank() for _ in range(m)]
+        self.XS = [blank() for _ in range(m)]
+        self.tS = [blank() for _ in range(m)]
+        self.tc = {}
         Z = blank()
         Z["mean"] = np.random.normal(0.0, 1.0, n_max * Kc).reshape(n_max, Kc)            # :1948
         Z["cov"] = np.eye(Kc)
         Z["prodT"] = Z["cov"] + n_max * Z["cov"]                                        # :1950
         self.Z = Z
         for i in range(m):
+            if self.SS[i]:                                                               # :1963-1970 (same draws, same order)
+                self.tc[i] = np.random.rand(n_max, d[i])
+                self.tS[i]["mean"] = np.random.randint(2, size=[n_max, d[i]])
+                self.tS[i]["cov"] = np.eye(d[i])
+                self.tS[i]["sumlogdet"] = 0
+                self.XS[i]["mean"] = np.random.normal(0.0, 1.0, n_max * d[i]).reshape(n_max, d[i])
+                self.XS[i]["cov"] = np.zeros(self.XS[i]["mean"].shape)
             W = self.W[i]
             scale = 1 / np.repeat(self.alpha_mean(i).reshape(1, Kc), d[i], axis=0)
             W["mean"] = np.random.normal(np.zeros((d[i], Kc)), scale)                    # :1977
@@ -125,6 +136,7 @@ class SSHIBAOracle:
         self.n_max = int(np.max(self.n))
         self.m = len(views)
         self.d, self.method, self.X, self.t = [], [], [], {}
+        self.SS, self.SS_mask = [], {}
         self.img_vae = [None] * self.m
         self.keep_training = {}
         self.total_elbo, self.kl_q_p, self.recon_loss = [], [], []
@@ -150,14 +162,32 @@ class SSHIBAOracle:
             if meth == "reg":                                                            # :236-257
                 info["data"] = data
                 info["mean"] = np.copy(data)
-                info["cov"] = np.zeros(info["mean"].shape)
+                if self.n_max > self.n[m]:                                               # fewer rows: the rest is unobserved
+                    info["mean"] = np.vstack((info["mean"], np.nan * np.ones((self.n_max - self.n[m], d))))
+                mask = np.isnan(info["mean"])
+                self.SS_mask[m] = mask
+                if np.sum(mask) > 0:                                                     # semi-supervised view
+                    self.SS.append(True)
+                    for dd in range(d):
+                        cnt = int(np.sum(mask[:, dd]))
+                        if cnt == mask.shape[0]:
+                            info["mean"][mask[:, dd], dd] = np.random.normal(0.0, 1.0, cnt)
+                        else:
+                            info["mean"][mask[:, dd], dd] = np.random.normal(np.nanmean(info["mean"][:, dd], axis=0),
+                                                                             np.nanstd(info["mean"][:, dd], axis=0), cnt)
+                    info["cov"][~mask] = 0.0                                             # the rest keeps its random init (:179)
+                else:
+                    self.SS.append(False)
+                    info["cov"] = np.zeros(info["mean"].shape)
             elif meth == "img":                                                          # :260-267
+                self.SS.append(False)
                 self.keep_training[m] = True
                 self.t[m] = copy.deepcopy(info)
                 self.t[m]["data"] = data
                 self.img_vae[m] = self.vae_factory(dimx=v["latent_dim"], channels=data.shape[1], lr=v["lr"],
                                                    dataset=v["dataset"], latentspace_lr=self.latentspace_lr)
             elif meth == "mult":                                                         # :269-346
+                self.SS.append(False)
                 self.t[m] = copy.deepcopy(info)
                 self.t[m]["data"] = data
                 tt = np.abs(data.astype(float) - 0.05)
@@ -168,7 +198,7 @@ class SSHIBAOracle:
         self.L = []
         self.metrics = {}
         self.hyper = Hyper(self.m)
-        self.q_dist = QDist(self.X, self.n, self.n_max, self.d, self.Kc, self.m, self.method, self.hyper)
+        self.q_dist = QDist(self.X, self.n, self.n_max, self.d, self.Kc, self.m, self.method, self.hyper, self.SS)
         if iterate:
             self.fit_iterate(max_iter=max_iter, pruning_crit=pruning_crit)
 
@@ -197,7 +227,17 @@ class SSHIBAOracle:
         for m in range(self.m):
             meth = self.method[m]
             if meth == "reg":
-                self.X[m]["prodT"] = self.X[m]["mean"].T @ self.X[m]["mean"]           # :785
+                if self.SS[m]:                                                           # :775-783
+                    X, mask = self.X[m], self.SS_mask[m]
+                    self.update_xs(m)
+                    X["mean"][mask] = q.XS[m]["mean"][mask]
+                    X["cov"][mask] = q.XS[m]["cov"][0, 0]
+                    X["prodT"] = X["mean"].T @ X["mean"] + np.diag(np.sum(X["cov"], axis=0))
+                    X_SS = np.copy(X["cov"])
+                    X_SS[~mask] = 1
+                    X["sumlogdet"] = np.sum(np.log(X_SS))
+                else:
+                    self.X[m]["prodT"] = self.X[m]["mean"].T @ self.X[m]["mean"]       # :785
                 self.update_tau(m)
                 self.update_b(m)
             if meth == "img":
@@ -432,6 +472,12 @@ class SSHIBAOracle:
         X["prodT"] = X["mean"].T @ X["mean"] + np.diag(np.sum(X["cov"], axis=0))
         X["sumlogdet"] = np.sum(np.log(X["cov"]))
 
+    def update_xs(self, m):
+        """cA/favae.py:1157-1174 (X* of a semi-supervised 'reg' view)."""
+        q = self.q_dist
+        q.XS[m]["cov"] = (q.tau_mean(m) ** (-1) * np.eye(self.d[m])).astype(float)
+        q.XS[m]["mean"] = np.add(np.dot(q.Z["mean"], q.W[m]["mean"].T), q.b[m]["mean"])
+
     def update_xi(self, m):
         """cA/favae.py:1216-1229."""
         self.q_dist.xi[m] = np.sqrt(self.X[m]["cov"] + self.X[m]["mean"] ** 2)
@@ -456,6 +502,10 @@ class SSHIBAOracle:
                 H = 0.5 * self.X[m]["sumlogdet"]
                 self.X[m]["LH"] = self.X[m]["LH"] if abs(H) == np.inf else H
                 ent = ent + self.X[m]["LH"]
+            if self.SS[m] and self.method[m] == "reg":                                   # :1651-1653, 1666-1668
+                H = 0.5 * self.X[m]["sumlogdet"]
+                q.XS[m]["LH"] = q.XS[m]["LH"] if abs(H) == np.inf else H
+                ent = ent + q.XS[m]["LH"]
         elogp = -0.5 * np.trace(q.Z["prodT"])
         for m in range(self.m):
             e_tau = -(0.5 * self.n_max * self.d[m] + self.hyper.tau_a[m] - 1) * np.log(q.tau[m]["b"] + EPS)

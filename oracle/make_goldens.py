@@ -11,6 +11,7 @@ Fixtures
                           prior: losses, mu/std, gradient and parameter checksums.
   vae_epoch.npz           ImgVAE.trainloop (N=24 => batches 16+8... uses batch 64 => one batch of 24) for
                           3 epochs + update_x + reconstruction: epoch metrics, X moments, checksums.
+  fa_A_ss.npz / fa_B_ss.npz  the same FA-only fit with a semi-supervised 'reg' view (128 rows + scattered entries unobserved).
   predict_fa_A/B.npz      SSHIBA.predict after the FA-only fits: 'mult' view in -> 'reg' view out and -> 'mult' view out.
   favae_A_predict.npz     after the favae_A fit: predict img -> mult, mult -> img (decoder of a sampled latent),
                           predict_sameimage mult -> img (seeds set before each call).
@@ -95,6 +96,33 @@ def gen_fa(folder, name, Kc=10, iters=4, rank=5, pretrained_kw=True):
     run_quiet(lambda: model.fit(v0, v1, **kw))
     out = {}
     dump_q(model, out)
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, "L =", model.L[-3:], "Kc =", model.q_dist.Kc)
+
+
+def ss_inputs():
+    """'reg' view with unobserved entries: the last 128 of 512 rows entirely, plus every 7th entry of column 3."""
+    X0, lab = fa_inputs()
+    X0 = X0.copy()
+    X0[384:, :] = np.nan
+    X0[::7, 3] = np.nan
+    return X0, lab
+
+
+def gen_fa_ss(folder, name, pretrained_kw=True):
+    """Semi-supervised 'reg' view (NaN = unobserved, imputed by update_xs every iteration; cA/favae.py:236-257, 775-783)."""
+    fav = rh.import_reference(folder)
+    X0, lab = ss_inputs()
+    model = fav.SSHIBA(10, 1)
+    v0, v1 = model.struct_data(X0, "reg"), model.struct_data(lab, "mult")
+    kw = dict(max_iter=4, pruning_crit=1e-3, verbose=1, store=False)
+    if pretrained_kw:
+        kw["pretrained"] = 0
+    run_quiet(lambda: model.fit(v0, v1, **kw))
+    out = {}
+    dump_q(model, out)
+    out["XS0_mean"] = model.q_dist.XS[0]["mean"]
+    out["X0_sumlogdet"] = np.array(model.X[0]["sumlogdet"])
     np.savez_compressed(os.path.join(OUT, name), **out)
     print(name, "L =", model.L[-3:], "Kc =", model.q_dist.Kc)
 
@@ -292,6 +320,9 @@ if __name__ == "__main__":
         gen_fa("condition_a_VAE", "fa_A.npz")
         gen_fa("domain_adaptation", "fa_B.npz", pretrained_kw=False)
         gen_fa("condition_a_VAE", "fa_A_prune.npz", Kc=30, iters=40, rank=3)
+    if "fa_ss" in which:
+        gen_fa_ss("condition_a_VAE", "fa_A_ss.npz")
+        gen_fa_ss("domain_adaptation", "fa_B_ss.npz", pretrained_kw=False)
     if "predict_fa" in which:
         gen_predict_fa("condition_a_VAE", "predict_fa_A.npz")
         gen_predict_fa("domain_adaptation", "predict_fa_B.npz", pretrained_kw=False)

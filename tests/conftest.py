@@ -32,6 +32,15 @@ def fa_inputs(n=512, rank=5, seed=1):
     return X0, lab
 
 
+def ss_inputs():
+    """fa_inputs with a semi-supervised 'reg' view: the last 128 rows and every 7th entry of column 3 unobserved (NaN)."""
+    X0, lab = fa_inputs()
+    X0 = X0.copy()
+    X0[384:, :] = np.nan
+    X0[::7, 3] = np.nan
+    return X0, lab
+
+
 def img_inputs(n, seed=1, zt=None):
     """Same generator as oracle/make_goldens.py:img_inputs."""
     rs = np.random.RandomState(seed)

@@ -72,6 +72,39 @@ def test_fa_only_fit_matches_reference_golden(golden, folder, name, kw):
     _close(p["output_view1"]["var_x"], gp["mult_var"], 1e-8, 1e-10)
 
 
+@pytest.mark.parametrize("folder,name,kw", [("condition_a_VAE", "fa_A_ss.npz", dict(pretrained=0)),
+                                            ("domain_adaptation", "fa_B_ss.npz", {})])
+def test_semi_supervised_reg_view_matches_reference_golden(golden, folder, name, kw):
+    """'reg' view with unobserved entries (NaN rows + scattered NaNs): imputation draws at fit, update_xs every iteration,
+    masked covariance / sumlogdet, X* entropy in the bound (cA/favae.py:236-257, 775-783, 1157-1174, 1651-1668), against
+    the reference's own run."""
+    from conftest import ss_inputs
+    fav = load_variant(folder)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    X0, lab = ss_inputs()
+    model = fav.SSHIBA(10, 1)
+    model.fit(model.struct_data(X0, "reg"), model.struct_data(lab, "mult"), max_iter=4, pruning_crit=1e-3, verbose=0,
+              store=False, **kw)
+    g = golden(name)
+    _check_q(model, g, 1e-8)
+    assert model.SS == [True, False]
+    _close(model.X[0]["cov"], g["X0_cov"], 1e-8, 1e-12)
+    _close(model.q_dist.XS[0]["mean"], g["XS0_mean"], 1e-8, 1e-8 * np.abs(g["XS0_mean"]).max())
+    _close(model.X[0]["sumlogdet"], g["X0_sumlogdet"], 1e-9)
+    # fewer rows than the other views = unobserved rows at the end; against the oracle (b's first covariance uses n[m])
+    Xs, _ = fa_inputs()
+    np.random.seed(0)
+    ref = fo.SSHIBAOracle(10, 1, variant="A" if folder == "condition_a_VAE" else "B")
+    ref.fit(fo.struct_data(Xs[:384], "reg"), fo.struct_data(lab, "mult"), max_iter=3, pruning_crit=1e-3)
+    np.random.seed(0)
+    mdl = fav.SSHIBA(10, 1)
+    mdl.fit(mdl.struct_data(Xs[:384], "reg"), mdl.struct_data(lab, "mult"), max_iter=3, pruning_crit=1e-3, verbose=0,
+            store=False, **kw)
+    _close(mdl.L, ref.L, 1e-8)
+    _close(mdl.X[0]["mean"], ref.X[0]["mean"], 1e-8, 1e-8 * np.abs(ref.X[0]["mean"]).max())
+
+
 def test_fa_only_fit_with_pruning_matches_reference_golden(golden):
     fav = load_variant("condition_a_VAE")
     np.random.seed(0)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import fa_inputs, img_inputs, checksum
+from conftest import fa_inputs, img_inputs, ss_inputs, checksum
 from oracle import fa_numpy as fa
 from oracle import vae_torch as vt
 
@@ -50,6 +50,35 @@ def test_fa_only_matches_reference(golden, variant, name):
     p = model.predict([1], [1], fa.struct_data(lab_t, "mult"))
     _close(p["output_view1"]["mean_x"], gp["mult_mean"], rtol=1e-8, atol=1e-10)
     _close(p["output_view1"]["var_x"], gp["mult_var"], rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("variant,name", [("A", "fa_A_ss.npz"), ("B", "fa_B_ss.npz")])
+def test_semi_supervised_reg_view_matches_reference(golden, variant, name):
+    """'reg' view with unobserved entries (NaN): initial imputation draws, update_xs, masked covariance, X* entropy
+    (cA/favae.py:236-257, 775-783, 1157-1174, 1651-1668)."""
+    g = golden(name)
+    X0, lab = ss_inputs()
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = fa.SSHIBAOracle(10, 1, variant=variant)
+    model.fit(fa.struct_data(X0, "reg"), fa.struct_data(lab, "mult"), max_iter=4, pruning_crit=1e-3)
+    _check_q(model, g)
+    _close(model.X[0]["cov"], g["X0_cov"], rtol=1e-8, atol=1e-12)
+    _close(model.q_dist.XS[0]["mean"], g["XS0_mean"], rtol=1e-8, atol=1e-9)
+    _close(model.X[0]["sumlogdet"], g["X0_sumlogdet"], rtol=1e-9)
+    # a view with fewer rows than the others is padded with unobserved rows (:239-240); only b's initial covariance
+    # differs from the NaN-row form (it uses n[m], :1986), so the two runs stay within a per cent of each other
+    Xs, _ = fa_inputs()
+    np.random.seed(0)
+    a = fa.SSHIBAOracle(10, 1, variant=variant)
+    a.fit(fa.struct_data(Xs[:384], "reg"), fa.struct_data(lab, "mult"), max_iter=2, pruning_crit=1e-3)
+    assert a.X[0]["mean"].shape == (512, 20) and a.SS == [True, False] and int(a.SS_mask[0].sum()) == 128 * 20
+    Xn = Xs.copy()
+    Xn[384:] = np.nan
+    np.random.seed(0)
+    b = fa.SSHIBAOracle(10, 1, variant=variant)
+    b.fit(fa.struct_data(Xn, "reg"), fa.struct_data(lab, "mult"), max_iter=2, pruning_crit=1e-3)
+    _close(a.L, b.L, rtol=2e-2)
 
 
 def test_fa_pruning_matches_reference(golden):
