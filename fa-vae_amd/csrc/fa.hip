@@ -486,6 +486,44 @@ extern "C" int favae_fa_mult_update(const double* t, const double* zwb, double* 
     return FAVAE_OK;
 }
 
+// Semi-supervised multilabel view: update_t (cA/favae.py:1176-1195) and its write-back t.mean[mask] = tS.mean[mask]
+// (:858-861) in one pass.  tS.mean = sigmoid(X.mean), tS.cov = exp(log tS.mean - log(1 + exp(X.mean))) over ALL entries;
+// out2 = (sum log tS.cov, sum_mask X.mean * (t_new - t_old)): the second is what the bound term sum X.mean * t.mean
+// (:1678), taken by mult_kernel with the labels of before, gains from the new labels.
+__global__ __launch_bounds__(256) void mult_ss_kernel(const double* __restrict__ mean, const unsigned char* __restrict__ mask,
+                                                      double* __restrict__ t, size_t n, double* __restrict__ partial) {
+    __shared__ double sm[8];
+    double a0 = 0.0, a1 = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double x = mean[i];
+        const double sg = ref_sigmoid(x);
+        a0 += log(sg) - log(1.0 + exp(x));
+        if (mask[i]) {
+            a1 += x * (sg - t[i]);
+            t[i] = sg;
+        }
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1);
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = a0; sm[4 + (threadIdx.x >> 6)] = a1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+        partial[2 * blockIdx.x + 1] = sm[4] + sm[5] + sm[6] + sm[7];
+    }
+}
+
+extern "C" int favae_fa_mult_ss_update(const double* mean, const unsigned char* mask, double* t, long long n, double* out2,
+                                       double* scratch, size_t scratch_doubles, void* stream) {
+    FAVAE_CHECK_ARG(mean && mask && t && out2 && scratch && n > 0, "favae_fa_mult_ss_update: bad argument");
+    const int grid = ew_grid((size_t)n);
+    FAVAE_CHECK_ARG((size_t)2 * grid <= scratch_doubles, "favae_fa_mult_ss_update: scratch too small");
+    hipLaunchKernelGGL(mult_ss_kernel, dim3(grid), dim3(256), 0, ST, mean, mask, t, (size_t)n, scratch);
+    FAVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pair_finish, dim3(1), dim3(64), 0, ST, scratch, grid, out2);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
 // SSHIBA.predict, multilabel output (cA/favae.py:1476-1479): s = m_x * scale[d]; mean_t = sigmoid(s) written the
 // reference's way exp(-log(1+exp(-s))) (:924-935), var_t = exp(s) / (1 + exp(s)^2) as written at :1479.
 __global__ __launch_bounds__(256) void mult_predict_kernel(const double* __restrict__ mx, const double* __restrict__ scale,

@@ -64,6 +64,15 @@ def mult_update(t, zwb, xi, mean, cov, tau, sc):
     return sc.pair[:2].cpu().numpy().copy()     # (sum log cov, bound term)
 
 
+def mult_ss_update(mean, mask_u8, t, sc):
+    """update_t + write-back of the unobserved labels; returns (sum log tS.cov, change of the bound term sum X.mean * t.mean)."""
+    s = sc.need(4096)
+    L.check(_raw.favae_fa_mult_ss_update(L.ptr(mean), L.ptr(mask_u8), L.ptr(t), _ll(t.numel()), L.ptr(sc.pair), L.ptr(s),
+                                         _sz(s.numel()), L.stream_ptr()))
+    dist.sum_(sc.pair)
+    return sc.pair[:2].cpu().numpy().copy()
+
+
 def xi_init(mean, cov, xi):
     L.check(_raw.favae_fa_xi_init(L.ptr(mean), L.ptr(cov), L.ptr(xi), _ll(mean.numel()), L.stream_ptr()))
 

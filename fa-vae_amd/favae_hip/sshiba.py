@@ -232,14 +232,39 @@ class SSHIBA(object):
                 self.img_vae[m] = self.img_vae_module.ImgVAE(dimx=arg["latent_dim"], channels=data.shape[1], lr=arg["lr"],
                                                              h=data.shape[2], w=data.shape[3], dataset=arg["dataset"],
                                                              latentspace_lr=self.latentspace_lr)
-            else:
-                self.t[m] = LazyDict(data=data, LH=0, Elogp=0, sumlogdet=0, epochs=20)
-                tt = np.abs(data.astype(float) - 0.05)
-                info["mean"] = np.log(tt / (1 - tt))                                                 # :276
-                info["cov"] = np.zeros(info["mean"].shape)
-                self.t[m]["mean"] = np.copy(data).astype(float)
-                self.t[m]["cov"] = np.zeros(data.shape)
-                self.SS_mask[m] = np.isnan(data.astype(float))
+            else:                                                                                    # :269-289 (SS_sep = 0)
+                tdata = data.astype(float)
+                mask = np.isnan(tdata)
+                self.SS_mask[m] = mask
+                self.t[m] = LazyDict(data=tdata, LH=0, Elogp=0, sumlogdet=0, epochs=20)
+                if dist.sum_scalar(float(mask.sum()), self.dev) > 0:                                 # semi-supervised labels
+                    if dist.active() or self.SS_sep:
+                        raise NotImplementedError("semi-supervised multilabel views: single process, SS_sep=0 only")
+                    self.SS[m] = True
+                    tmean, tcov = np.copy(info["mean"]), np.copy(info["cov"])                        # t = deepcopy(info) (:270)
+                    mean, cov = np.copy(info["mean"]), np.copy(info["cov"])
+                    tt = np.abs(tdata[~mask] - 0.05)
+                    mean[~mask] = np.log(tt / (1 - tt))                                              # :276
+                    cov[~mask] = 0
+                    for dd in range(d):                                                              # :278-280
+                        obs, cnt = mean[~mask[:, dd], dd], int(np.sum(mask[:, dd]))
+                        mean[mask[:, dd], dd] = np.random.normal(np.nanmean(obs, axis=0), np.nanstd(obs, axis=0), cnt)
+                        cov[mask[:, dd], dd] = np.abs(np.random.normal(np.nanmean(obs, axis=0), np.nanstd(obs, axis=0), cnt))
+                    for dd in range(d):                                                              # :285-286
+                        tmean[mask[:, dd], dd] = np.random.normal(np.nanmean(tmean[:, dd], axis=0), np.nanstd(tmean[:, dd], axis=0),
+                                                                  int(np.sum(mask[:, dd])))
+                    tmean[~mask] = tdata[~mask]
+                    tcov[~mask] = 0
+                    info["mean"], info["cov"] = mean, cov
+                    self.t[m]["mean"], self.t[m]["cov"] = tmean, tcov
+                    self._ss_mask_dev = getattr(self, "_ss_mask_dev", {})
+                    self._ss_mask_dev[m] = torch.from_numpy(mask.astype(np.uint8)).to(self.dev)
+                else:
+                    tt = np.abs(tdata - 0.05)
+                    info["mean"] = np.log(tt / (1 - tt))                                             # :276
+                    info["cov"] = np.zeros(info["mean"].shape)
+                    self.t[m]["mean"] = np.copy(tdata)
+                    self.t[m]["cov"] = np.zeros(tdata.shape)
         self.keep_training = {m: True for m in range(len(n)) if self.method[m] == "img"}
         self.L, self.mse, self.R2, self.HL, self.AUC, self.AUC_tr, self.ACC, self.ACC_tr = [], [], [], [], [], [], [], []
         self.wandb_metrics = {}
@@ -323,6 +348,8 @@ class SSHIBA(object):
             elif meth == "mult":
                 for _ in range(2):
                     self.update_x(m)          # update_x + update_xi fused (:856-857)
+                    if self.SS[m]:
+                        self.update_t(m)      # :858-861
                 self._refresh_xstats(m)
                 self.update_tau(m)
             self.update_b(m)
@@ -649,6 +676,15 @@ class SSHIBA(object):
         self._mult_elbo = getattr(self, "_mult_elbo", {})
         self._mult_elbo[m] = float(sums[1])
 
+    def update_t(self, m):
+        """t* of a semi-supervised multilabel view (:1176-1195) and t.mean[mask] = tS.mean[mask] (:861), one pass"""
+        t = self.t[m]
+        tm = t.dev("mean", self.dev)
+        sums = fa.mult_ss_update(self.X[m].dev("mean", self.dev), self._ss_mask_dev[m], tm, self.sc)
+        t.set_dev("mean", tm)
+        self.q_dist.tS[m]["sumlogdet"] = float(sums[0])
+        self._mult_elbo[m] += float(sums[1])      # the bound term sum X.mean * t.mean (:1678) with the new labels
+
     def update_xi(self, m):
         """fused into update_x (the kernel writes xi = sqrt(cov + mean^2) in the same pass, :1229)"""
 
@@ -678,6 +714,10 @@ class SSHIBA(object):
                 H = 0.5 * self.X[m]["sumlogdet"]
                 dict.__setitem__(q.XS[m], "LH", q.XS[m]["LH"] if abs(H) == np.inf else H)
                 ent = ent + q.XS[m]["LH"]
+            if self.SS[m] and self.method[m] == "mult":                                              # :1655-1656, 1669-1670
+                H = 0.5 * q.tS[m]["sumlogdet"]
+                q.tS[m]["LH"] = q.tS[m]["LH"] if abs(H) == np.inf else H
+                ent = ent + q.tS[m]["LH"]
         q.Z["Elogp"] = -0.5 * np.trace(q.Z["prodT"])
         elogp = q.Z["Elogp"]
         for m in range(self.m):

@@ -267,6 +267,11 @@ int favae_fa_rows_gemm(const double* X, int ldx, int d, const double* P, int ldp
  * out2[0] = sum log cov, out2[1] = sum log sig(xi) + mean*t - (mean+xi)/2.  n = N*d elements. scratch >= 4096 doubles. */
 int favae_fa_mult_update(const double* t, const double* zwb, double* xi, double* mean, double* cov, double tau, long long n,
                          double* out2, double* scratch, size_t scratch_doubles, void* stream);
+/* Semi-supervised multilabel view, update_t (cA/favae.py:1176-1195) + t.mean[mask] = sigmoid(X.mean)[mask] (:858-861):
+ * mask [n] bytes (1 = label unobserved), t updated in place; out2 = (sum over all entries of log tS.cov,
+ * sum_mask X.mean * (t_new - t_old) = the change of the bound term sum X.mean * t.mean of :1678).  scratch as above. */
+int favae_fa_mult_ss_update(const double* mean, const unsigned char* mask, double* t, long long n, double* out2,
+                            double* scratch, size_t scratch_doubles, void* stream);
 int favae_fa_xi_init(const double* mean, const double* cov, double* xi, long long n, void* stream);
 /* Multilabel output of SSHIBA.predict (cA/favae.py:1469-1481): for rows of m_x [N][d] and scale[d] = (1 + pi/8 var_x[d,d])^-1/2,
  * mean_t = sigmoid(m_x scale), var_t = exp(s) / (1 + exp(s)^2) (as the reference writes it). */

@@ -3,7 +3,7 @@ oracle/__init__.py).  Citations are path:line under /root/reference; "cA" = cond
 "DA" = domain_adaptation.
 
 Only the branches the four reference trainers exercise are restated ('reg', 'mult', 'img' views; no sparse,
-kernel, categorical or semi-supervised multilabel paths -- SURVEY.md section 2 row 13; semi-supervised 'reg' views are in).
+kernel or categorical paths -- SURVEY.md section 2 row 13; semi-supervised 'reg' and 'mult' views with SS_sep=0 are in).
 """
 import math
 import sys
@@ -187,14 +187,32 @@ class SSHIBAOracle:
                 self.img_vae[m] = self.vae_factory(dimx=v["latent_dim"], channels=data.shape[1], lr=v["lr"],
                                                    dataset=v["dataset"], latentspace_lr=self.latentspace_lr)
             elif meth == "mult":                                                         # :269-346
-                self.SS.append(False)
                 self.t[m] = copy.deepcopy(info)
-                self.t[m]["data"] = data
-                tt = np.abs(data.astype(float) - 0.05)
-                info["mean"] = np.log(tt / (1 - tt))                                     # :276
-                info["cov"] = np.zeros_like(info["mean"])
-                self.t[m]["mean"] = np.copy(data).astype(float)
-                self.t[m]["cov"] = np.zeros(self.t[m]["mean"].shape)
+                tdata = data.astype(float)
+                if self.n_max > self.n[m]:
+                    tdata = np.vstack((tdata, np.nan * np.ones((self.n_max - self.n[m], d))))
+                self.t[m]["data"] = tdata
+                mask = np.isnan(tdata)
+                self.SS_mask[m] = mask
+                tt = np.abs(tdata[~mask] - 0.05)
+                info["mean"][~mask] = np.log(tt / (1 - tt))                              # :276
+                info["cov"][~mask] = 0
+                if np.sum(mask) > 0:                                                     # semi-supervised labels (SS_sep = 0)
+                    self.SS.append(True)
+                    for dd in range(d):                                                  # :278-280
+                        obs, cnt = info["mean"][~mask[:, dd], dd], int(np.sum(mask[:, dd]))
+                        info["mean"][mask[:, dd], dd] = np.random.normal(np.nanmean(obs, axis=0), np.nanstd(obs, axis=0), cnt)
+                        info["cov"][mask[:, dd], dd] = np.abs(np.random.normal(np.nanmean(obs, axis=0), np.nanstd(obs, axis=0), cnt))
+                    tm = self.t[m]["mean"]
+                    for dd in range(d):                                                  # :285-286
+                        tm[mask[:, dd], dd] = np.random.normal(np.nanmean(tm[:, dd], axis=0), np.nanstd(tm[:, dd], axis=0),
+                                                               int(np.sum(mask[:, dd])))
+                    tm[~mask] = tdata[~mask]
+                    self.t[m]["cov"][~mask] = 0
+                else:
+                    self.SS.append(False)
+                    self.t[m]["mean"] = np.copy(tdata)
+                    self.t[m]["cov"] = np.zeros(tdata.shape)
         self.L = []
         self.metrics = {}
         self.hyper = Hyper(self.m)
@@ -243,9 +261,12 @@ class SSHIBAOracle:
             if meth == "img":
                 self._update_img(m, iter_count)
             elif meth == "mult":
-                for _ in range(2):                                                       # :855-857
+                for _ in range(2):                                                       # :855-861
                     self.update_x(m)
                     self.update_xi(m)
+                    if self.SS[m]:
+                        self.update_t(m)
+                        self.t[m]["mean"][self.SS_mask[m]] = q.tS[m]["mean"][self.SS_mask[m]]
                 self.update_tau(m)
             self.update_b(m)                                                             # :867-868
             self.update_alpha(m)                                                         # :872
@@ -478,6 +499,13 @@ class SSHIBAOracle:
         q.XS[m]["cov"] = (q.tau_mean(m) ** (-1) * np.eye(self.d[m])).astype(float)
         q.XS[m]["mean"] = np.add(np.dot(q.Z["mean"], q.W[m]["mean"].T), q.b[m]["mean"])
 
+    def update_t(self, m):
+        """cA/favae.py:1176-1195 (t* of a semi-supervised multilabel view)."""
+        tS = self.q_dist.tS[m]
+        tS["mean"] = sigmoid(self.X[m]["mean"])
+        tS["cov"] = np.exp(np.subtract(np.log(tS["mean"]), np.log((1 + np.exp(self.X[m]["mean"])))))
+        tS["sumlogdet"] = np.sum(np.log(tS["cov"]))
+
     def update_xi(self, m):
         """cA/favae.py:1216-1229."""
         self.q_dist.xi[m] = np.sqrt(self.X[m]["cov"] + self.X[m]["mean"] ** 2)
@@ -506,6 +534,10 @@ class SSHIBAOracle:
                 H = 0.5 * self.X[m]["sumlogdet"]
                 q.XS[m]["LH"] = q.XS[m]["LH"] if abs(H) == np.inf else H
                 ent = ent + q.XS[m]["LH"]
+            if self.SS[m] and self.method[m] == "mult":                                  # :1655-1656, 1669-1670
+                H = 0.5 * q.tS[m]["sumlogdet"]
+                q.tS[m]["LH"] = q.tS[m]["LH"] if abs(H) == np.inf else H
+                ent = ent + q.tS[m]["LH"]
         elogp = -0.5 * np.trace(q.Z["prodT"])
         for m in range(self.m):
             e_tau = -(0.5 * self.n_max * self.d[m] + self.hyper.tau_a[m] - 1) * np.log(q.tau[m]["b"] + EPS)

@@ -12,6 +12,7 @@ Fixtures
   vae_epoch.npz           ImgVAE.trainloop (N=24 => batches 16+8... uses batch 64 => one batch of 24) for
                           3 epochs + update_x + reconstruction: epoch metrics, X moments, checksums.
   fa_A_ss.npz / fa_B_ss.npz  the same FA-only fit with a semi-supervised 'reg' view (128 rows + scattered entries unobserved).
+  fa_A_ss2.npz            ... and unobserved labels in the 'mult' view as well (rows 300-419, every 5th entry of label 7).
   predict_fa_A/B.npz      SSHIBA.predict after the FA-only fits: 'mult' view in -> 'reg' view out and -> 'mult' view out.
   favae_A_predict.npz     after the favae_A fit: predict img -> mult, mult -> img (decoder of a sampled latent),
                           predict_sameimage mult -> img (seeds set before each call).
@@ -109,10 +110,15 @@ def ss_inputs():
     return X0, lab
 
 
-def gen_fa_ss(folder, name, pretrained_kw=True):
-    """Semi-supervised 'reg' view (NaN = unobserved, imputed by update_xs every iteration; cA/favae.py:236-257, 775-783)."""
+def gen_fa_ss(folder, name, pretrained_kw=True, labels_too=False):
+    """Semi-supervised 'reg' view (NaN = unobserved, imputed by update_xs every iteration; cA/favae.py:236-257, 775-783);
+    labels_too: the multilabel view has unobserved labels as well (update_t, :269-289, 858-861, 1176-1195)."""
     fav = rh.import_reference(folder)
     X0, lab = ss_inputs()
+    if labels_too:
+        lab = lab.astype(float)
+        lab[300:420, :] = np.nan
+        lab[::5, 7] = np.nan
     model = fav.SSHIBA(10, 1)
     v0, v1 = model.struct_data(X0, "reg"), model.struct_data(lab, "mult")
     kw = dict(max_iter=4, pruning_crit=1e-3, verbose=1, store=False)
@@ -123,6 +129,9 @@ def gen_fa_ss(folder, name, pretrained_kw=True):
     dump_q(model, out)
     out["XS0_mean"] = model.q_dist.XS[0]["mean"]
     out["X0_sumlogdet"] = np.array(model.X[0]["sumlogdet"])
+    if labels_too:
+        out["t1_mean"] = model.t[1]["mean"]
+        out["tS1_sumlogdet"] = np.array(model.q_dist.tS[1]["sumlogdet"])
     np.savez_compressed(os.path.join(OUT, name), **out)
     print(name, "L =", model.L[-3:], "Kc =", model.q_dist.Kc)
 
@@ -323,6 +332,7 @@ if __name__ == "__main__":
     if "fa_ss" in which:
         gen_fa_ss("condition_a_VAE", "fa_A_ss.npz")
         gen_fa_ss("domain_adaptation", "fa_B_ss.npz", pretrained_kw=False)
+        gen_fa_ss("condition_a_VAE", "fa_A_ss2.npz", labels_too=True)
     if "predict_fa" in which:
         gen_predict_fa("condition_a_VAE", "predict_fa_A.npz")
         gen_predict_fa("domain_adaptation", "predict_fa_B.npz", pretrained_kw=False)

@@ -41,6 +41,15 @@ def ss_inputs():
     return X0, lab
 
 
+def ss2_inputs():
+    """ss_inputs plus unobserved labels in the multilabel view (rows 300-419, every 5th entry of label 7)."""
+    X0, lab = ss_inputs()
+    lab = lab.astype(float)
+    lab[300:420, :] = np.nan
+    lab[::5, 7] = np.nan
+    return X0, lab
+
+
 def img_inputs(n, seed=1, zt=None):
     """Same generator as oracle/make_goldens.py:img_inputs."""
     rs = np.random.RandomState(seed)

@@ -105,6 +105,24 @@ def test_semi_supervised_reg_view_matches_reference_golden(golden, folder, name,
     _close(mdl.X[0]["mean"], ref.X[0]["mean"], 1e-8, 1e-8 * np.abs(ref.X[0]["mean"]).max())
 
 
+def test_semi_supervised_labels_match_reference_golden(golden):
+    """Unobserved labels in the multilabel view too: update_t after every update_x / update_xi, t* entropy and the bound
+    term with the refreshed labels (cA/favae.py:269-289, 858-861, 1176-1195, 1655-1656, 1678), against the reference's run."""
+    from conftest import ss2_inputs
+    fav = load_variant("condition_a_VAE")
+    np.random.seed(0)
+    torch.manual_seed(0)
+    X0, lab = ss2_inputs()
+    model = fav.SSHIBA(10, 1)
+    model.fit(model.struct_data(X0, "reg"), model.struct_data(lab, "mult"), max_iter=4, pruning_crit=1e-3, verbose=0,
+              store=False, pretrained=0)
+    g = golden("fa_A_ss2.npz")
+    _check_q(model, g, 1e-8)
+    assert model.SS == [True, True]
+    _close(model.t[1]["mean"], g["t1_mean"], 1e-8, 1e-10)
+    _close(model.q_dist.tS[1]["sumlogdet"], g["tS1_sumlogdet"], 1e-9)
+
+
 def test_fa_only_fit_with_pruning_matches_reference_golden(golden):
     fav = load_variant("condition_a_VAE")
     np.random.seed(0)

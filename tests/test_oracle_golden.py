@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import fa_inputs, img_inputs, ss_inputs, checksum
+from conftest import fa_inputs, img_inputs, ss_inputs, ss2_inputs, checksum
 from oracle import fa_numpy as fa
 from oracle import vae_torch as vt
 
@@ -79,6 +79,21 @@ def test_semi_supervised_reg_view_matches_reference(golden, variant, name):
     b = fa.SSHIBAOracle(10, 1, variant=variant)
     b.fit(fa.struct_data(Xn, "reg"), fa.struct_data(lab, "mult"), max_iter=2, pruning_crit=1e-3)
     _close(a.L, b.L, rtol=2e-2)
+
+
+def test_semi_supervised_labels_match_reference(golden):
+    """Unobserved labels in the multilabel view as well: initial draws (:276-289), update_t after every update_x/update_xi
+    (:858-861, 1176-1195), t* entropy in the bound (:1655-1656)."""
+    g = golden("fa_A_ss2.npz")
+    X0, lab = ss2_inputs()
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = fa.SSHIBAOracle(10, 1, variant="A")
+    model.fit(fa.struct_data(X0, "reg"), fa.struct_data(lab, "mult"), max_iter=4, pruning_crit=1e-3)
+    _check_q(model, g)
+    assert model.SS == [True, True]
+    _close(model.t[1]["mean"], g["t1_mean"], rtol=1e-8, atol=1e-10)
+    _close(model.q_dist.tS[1]["sumlogdet"], g["tS1_sumlogdet"], rtol=1e-9)
 
 
 def test_fa_pruning_matches_reference(golden):
