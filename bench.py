@@ -125,6 +125,11 @@ def main():
     if os.environ.get("FAVAE_HANG_DUMP"):                # debugging aid: dump all Python stacks after N seconds and exit
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["FAVAE_HANG_DUMP"]), exit=True)
+    # stdout carries exactly ONE line, the JSON: native libraries write there too (RCCL prints a version banner when its
+    # communicator comes up), so fd 1 is pointed at stderr for the run and the result goes to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -132,8 +137,12 @@ def main():
         local = 0
         os.environ["LOCAL_RANK"] = "0"
     torch.cuda.set_device(local)
-    if ws > 1:
+    force_dp = os.environ.get("FAVAE_FORCE_DP") == "1"     # one-rank rehearsal of the whole multi-rank code path (RCCL)
+    if ws > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if os.environ.get("FAVAE_DIST_BACKEND", "nccl") == "nccl":
             torch.distributed.init_process_group("nccl", device_id=torch.device("cuda:%d" % local))
         else:
@@ -219,8 +228,11 @@ def main():
         }
         if ws == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.n, a.latent, a.kc)
-        print(json.dumps(out))
-    if ws > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if ws > 1 or force_dp:
+        from favae_hip import dist as fdist
+        fdist.shutdown()
         torch.distributed.destroy_process_group()
 
 

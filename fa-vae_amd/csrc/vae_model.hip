@@ -8,6 +8,7 @@
 #include <vector>
 #include "common.h"
 #include "favae_hip.h"
+#include "comm_internal.h"
 
 namespace {
 
@@ -96,7 +97,9 @@ struct Vae {
     // main stream joins the side stream only when the next step's forward pass is about to read the weights
     struct { bool on; float lr, b1, b2, eps; long long step; int pending; bool epoch; } ada;
     bool join_pending; bool dg_all;
+    bool dp_epoch;   // steps of favae_vae_train_epoch_dp: gradients cleared by the bucket-wise Adam, joins through the communication stream
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
+    hipEvent_t ev_join_ext;   // when set: the event join_pending refers to (the communicator's), else ev_join
     unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients, 128 Adam + weight re-layout in one pass, 256 final conv + loss in one launch
     float* xf_alt; char* xt_alt;
     char* wk_out;   // weights of final_layer.3 in the MFMA operand order for favae_conv_out_ll (rebuilt whenever the layer changes)
@@ -442,6 +445,8 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.side2 = nullptr;
     v.ada = {false, 0.f, 0.f, 0.f, 0.f, 0, -1, false};
     v.join_pending = false;
+    v.dp_epoch = false;
+    v.ev_join_ext = nullptr;
     v.ev_fence_ok = false;
     {
         const char* d = getenv("FAVAE_DG_EVENTS");
@@ -506,14 +511,14 @@ constexpr int N_STAGES = 13;
 
 int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const float* eps, const double* prior, float tau,
                  float beta, float var_x, double* metrics2_out, int stage_lo, int stage_hi, void* st) {
-    const bool epoch = v.overlap && v.ada.on && v.ada.epoch;
+    const bool epoch = (v.overlap && v.ada.on && v.ada.epoch) || v.dp_epoch;
     if (stage_lo == 0) {
         if (!epoch) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));
         FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, (hipStream_t)st));
         if (epoch) { std::swap(v.xf, v.xf_alt); std::swap(v.xt, v.xt_alt); }
         RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, v.xf, v.xt, v.dtype, st));
         if (v.join_pending) {   // the previous step's weight gradients / updates, still running next to the two launches above
-            FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_join, 0));
+            FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_join_ext ? v.ev_join_ext : v.ev_join, 0));
             v.join_pending = false;
         }
         RC(encoder_fwd(v, B, true, st, true));
@@ -575,7 +580,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             RC(wgrad(v, 0, v.xt, B, st));
         }
     }
-    if (stage_hi == N_STAGES && v.overlap) {
+    if (stage_hi == N_STAGES && v.overlap && !v.dp_epoch) {   // (data-parallel epochs join through favae_vae_fence)
         if (v.ada.on) {   // encoder.0: no input gradient reads its shadows
             if (v.ada.pending >= 0 && v.ada.pending != 0) {
                 FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[v.ada.pending], 0));
@@ -676,6 +681,64 @@ extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const
         }
     }
     return FAVAE_OK;
+}
+
+/* Data-parallel epoch (see include/favae_hip.h). */
+extern "C" int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float* data_nhwc, const int* perm, long long n, int batch,
+                                        const float* eps, const double* prior, float tau, float beta, float var_x, float lr,
+                                        long long step0, double* metrics, void* st) {
+    FAVAE_CHECK_ARG(h && c && perm && metrics && n >= 1 && batch >= 1, "favae_vae_train_epoch_dp: bad argument");
+    Vae& v = h->v;
+    FAVAE_CHECK_ARG(v.overlap, "favae_vae_train_epoch_dp needs the weight-gradient stream (FAVAE_SINGLE_STREAM is set)");
+    hipStream_t cs = favae_comm_stream(c);
+    hipEvent_t done = favae_comm_event(c);
+    // (arena_lo, arena_hi, first layer, last layer, stage_hi): the slice is complete once backward stages < stage_hi ran
+    const long long w3 = v.L[3].w_off, w6 = v.L[6].w_off;
+    const struct { long long lo, hi; int l0, l1, stage_hi; } bk[3] = {{w6, v.nparam, 6, NL - 1, 7}, {w3, w6, 3, 5, 10}, {0, w3, 0, 2, N_STAGES}};
+    FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));   // the bucket-wise Adam keeps it cleared
+    int rc = FAVAE_OK;
+    long long s = 0;
+    v.dp_epoch = true;
+    for (long long o = 0; o < n && rc == FAVAE_OK; o += batch, ++s) {
+        const int B = (int)std::min<long long>(batch, n - o);
+        int lo = 0;
+        for (int b = 0; b < 3 && rc == FAVAE_OK; ++b) {
+            rc = train_stages(v, data_nhwc, perm + o, B, eps + o * v.z, prior, tau, beta, var_x, metrics + 2 * s, lo, bk[b].stage_hi, st);
+            lo = bk[b].stage_hi;
+            if (rc) break;
+            rc = favae_vae_fence(h, st, (void*)cs);       // cs waits for the main and the weight-gradient stream, neither waits
+            if (rc) break;
+            rc = favae_allreduce_f32(c, v.G + bk[b].lo, bk[b].hi - bk[b].lo, 1, (void*)cs);
+            if (rc) break;
+            rc = favae_adam_step_clear(v.P + bk[b].lo, v.G + bk[b].lo, v.M + bk[b].lo, v.V + bk[b].lo, bk[b].hi - bk[b].lo, lr, 0.9f,
+                                       0.999f, 1e-8f, step0 + s + 1, (void*)cs);
+            if (rc) break;
+            const float* w[16]; void* wc[16]; void* wt[16]; int Co[16], taps[16], Ci[16];
+            int k = 0;
+            for (int l = bk[b].l0; l <= bk[b].l1; ++l) {
+                const Layer& L = v.L[l];
+                void* cc = L.wc_off >= 0 ? v.SH + L.wc_off * v.esz : nullptr;
+                void* tt = L.wt_off >= 0 ? v.SH + L.wt_off * v.esz : nullptr;
+                if (!cc && !tt) continue;
+                w[k] = v.P + L.w_off; wc[k] = cc; wt[k] = tt; Co[k] = L.Cout; taps[k] = L.taps; Ci[k] = L.Cin;
+                ++k;
+            }
+            if (k) rc = favae_weight_prep_batch(k, w, wc, wt, Co, taps, Ci, v.dtype, (void*)cs);
+            if (rc == FAVAE_OK && bk[b].l1 == NL - 1) rc = favae_conv_out_wprep(v.Wf(L_OUT), v.wk_out, v.ch, v.dtype, (void*)cs);
+        }
+        if (rc) break;
+        // the next forward pass (and, through its fork events, the next weight gradients) waits for the updates
+        if (hipEventRecord(done, cs) != hipSuccess) { favae_set_error("favae_vae_train_epoch_dp: hipEventRecord"); rc = FAVAE_ERR_HIP; break; }
+        v.ev_join_ext = done;
+        v.join_pending = true;
+    }
+    v.dp_epoch = false;
+    if (v.join_pending) {
+        (void)hipStreamWaitEvent((hipStream_t)st, v.ev_join_ext ? v.ev_join_ext : v.ev_join, 0);
+        v.join_pending = false;
+    }
+    v.ev_join_ext = nullptr;
+    return rc;
 }
 
 /* Encoder over B samples (update_x, :331-358 when train=0; the encoder half of forward() when train=1):

@@ -52,6 +52,51 @@ def mean_(t):
     return t
 
 
+_native = {"comm": None, "tried": False}
+
+
+def native_comm(device):
+    """The library's own RCCL communicator (favae_comm_*), bootstrapped through torch.distributed: rank 0 draws the RCCL
+    unique id, a broadcast hands it to the others, every rank joins.  None when the backend is not RCCL or the bootstrap
+    fails (the callers then take the torch.distributed path).  FAVAE_NATIVE_COMM=0 disables it."""
+    if _native["tried"]:
+        return _native["comm"]
+    _native["tried"] = True
+    if not active() or td.get_backend() != "nccl" or os.environ.get("FAVAE_NATIVE_COMM") == "0":
+        return None
+    import ctypes
+    from . import lib as L
+    raw = L.raw()
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()
+    ident = (ctypes.c_ubyte * 128)()
+    ok = torch.ones(1, dtype=torch.int32, device=device)
+    if td.get_rank() == 0 and raw.favae_comm_unique_id(path, ident) != 0:
+        ok.zero_()
+    t = torch.tensor(list(ident), dtype=torch.uint8, device=device)
+    td.broadcast(t, 0)
+    td.all_reduce(ok, op=td.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        return None
+    ident = (ctypes.c_ubyte * 128)(*t.cpu().tolist())
+    comm = ctypes.c_void_p()
+    rc = raw.favae_comm_init(ctypes.byref(comm), path, ident, ctypes.c_int(td.get_rank()), ctypes.c_int(td.get_world_size()))
+    ok.fill_(1 if rc == 0 else 0)
+    td.all_reduce(ok, op=td.ReduceOp.MIN)          # all ranks or none
+    if int(ok.item()) == 0:
+        if rc == 0:
+            raw.favae_comm_destroy(comm)
+        return None
+    _native["comm"] = comm
+    return comm
+
+
+def shutdown():
+    if _native["comm"] is not None:
+        from . import lib as L
+        L.raw().favae_comm_destroy(_native["comm"])
+    _native["comm"], _native["tried"] = None, False
+
+
 def mean_async(t, engine, comm_stream):
     """Mean over ranks of a gradient bucket whose producers (main + weight-gradient stream of `engine`) may still be running:
     RCCL: the all-reduce is enqueued behind them on `comm_stream` and returns a work handle (wait() orders the current

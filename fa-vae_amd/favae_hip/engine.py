@@ -244,6 +244,14 @@ class VaeEngine:
                                            L.stream_ptr()))
         self.step += (n + batch - 1) // batch
 
+    def train_epoch_dp(self, comm, data, perm, eps, prior, tau, beta, var_x, lr, batch, metrics):
+        """One data-parallel epoch in one call: bucketed gradient all-reduce + bucket-wise Adam on the communicator's stream."""
+        n = perm.numel()
+        L.check(_raw.favae_vae_train_epoch_dp(self.h, comm, L.ptr(data), L.ptr(perm), _ll(n), _i(batch), L.ptr(eps), L.ptr(prior),
+                                              _f(tau), _f(beta), _f(var_x), _f(lr), _ll(self.step), L.ptr(metrics),
+                                              L.stream_ptr()))
+        self.step += (n + batch - 1) // batch
+
     def encode(self, data, idx, B, xmean, xcov, train=False):
         L.check(_raw.favae_vae_encode(self.h, L.ptr(data), L.ptr(idx), _i(B), ctypes.c_void_p(xmean.data_ptr()),
                                       ctypes.c_void_p(xcov.data_ptr()), _i(int(train)), L.stream_ptr()))

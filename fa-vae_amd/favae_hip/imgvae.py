@@ -256,9 +256,17 @@ class ImgVAE(VAE):
             perm_d, eps_d = perm.to(torch.int32).to(self.device), eps.to(self.device)
             if not dist.active():
                 e.train_epoch(data, perm_d, eps_d, prior, tau_f, float(beta), float(self.var_x), float(self.lr), self.BATCH, metrics)
+            elif dist.native_comm(self.device) is not None:
+                # data parallel over the N shards, RCCL driven from the executor's own launch loop: one call per epoch
+                # (bucketed all-reduce + bucket-wise Adam under the backward pass; favae_vae_train_epoch_dp)
+                e.train_epoch_dp(dist.native_comm(self.device), data, perm_d, eps_d, prior, tau_f, float(beta), float(self.var_x),
+                                 float(self.lr), self.BATCH, metrics)
+                dist.mean_(metrics)
+                dist.mean_(e.BUF)
             else:
-                # data parallel over the N shards: every rank runs its own mini-batch of 64, gradients are averaged over
-                # RCCL before the (replicated) Adam step; BN batch statistics stay per rank (group size 64, as :218)
+                # the same through torch.distributed (gloo rehearsals, or when the native communicator is not available):
+                # every rank runs its own mini-batch of 64, gradients are averaged before the (replicated) Adam step; BN
+                # batch statistics stay per rank (group size 64, as :218)
                 # The gradient arena is averaged in three buckets; the all-reduce of a bucket runs on a communication
                 # stream while the layers behind it are still in their backward pass (decoder bucket under the whole
                 # encoder backward).

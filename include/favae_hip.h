@@ -231,6 +231,26 @@ int favae_vae_train_stages(favae_vae* h, const float* data_nhwc, const int* idx,
 /* Orders stream `waiting` behind everything queued so far on `stream` and on the handle's weight-gradient stream (the
  * gradients of the stages issued so far are complete for work enqueued on `waiting` afterwards).  Blocks nothing. */
 int favae_vae_fence(favae_vae* h, void* stream, void* waiting);
+
+/* ---- data-parallel epoch over RCCL (xGMI) ---------------------------------------------------------------------- */
+/* No reference counterpart (the reference is single-device).  One process per GPU; rank 0 calls favae_comm_unique_id, the
+ * 128 bytes travel to the other ranks (the caller's bootstrap, e.g. a torch.distributed broadcast), every rank calls
+ * favae_comm_init with its device current (collective: ncclCommInitRank).  RCCL is resolved at run time from the copy the
+ * process already holds (PyTorch's); rccl_path (may be NULL) names a librccl.so to load if there is none. */
+typedef struct favae_comm favae_comm;
+int favae_comm_unique_id(const char* rccl_path, void* id128);
+int favae_comm_init(favae_comm** out, const char* rccl_path, const void* id128, int rank, int nranks);
+int favae_comm_destroy(favae_comm* c);
+/* In-place all-reduce (sum, or mean with average != 0) of n floats on `stream`. */
+int favae_allreduce_f32(favae_comm* c, float* buf, long long n, int average, void* stream);
+/* favae_vae_train_epoch for data-parallel training (each rank passes its own shard / permutation / eps): per step the
+ * gradient arena is averaged over the ranks in three buckets (decoder | enc.3-4 + heads | enc.0-2); a bucket's all-reduce
+ * and the Adam step + weight re-layout of its layers run on the communicator's stream as soon as its last weight
+ * gradient is complete, under the backward pass of the layers behind it; the next forward pass waits for that stream.
+ * Same arithmetic as fwd/bwd -> all-reduce(mean) -> Adam (replicated parameters stay bit-identical across ranks). */
+int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float* data_nhwc, const int* perm, long long n, int batch,
+                             const float* eps, const double* prior, float tau, float beta, float var_x, float lr,
+                             long long step0, double* metrics, void* stream);
 /* optim.step() (:250) + weight re-layout. */
 int favae_vae_adam(favae_vae* h, float lr, float beta1, float beta2, float eps, long long step, void* stream);
 /* all mini-batches of one epoch (:227-255) on one device. perm [n], eps [n][z] in visiting order, metrics [steps][2]. */

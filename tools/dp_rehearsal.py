@@ -14,8 +14,11 @@ from favae_hip import imgvae
 rs = np.random.RandomState(1)
 img = rs.rand(N, 3, 64, 64).astype(np.float32)
 res = {}
-for mode in ("epoch", "dp"):
-    os.environ["FAVAE_FORCE_DP"] = "1" if mode == "dp" else "0"
+from favae_hip import dist as fdist
+for mode in ("epoch", "dp_native", "dp_torch"):
+    os.environ["FAVAE_FORCE_DP"] = "0" if mode == "epoch" else "1"
+    os.environ["FAVAE_NATIVE_COMM"] = "0" if mode == "dp_torch" else "1"
+    fdist.shutdown()
     torch.manual_seed(0)
     vae = imgvae.ImgVAE(dimx=20, channels=3, lr=1e-3, dataset="rehearsal")
     vae.trainloop(img, epochs=1)
@@ -26,6 +29,9 @@ for mode in ("epoch", "dp"):
     dt = time.time() - t
     res[mode] = (dt, list(vae.elbo_training))
     print("%s: %.3f ms/step  elbo %s" % (mode, 1e3 * dt / (2 * ((N + 63) // 64)), vae.elbo_training), flush=True)
-a, b = np.array(res["epoch"][1]), np.array(res["dp"][1])
-print("relative ELBO difference epoch vs dp path:", float(np.abs(a - b).max() / np.abs(a).max()))
+a = np.array(res["epoch"][1])
+for mode in ("dp_native", "dp_torch"):
+    b = np.array(res[mode][1])
+    print("relative ELBO difference epoch vs %s path:" % mode, float(np.abs(a - b).max() / np.abs(a).max()))
+fdist.shutdown()
 td.destroy_process_group()
