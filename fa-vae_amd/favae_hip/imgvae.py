@@ -75,6 +75,9 @@ class ImgVAE(VAE):
         self.reconstruc_during_training, self.KL_QandP, self.KL_during_training = [], [], []
         self._eng = None
         self._synced_version = None
+        # defer_pull: a coordinator that calls trainloop many times (SSHIBA.fit) sets it and calls sync() when it is done, so
+        # the 150 MB of parameters + Adam moments are not copied back to the nn.Module after every trainloop
+        self.defer_pull, self._stale = False, False
         self._img_key, self._data_dev = None, None
         self.x_mean_dev = self.x_cov_dev = None
 
@@ -82,6 +85,7 @@ class ImgVAE(VAE):
     def __getstate__(self):
         self._pull()
         st = self.__dict__.copy()
+        st["_stale"] = False
         for k in ("_eng", "_data_dev", "x_mean_dev", "x_cov_dev", "_ckp", "_img_src"):
             st[k] = None
         st["_synced_version"], st["_img_key"] = None, None
@@ -116,6 +120,16 @@ class ImgVAE(VAE):
             e.pack(v, e.V)
             e.step = int(max(float(st[p]["step"]) for p in st))
         self._synced_version = self._version()
+        self._stale = False
+
+    def sync(self):
+        """Bring the nn.Module parameters / buffers / torch optimiser state up to date with the executor (no-op if they are)."""
+        if getattr(self, "_stale", False):
+            self._pull()
+
+    def state_dict(self, *a, **k):
+        self.sync()
+        return super().state_dict(*a, **k)
 
     def _pull(self):
         """Copy the trained parameters, BN buffers and Adam moments back into the nn.Module / torch optimiser."""
@@ -137,6 +151,7 @@ class ImgVAE(VAE):
                 self.optim.state[p] = {"step": torch.tensor(float(e.step)), "exp_avg": m[k].to(p.device),
                                        "exp_avg_sq": v[k].to(p.device)}
         self._synced_version = self._version()
+        self._stale = False
 
     def load_state_dict(self, state_dict, strict=True):
         out = super().load_state_dict(state_dict, strict)
@@ -300,7 +315,10 @@ class ImgVAE(VAE):
                            str(self.dataset) + " Gaussian LogLikelihood": float(-self.reconstruc_during_training[-1]),
                            str(self.dataset) + " KL(Q||P)": float(self.KL_QandP[-1])})
         self.training = True
-        self._pull()
+        if self.defer_pull:
+            self._stale = True
+        else:
+            self._pull()
         if not self.elbo_training:
             return True
         return abs(1 - np.mean(self.elbo_training[-10:]) / self.elbo_training[-1]) > 1e-4

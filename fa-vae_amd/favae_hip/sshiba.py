@@ -232,6 +232,7 @@ class SSHIBA(object):
                 self.img_vae[m] = self.img_vae_module.ImgVAE(dimx=arg["latent_dim"], channels=data.shape[1], lr=arg["lr"],
                                                              h=data.shape[2], w=data.shape[3], dataset=arg["dataset"],
                                                              latentspace_lr=self.latentspace_lr)
+                self.img_vae[m].defer_pull = True      # fit_iterate syncs the nn.Module once, when it returns
             else:                                                                                    # :269-289 (SS_sep = 0)
                 tdata = data.astype(float)
                 mask = np.isnan(tdata)
@@ -305,9 +306,17 @@ class SSHIBA(object):
             self.fit_iterate(**kwargs)
 
     # ---- fit_iterate (:383-451) ----------------------------------------------------------------------------------
-    def fit_iterate(self, max_iter=int(1e3), pruning_crit=1e-6, tol=1e-5, feat_crit=1e-6, perc=False, verbose=0, Y_tst=[None],
-                    X_tst=[None], X_tr=[None], HL=0, AUC=0, ACC=0, mse=0, R2=0, m_in=[0], m_out=1, steps=50, nnd=None,
-                    pretrained=0, mc_it=1, Y_ss=None, store=False, xga=None, tgx=None, lr=None):
+    def fit_iterate(self, *args, **kwargs):
+        try:
+            return self._fit_iterate(*args, **kwargs)
+        finally:                       # the image models' nn.Module parameters / optimiser state follow the executor once
+            for vae in self.img_vae:
+                if vae is not None:
+                    vae.sync()
+
+    def _fit_iterate(self, max_iter=int(1e3), pruning_crit=1e-6, tol=1e-5, feat_crit=1e-6, perc=False, verbose=0, Y_tst=[None],
+                     X_tst=[None], X_tr=[None], HL=0, AUC=0, ACC=0, mse=0, R2=0, m_in=[0], m_out=1, steps=50, nnd=None,
+                     pretrained=0, mc_it=1, Y_ss=None, store=False, xga=None, tgx=None, lr=None):
         q = self.q_dist
         for i in range(max_iter):
             self.update(iter_count=i)
