@@ -70,8 +70,6 @@ int load_rccl(const char* path) {
 struct favae_comm {
     ncclComm_t comm;
     int rank, nranks;
-    hipStream_t stream;      // communication stream (collectives + the bucket-wise optimiser step behind them)
-    hipEvent_t done;
 };
 
 extern "C" int favae_comm_unique_id(const char* rccl_path, void* id128) {
@@ -89,19 +87,12 @@ extern "C" int favae_comm_init(favae_comm** out, const char* rccl_path, const vo
     if (rc) return rc;
     favae_comm* c = new (std::nothrow) favae_comm();
     FAVAE_CHECK_ARG(c, "favae_comm_init: out of host memory");
-    c->rank = rank; c->nranks = nranks; c->comm = nullptr; c->stream = nullptr; c->done = nullptr;
+    c->rank = rank; c->nranks = nranks; c->comm = nullptr;
     ncclUniqueId id;
     memcpy((void*)&id, id128, sizeof(id));
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);      // collective: every rank calls it
     if (r != ncclSuccess) {
         favae_set_error("favae_comm_init: ncclCommInitRank -> %s", g_rccl.GetErrorString(r));
-        delete c;
-        return FAVAE_ERR_HIP;
-    }
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
-        favae_set_error("favae_comm_init: could not create the communication stream / event");
-        (void)g_rccl.CommDestroy(c->comm);
         delete c;
         return FAVAE_ERR_HIP;
     }
@@ -111,10 +102,8 @@ extern "C" int favae_comm_init(favae_comm** out, const char* rccl_path, const vo
 
 extern "C" int favae_comm_destroy(favae_comm* c) {
     if (!c) return FAVAE_OK;
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();
     if (c->comm) (void)g_rccl.CommDestroy(c->comm);
-    (void)hipEventDestroy(c->done);
-    (void)hipStreamDestroy(c->stream);
     delete c;
     return FAVAE_OK;
 }
@@ -126,6 +115,4 @@ extern "C" int favae_allreduce_f32(favae_comm* c, float* buf, long long n, int a
 }
 
 // ---- internal (vae_model.hip) ----------------------------------------------------------------------------------------
-hipStream_t favae_comm_stream(favae_comm* c) { return c->stream; }
-hipEvent_t favae_comm_event(favae_comm* c) { return c->done; }
 int favae_comm_size(favae_comm* c) { return c->nranks; }

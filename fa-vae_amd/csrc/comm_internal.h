@@ -2,6 +2,4 @@
 #pragma once
 #include <hip/hip_runtime.h>
 struct favae_comm;
-hipStream_t favae_comm_stream(favae_comm* c);
-hipEvent_t favae_comm_event(favae_comm* c);
 int favae_comm_size(favae_comm* c);

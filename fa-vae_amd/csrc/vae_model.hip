@@ -91,11 +91,12 @@ struct Vae {
     bool stats_fused[NL], grad_fused[NL];
     // weight gradients run on a second stream next to the dgrad -> BN-backward chain of the main stream
     // and the layer-wise optimiser steps of an epoch on a third (side2), behind the weight gradient of their layer
-    hipStream_t side, side2; hipEvent_t ev_fork[NL]; hipEvent_t ev_dg[NL]; hipEvent_t ev_wg[NL]; hipEvent_t ev_join; bool overlap;
+    hipStream_t side, side2, side3; hipEvent_t ev_comm; hipEvent_t ev_fork[NL]; hipEvent_t ev_dg[NL]; hipEvent_t ev_wg[NL]; hipEvent_t ev_join; bool overlap;
     // single-device epochs: Adam + weight re-layout of a layer follow its weight gradient on the side stream
     // epoch: steps of one epoch run back to back: Adam clears the gradients it has consumed (no memset per step) and the
     // main stream joins the side stream only when the next step's forward pass is about to read the weights
     struct { bool on; float lr, b1, b2, eps; long long step; int pending; bool epoch; } ada;
+    int stream_score;   // ensure_streams: 21 = all three side streams run beside the main stream and each other
     bool join_pending; bool dg_all;
     bool dp_epoch;   // steps of favae_vae_train_epoch_dp: gradients cleared by the bucket-wise Adam, joins through the communication stream
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
@@ -195,6 +196,67 @@ int bins_for(long long rows) {
     int nb = 4;
     while (nb < MAX_BINS && (long long)nb * 16 * 64 < rows) nb *= 2;
     return nb;
+}
+
+// ---- side streams on hardware queues of their own ----------------------------------------------------------------
+// The runtime hands out its few hardware queues (4 per process here) to streams round-robin, so a side stream created
+// after some other streams of the process (torch, RCCL, a second executor) can land on the hardware queue of the main
+// stream and then runs serialised with it (measured: 1.15 -> 1.54 ms per step).  Which queue a stream got is not exposed,
+// so it is measured once, at the first training step: a bounded ~150 us spin on one stream, time stamps on the others; a
+// stamp taken before the spin ended ran beside it, i.e. on another queue.  Of 4 consecutively created streams the three
+// that run beside the main stream and beside each other become the weight-gradient, optimiser and communication streams.
+__global__ void probe_spin(unsigned long long ticks, unsigned long long* out) {
+    const unsigned long long t0 = wall_clock64();
+    int it = 0;
+    while (wall_clock64() - t0 < ticks && ++it < (1 << 13)) __builtin_amdgcn_s_sleep(8);   // bounded either way
+    if (threadIdx.x == 0) *out = wall_clock64();
+}
+__global__ void probe_stamp(unsigned long long* out) {
+    if (threadIdx.x == 0) *out = wall_clock64();
+}
+
+int ensure_streams(Vae& v, hipStream_t main) {
+    if (v.side) return FAVAE_OK;
+    constexpr int NC = 4, NS = NC + 1;
+    hipStream_t s[NS] = {main, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 1; i < NS; ++i) FAVAE_HIP(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
+    unsigned long long* buf = (unsigned long long*)v.scratch;      // NS*NS stamps; the scratch is idle before the first step
+    unsigned long long host[NS * NS];
+    bool beside[NS][NS];
+    const char* e = getenv("FAVAE_STREAM_PROBE");
+    const bool probe = !(e && e[0] == '0');
+    for (int i = 0; i < NS; ++i)
+        for (int j = 0; j < NS; ++j) beside[i][j] = i != j;
+    if (probe) {
+        FAVAE_HIP(hipDeviceSynchronize());
+        for (int i = 0; i < NS; ++i) {
+            hipLaunchKernelGGL(probe_spin, dim3(1), dim3(64), 0, s[i], 15000ULL, buf + i * NS + i);   // 100 MHz clock: 150 us
+            for (int j = 0; j < NS; ++j)
+                if (j != i) hipLaunchKernelGGL(probe_stamp, dim3(1), dim3(64), 0, s[j], buf + i * NS + j);
+            FAVAE_HIP(hipGetLastError());
+            FAVAE_HIP(hipDeviceSynchronize());
+        }
+        FAVAE_HIP(hipMemcpy(host, buf, sizeof(host), hipMemcpyDeviceToHost));
+        for (int i = 0; i < NS; ++i)
+            for (int j = 0; j < NS; ++j)
+                if (i != j) beside[i][j] = host[i * NS + j] < host[i * NS + i];
+    }
+    auto ok2 = [&](int a, int b) { return beside[a][b] && beside[b][a]; };
+    int pick[3] = {-1, -1, -1}, best = -1;
+    for (int a = 1; a < NS; ++a)
+        for (int b = 1; b < NS; ++b)
+            for (int c = 1; c < NS; ++c) {
+                if (a == b || a == c || b == c) continue;
+                // what matters most: weight gradients beside the main chain, then the optimiser / communication streams
+                const int score = 8 * ok2(0, a) + 4 * ok2(0, b) + 4 * ok2(0, c) + 2 * ok2(a, b) + 2 * ok2(a, c) + ok2(b, c);
+                if (score > best) { best = score; pick[0] = a; pick[1] = b; pick[2] = c; }
+            }
+    v.side = s[pick[0]]; v.side2 = s[pick[1]]; v.side3 = s[pick[2]];
+    for (int i = 1; i < NS; ++i)
+        if (i != pick[0] && i != pick[1] && i != pick[2]) (void)hipStreamDestroy(s[i]);
+    v.stream_score = best;
+    if (getenv("FAVAE_VERBOSE")) fprintf(stderr, "favae: side streams picked %d %d %d of 4 (score %d of 21)\n", pick[0], pick[1], pick[2], best);
+    return FAVAE_OK;
 }
 
 int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false) {
@@ -443,6 +505,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.overlap = !(e && e[0] == '1');
     v.side = nullptr;
     v.side2 = nullptr;
+    v.side3 = nullptr;
     v.ada = {false, 0.f, 0.f, 0.f, 0.f, 0, -1, false};
     v.join_pending = false;
     v.dp_epoch = false;
@@ -455,8 +518,8 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
         v.fuse = f ? (unsigned)strtoul(f, nullptr, 0) : 0x17bu;   // 128 (fused Adam) measured slower in the step: its bandwidth bursts sit on the main chain   // 4 (thin-input path) measured slower: the prefetch costs occupancy
     }
     if (v.overlap) {
-        bool ok = hipStreamCreateWithFlags(&v.side, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipStreamCreateWithFlags(&v.side2, hipStreamNonBlocking) == hipSuccess;
+        // the side streams themselves are created at the first training step (ensure_streams), next to the caller's stream
+        bool ok = hipEventCreateWithFlags(&v.ev_comm, hipEventDisableTiming) == hipSuccess;
         for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_wg[l], hipEventDisableTiming) == hipSuccess;
         for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_fork[l], hipEventDisableTiming) == hipSuccess;
         for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_dg[l], hipEventDisableTiming) == hipSuccess;
@@ -473,13 +536,12 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
 
 extern "C" int favae_vae_destroy(favae_vae* h) {
     if (h && h->v.ev_fence_ok) { (void)hipEventDestroy(h->v.ev_fence[0]); (void)hipEventDestroy(h->v.ev_fence[1]); }
-    if (h && h->v.overlap && h->v.side) {
-        (void)hipStreamSynchronize(h->v.side);
-        (void)hipStreamSynchronize(h->v.side2);
+    if (h && h->v.overlap) {
+        for (hipStream_t q : {h->v.side, h->v.side2, h->v.side3})
+            if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+        (void)hipEventDestroy(h->v.ev_comm);
         for (int l = 0; l < NL; ++l) { (void)hipEventDestroy(h->v.ev_fork[l]); (void)hipEventDestroy(h->v.ev_dg[l]); (void)hipEventDestroy(h->v.ev_wg[l]); }
-        (void)hipStreamDestroy(h->v.side2);
         (void)hipEventDestroy(h->v.ev_join);
-        (void)hipStreamDestroy(h->v.side);
     }
     delete h;
     return FAVAE_OK;
@@ -512,6 +574,7 @@ constexpr int N_STAGES = 13;
 int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const float* eps, const double* prior, float tau,
                  float beta, float var_x, double* metrics2_out, int stage_lo, int stage_hi, void* st) {
     const bool epoch = (v.overlap && v.ada.on && v.ada.epoch) || v.dp_epoch;
+    if (v.overlap) RC(ensure_streams(v, (hipStream_t)st));
     if (stage_lo == 0) {
         if (!epoch) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));
         FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, (hipStream_t)st));
@@ -639,7 +702,7 @@ extern "C" int favae_vae_fence(favae_vae* h, void* st, void* waiting) {
     }
     FAVAE_HIP(hipEventRecord(v.ev_fence[0], (hipStream_t)st));
     FAVAE_HIP(hipStreamWaitEvent((hipStream_t)waiting, v.ev_fence[0], 0));
-    if (v.overlap) {
+    if (v.overlap && v.side) {
         FAVAE_HIP(hipEventRecord(v.ev_fence[1], v.side));
         FAVAE_HIP(hipStreamWaitEvent((hipStream_t)waiting, v.ev_fence[1], 0));
     }
@@ -690,8 +753,9 @@ extern "C" int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float
     FAVAE_CHECK_ARG(h && c && perm && metrics && n >= 1 && batch >= 1, "favae_vae_train_epoch_dp: bad argument");
     Vae& v = h->v;
     FAVAE_CHECK_ARG(v.overlap, "favae_vae_train_epoch_dp needs the weight-gradient stream (FAVAE_SINGLE_STREAM is set)");
-    hipStream_t cs = favae_comm_stream(c);
-    hipEvent_t done = favae_comm_event(c);
+    RC(ensure_streams(v, (hipStream_t)st));
+    hipStream_t cs = v.side3;          // collectives + the bucket-wise optimiser step behind them
+    hipEvent_t done = v.ev_comm;
     // (arena_lo, arena_hi, first layer, last layer, stage_hi): the slice is complete once backward stages < stage_hi ran
     const long long w3 = v.L[3].w_off, w6 = v.L[6].w_off;
     const struct { long long lo, hi; int l0, l1, stage_hi; } bk[3] = {{w6, v.nparam, 6, NL - 1, 7}, {w3, w6, 3, 5, 10}, {0, w3, 0, 2, N_STAGES}};

@@ -5,6 +5,11 @@ for p in (ROOT, os.path.join(ROOT, "fa-vae_amd"), os.path.join(ROOT, "fa-vae_amd
     sys.path.insert(0, p)
 os.environ.setdefault("FAVAE_CONV_DTYPE", "bf16")
 import numpy as np, torch
+if os.environ.get("FAVAE_FORCE_DP") == "1":      # the multi-rank code path in a one-rank RCCL group
+    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29519"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+        os.environ.setdefault(k, v)
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("nccl", device_id=torch.device("cuda:0"))
 import favae
 from favae_hip import imgvae, sshiba
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
@@ -28,8 +33,11 @@ def timed(cls, name):
 for n in ("update_w", "update_Z", "update_b", "update_tau", "update_alpha", "update_x", "update_bound", "pruning", "depruning",
           "_refresh_xstats", "_zero_input_r2"):
     timed(sshiba.SSHIBA, n)
-for n in ("trainloop", "update_x", "reconstruction_r2"):
+for n in ("trainloop", "update_x", "reconstruction_r2", "restore_weights", "_prior_rows"):
     timed(imgvae.ImgVAE, n)
+from favae_hip import engine as _engine
+for n in ("train_epoch", "train_epoch_dp", "snapshot"):
+    timed(_engine.VaeEngine, n)
 def it():
     model.keep_training[0] = True
     model.update(iter_count=1); model.depruning(1e-15); model.L.append(model.update_bound()); model.pruning(1e-3)
