@@ -140,6 +140,21 @@ def test_staged_step_equals_the_whole_step(dtype):
     assert _rel(eng.G.cpu().numpy(), g0.cpu().numpy()) <= tol
 
 
+def test_data_parallel_epoch_over_rccl_one_rank():
+    """The multi-rank trainloop in a one-rank RCCL group (own process: it owns a process group): favae_vae_train_epoch_dp
+    through the library's communicator and the torch.distributed fallback both reproduce the single-device epochs
+    (same data, same draws; only the summation order of atomics differs)."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FAVAE_CONV_DTYPE="f32", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_rehearsal.py"), "1024"], env=env, capture_output=True,
+                         text=True, timeout=110)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "native communicator in use: True" in out.stdout
+    diffs = [float(x) for x in re.findall(r"relative ELBO difference epoch vs \w+ path: ([0-9.e+-]+)", out.stdout)]
+    assert len(diffs) == 2 and max(diffs) < 1e-3, out.stdout[-2000:]
+
+
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("bf16", 2e-2)])
 def test_eval_encoder_and_decoder_match_oracle(dtype, tol):
     z, Bn = 8, 24

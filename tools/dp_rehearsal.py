@@ -28,6 +28,8 @@ for mode in ("epoch", "dp_native", "dp_torch"):
     torch.cuda.synchronize()
     dt = time.time() - t
     res[mode] = (dt, list(vae.elbo_training))
+    if mode == "dp_native":
+        print("native communicator in use:", fdist.native_comm(torch.device("cuda:0")) is not None, flush=True)
     print("%s: %.3f ms/step  elbo %s" % (mode, 1e3 * dt / (2 * ((N + 63) // 64)), vae.elbo_training), flush=True)
 a = np.array(res["epoch"][1])
 for mode in ("dp_native", "dp_torch"):
