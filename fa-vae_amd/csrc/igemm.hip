@@ -450,6 +450,7 @@ struct PmParams {
     float* dw;
     int Rc, Cc, r_large, c_large;
     int Nb, Hs, Ws, Hl, Wl, ks, stride, pad, splitk, ntn, K;
+    int overwrite;  // unsplit reductions store instead of adding (the caller guarantees dw == 0: splitk < 0)
     int Rst, Cst;   // rows / columns of dw that exist (<= Rc, Cc: operands padded to whole vectors, see favae_conv_wgrad_folded)
 };
 
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
                     // one block per output element when the reduction is not split: add without an atomic (the
                     // gradient arena is zeroed per step; chip-wide float atomics run at ~1.3 TB/s, plain stores at 6)
                     float* dst = p.dw + ((size_t)row * ntaps + tap) * p.Cst + col;
-                    if (p.splitk > 1) atomicAdd(dst, acc[a][b][r]); else *dst += acc[a][b][r];
+                    if (p.splitk > 1) atomicAdd(dst, acc[a][b][r]); else if (p.overwrite) *dst = acc[a][b][r]; else *dst += acc[a][b][r];
                 }
             }
         }
@@ -652,6 +653,7 @@ int dispatch_pm(PmParams p, hipStream_t st) {
     // ~256 blocks: the weight gradients run on the side stream beside the main chain; a grid that fills the chip several
     // times over delays the main-stream kernels more than it shortens itself (tools/prof_step.py sweep)
     static const int pm_target = getenv("FAVAE_PM_TARGET") ? atoi(getenv("FAVAE_PM_TARGET")) : 256;
+    p.overwrite = p.splitk < 0;
     int sk = p.splitk > 0 ? p.splitk : std::min(std::max(1, nchunk / 8), std::max(1, (pm_target + blocks / 2) / blocks));
     p.splitk = std::max(1, std::min(sk, nchunk));
     dim3 grid(cdiv(p.Rc, BM) * p.ntn, p.splitk, p.ks * p.ks);

@@ -399,17 +399,17 @@ int wgrad_launch(Vae& v, int l, const void* in, int B, void* st) {
     const Layer& L = v.L[l];
     float* dw = v.G + L.w_off;
     if ((v.fuse & 64u) && v.ch <= 3 && (l == 0 || l == L_OUT))   // image-sized channel count on one side: one GEMM over folded taps
-        return favae_conv_wgrad_folded(v.draw[l], L.Cout, in, L.Cin, dw, B, L.Hout, L.Hout, L.Hin, L.Hin, l == 0 ? 2 : 1, 0, v.dtype,
+        return favae_conv_wgrad_folded(v.draw[l], L.Cout, in, L.Cin, dw, B, L.Hout, L.Hout, L.Hin, L.Hin, l == 0 ? 2 : 1, -1, v.dtype,
                                        v.fold, v.fold_bytes, st);
     switch (L.kind) {
     case CONV_S2:
-        return favae_conv_wgrad(v.draw[l], L.Cout, 0, in, L.Cin, 1, dw, B, L.Hout, L.Hout, L.Hin, L.Hin, 3, 2, 1, 0, v.dtype, st);
+        return favae_conv_wgrad(v.draw[l], L.Cout, 0, in, L.Cin, 1, dw, B, L.Hout, L.Hout, L.Hin, L.Hin, 3, 2, 1, -1, v.dtype, st);
     case CONV_S1:
-        return favae_conv_wgrad(v.draw[l], L.Cout, 0, in, L.Cin, 1, dw, B, L.Hout, L.Hout, L.Hin, L.Hin, 3, 1, 1, 0, v.dtype, st);
+        return favae_conv_wgrad(v.draw[l], L.Cout, 0, in, L.Cin, 1, dw, B, L.Hout, L.Hout, L.Hin, L.Hin, 3, 1, 1, -1, v.dtype, st);
     case CONVT_S2:
-        return favae_conv_wgrad(v.draw[l], L.Cout, 1, in, L.Cin, 0, dw, B, L.Hin, L.Hin, L.Hout, L.Hout, 3, 2, 1, 0, v.dtype, st);
+        return favae_conv_wgrad(v.draw[l], L.Cout, 1, in, L.Cin, 0, dw, B, L.Hin, L.Hin, L.Hout, L.Hout, 3, 2, 1, -1, v.dtype, st);
     default:
-        return favae_conv_wgrad(v.draw[l], L.Cout, 0, in, L.Cin, 0, dw, B, 1, 1, 1, 1, 1, 1, 0, 0, v.dtype, st);
+        return favae_conv_wgrad(v.draw[l], L.Cout, 0, in, L.Cin, 0, dw, B, 1, 1, 1, 1, 1, 1, 0, -1, v.dtype, st);   // splitk < 0: the gradient arena is zero here
     }
 }
 

@@ -65,6 +65,8 @@ int favae_conv_igemm_red(const void* in, const void* w, const float* bias, float
                          const float* invstd, int* fused, void* stream);
 
 /* Weight gradient  dw[r][tap][c] += sum_pixels rows[pix][r] * cols[pix'][c]  (fp32 atomics; caller zeroes dw).
+ * splitk: 0 = choose, > 0 = that many slices of the pixel range, < 0 = choose and dw is known to be all zero (an unsplit
+ * reduction then stores its result instead of reading the zeros back).
  * Exactly one of the two operands may be the large-spatial tensor (Hl x Wl), read at (s*h-p+kh, s*w-p+kw);
  * the other lives on the small grid (Hs x Ws).  Conv2d: rows = dout (small), cols = input (large).
  * ConvTranspose2d: rows = dout (large), cols = input (small).  Linear: 1x1 grids, ks=1.
