@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--latent", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the extra (untimed) iteration that splits VAE and FA time")
     a = ap.parse_args()
 
     if os.environ.get("FAVAE_HANG_DUMP"):                # debugging aid: dump all Python stacks after N seconds and exit
@@ -193,6 +194,34 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
 
+    # secondary figures of SURVEY 8(d), from ONE extra iteration outside the timed region with a device synchronisation
+    # around the VAE trainloop: VAE-step samples/s and FA-update samples/s (everything of the iteration but the trainloop)
+    secondary = None
+    if not a.no_secondary:
+        from favae_hip import imgvae as _iv
+        acc = {"trainloop": 0.0}
+        orig = _iv.ImgVAE.trainloop
+
+        def timed_trainloop(self, *args, **kw):
+            torch.cuda.synchronize()
+            ts = time.time()
+            r = orig(self, *args, **kw)
+            torch.cuda.synchronize()
+            acc["trainloop"] += time.time() - ts
+            return r
+        _iv.ImgVAE.trainloop = timed_trainloop
+        fence()
+        ts = time.time()
+        one_iteration()
+        fence()
+        tot = time.time() - ts
+        _iv.ImgVAE.trainloop = orig
+        rest = max(tot - acc["trainloop"], 1e-9)
+        secondary = {"vae_trainloop_samples_per_s": E_EPOCHS * a.n * ws / acc["trainloop"],
+                     "vae_ms_per_64_image_step": 1e3 * acc["trainloop"] / (E_EPOCHS * ((a.n + 63) // 64)),
+                     "fa_and_eval_passes_samples_per_s": a.n * ws / rest,
+                     "seconds": {"iteration": tot, "trainloop": acc["trainloop"], "fa_updates_update_x_reconstruction": rest}}
+
     if rank == 0:
         n_global = a.n * ws
         kern = []
@@ -226,6 +255,8 @@ def main():
                         "committed rocprofv3 --pmc passes (profiles/r1_pmc_traffic_per_launch.json)"},
             "kernels": kern,
         }
+        if secondary is not None:
+            out["secondary"] = secondary
         if ws == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.n, a.latent, a.kc)
         sys.stdout.flush()
