@@ -654,7 +654,8 @@ int dispatch_pm(PmParams p, hipStream_t st) {
     // times over delays the main-stream kernels more than it shortens itself (tools/prof_step.py sweep)
     static const int pm_target = getenv("FAVAE_PM_TARGET") ? atoi(getenv("FAVAE_PM_TARGET")) : 256;
     p.overwrite = p.splitk < 0;
-    int sk = p.splitk > 0 ? p.splitk : std::min(std::max(1, nchunk / 8), std::max(1, (pm_target + blocks / 2) / blocks));
+    int sk = p.splitk > 0 ? p.splitk : p.splitk < -1 ? -p.splitk   // < -1: that many slices of a gradient the caller zeroed
+                                     : std::min(std::max(1, nchunk / 8), std::max(1, (pm_target + blocks / 2) / blocks));
     p.splitk = std::max(1, std::min(sk, nchunk));
     dim3 grid(cdiv(p.Rc, BM) * p.ntn, p.splitk, p.ks * p.ks);
     ProfScope prof(10 + tile, 2.0 * p.Rc * (double)p.Cc * p.K * p.ks * p.ks, st);
@@ -771,6 +772,34 @@ extern "C" size_t favae_conv_wgrad_folded_scratch(int Nb, int Hl, int Wl, int dt
     return (size_t)Nb * Hl * Wl * 32 * (dtype == FAVAE_F32 ? 4 : 2) + 256;
 }
 
+extern "C" int favae_conv_fold_taps(const void* src, void* dst, size_t dst_bytes, int Nb, int Hs, int Ws, int Hl, int Wl, int C,
+                                    int stride, int shifted, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(src && dst, "favae_conv_fold_taps: null pointer");
+    FAVAE_CHECK_ARG(Nb > 0 && Hs > 0 && Ws > 0 && C >= 1 && C <= 3, "favae_conv_fold_taps: bad shape (1..3 channels)");
+    FAVAE_CHECK_ARG(stride == 1 || (stride == 2 && !shifted), "favae_conv_fold_taps: stride");
+    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_conv_fold_taps: dtype");
+    FAVAE_CHECK_ARG(shifted ? (Hs == Hl && Ws == Wl) : (Hs == (Hl + 2 - 3) / stride + 1 && Ws == (Wl + 2 - 3) / stride + 1),
+                    "favae_conv_fold_taps: small/large size mismatch");
+    FAVAE_CHECK_ARG((size_t)Nb * Hl * Wl < (1u << 31), "favae_conv_fold_taps: too many pixels");
+    const size_t need = (size_t)Nb * Hs * Ws * 32 * (dtype == FAVAE_F32 ? 4 : 2);
+    FAVAE_CHECK_ARG(need <= dst_bytes && ((uintptr_t)dst % 16) == 0, "favae_conv_fold_taps: dst holds %zu bytes, %zu needed (16-byte aligned)", dst_bytes, need);
+    return fold_taps_launch(src, dst, Nb, Hs, Ws, Hl, Wl, C, stride, shifted, dtype, (hipStream_t)stream);
+}
+
+extern "C" int favae_conv_wgrad_prefolded(const void* rows, int Rc, int Rst, const void* cols, int Cc, int Cst, float* dw,
+                                          long long K, int splitk, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(rows && cols && dw, "favae_conv_wgrad_prefolded: null pointer");
+    FAVAE_CHECK_ARG(K > 0 && K < (1ll << 31) && Rc > 0 && Cc > 0 && Rst >= 1 && Rst <= Rc && Cst >= 1 && Cst <= Cc, "favae_conv_wgrad_prefolded: bad shape");
+    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_conv_wgrad_prefolded: dtype");
+    const int ve = dtype == FAVAE_F32 ? 4 : 8;
+    FAVAE_CHECK_ARG(Rc % ve == 0 && Cc % ve == 0, "favae_conv_wgrad_prefolded: channel counts must fill 16-byte vectors");
+    FAVAE_CHECK_ARG(((uintptr_t)rows % 16) == 0 && ((uintptr_t)cols % 16) == 0, "favae_conv_wgrad_prefolded: 16-byte alignment");
+    PmParams p;
+    p.rp = rows; p.cp = cols; p.dw = dw; p.Rc = Rc; p.Cc = Cc; p.Rst = Rst; p.Cst = Cst; p.r_large = 0; p.c_large = 0;
+    p.Nb = 1; p.Hs = 1; p.Ws = (int)K; p.Hl = 1; p.Wl = (int)K; p.ks = 1; p.stride = 1; p.pad = 0; p.splitk = splitk; p.ntn = 1; p.K = (int)K;
+    return dtype == FAVAE_F32 ? dispatch_pm<float>(p, (hipStream_t)stream) : dispatch_pm<bf16_t>(p, (hipStream_t)stream);
+}
+
 extern "C" int favae_conv_wgrad_folded(const void* rows, int Rc, const void* cols, int Cc, float* dw, int Nb, int Hs, int Ws,
                                        int Hl, int Wl, int stride, int splitk, int dtype, void* scratch, size_t scratch_bytes,
                                        void* stream) {
@@ -779,33 +808,18 @@ extern "C" int favae_conv_wgrad_folded(const void* rows, int Rc, const void* col
     FAVAE_CHECK_ARG(stride == 1 || stride == 2, "favae_conv_wgrad_folded: stride");
     FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_conv_wgrad_folded: dtype");
     FAVAE_CHECK_ARG(Hs == (Hl + 2 - 3) / stride + 1 && Ws == (Wl + 2 - 3) / stride + 1, "favae_conv_wgrad_folded: small/large size mismatch");
-    FAVAE_CHECK_ARG((size_t)Nb * Hl * Wl < (1u << 31), "favae_conv_wgrad_folded: too many pixels");
     const bool fold_cols = Cc <= 3, fold_rows = !fold_cols && Rc <= 3 && stride == 1;
     FAVAE_CHECK_ARG(fold_cols || fold_rows, "favae_conv_wgrad_folded: needs <= 3 channels on the image side (cols) or, at stride 1, on rows");
-    FAVAE_CHECK_ARG(((uintptr_t)scratch % 16) == 0 && ((uintptr_t)(fold_cols ? rows : cols) % 16) == 0, "favae_conv_wgrad_folded: 16-byte alignment");
-    FAVAE_CHECK_ARG((fold_cols ? Rc : Cc) % (dtype == FAVAE_F32 ? 4 : 8) == 0, "favae_conv_wgrad_folded: wide channel count must fill 16-byte vectors");
-    hipStream_t st = (hipStream_t)stream;
-    const int esz = dtype == FAVAE_F32 ? 4 : 2;
-    PmParams p;
-    p.dw = dw; p.r_large = 0; p.c_large = 0; p.Nb = Nb; p.ks = 1; p.stride = 1; p.pad = 0; p.splitk = splitk; p.ntn = 1;
     if (fold_cols) {
         // dw[r][tap][c] = sum_pix rows[pix][r] * cols[nb(pix, tap)][c]: columns (tap, c) gathered once into [pix][32]
-        const size_t need = (size_t)Nb * Hs * Ws * 32 * esz;
-        FAVAE_CHECK_ARG(need <= scratch_bytes, "favae_conv_wgrad_folded: scratch %zu < %zu", scratch_bytes, need);
-        int rc = fold_taps_launch(cols, scratch, Nb, Hs, Ws, Hl, Wl, Cc, stride, 0, dtype, st);
+        int rc = favae_conv_fold_taps(cols, scratch, scratch_bytes, Nb, Hs, Ws, Hl, Wl, Cc, stride, 0, dtype, stream);
         if (rc) return rc;
-        p.rp = rows; p.cp = scratch; p.Rc = Rc; p.Cc = 32; p.Rst = Rc; p.Cst = 9 * Cc;
-        p.Hs = Hs; p.Ws = Ws; p.Hl = Hs; p.Wl = Ws; p.K = Nb * Hs * Ws;
-    } else {
-        // stride 1: the same sum over the pixels of the wide operand, the narrow one shifted: rows (r, tap) into [pix'][32]
-        const size_t need = (size_t)Nb * Hl * Wl * 32 * esz;
-        FAVAE_CHECK_ARG(need <= scratch_bytes, "favae_conv_wgrad_folded: scratch %zu < %zu", scratch_bytes, need);
-        int rc = fold_taps_launch(rows, scratch, Nb, Hl, Wl, Hs, Ws, Rc, 1, 1, dtype, st);
-        if (rc) return rc;
-        p.rp = scratch; p.cp = cols; p.Rc = 32; p.Cc = Cc; p.Rst = 9 * Rc; p.Cst = Cc;
-        p.Hs = Hl; p.Ws = Wl; p.Hl = Hl; p.Wl = Wl; p.K = Nb * Hl * Wl;
+        return favae_conv_wgrad_prefolded(rows, Rc, Rc, scratch, 32, 9 * Cc, dw, (long long)Nb * Hs * Ws, splitk, dtype, stream);
     }
-    return dtype == FAVAE_F32 ? dispatch_pm<float>(p, st) : dispatch_pm<bf16_t>(p, st);
+    // stride 1: the same sum over the pixels of the wide operand, the narrow one shifted: rows (r, tap) into [pix'][32]
+    int rc = favae_conv_fold_taps(rows, scratch, scratch_bytes, Nb, Hl, Wl, Hs, Ws, Rc, 1, 1, dtype, stream);
+    if (rc) return rc;
+    return favae_conv_wgrad_prefolded(scratch, 32, 9 * Rc, cols, Cc, Cc, dw, (long long)Nb * Hl * Wl, splitk, dtype, stream);
 }
 
 extern "C" int favae_debug_force_tile(int kc_tile, int pm_tile) {

@@ -101,9 +101,10 @@ struct Vae {
     bool dp_epoch;   // steps of favae_vae_train_epoch_dp: gradients cleared by the bucket-wise Adam, joins through the communication stream
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
     hipEvent_t ev_join_ext;   // when set: the event join_pending refers to (the communicator's), else ev_join
-    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients, 128 Adam + weight re-layout in one pass, 256 final conv + loss in one launch
+    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients (0x200: do not hoist encoder.0's gather to the start of the step), 128 Adam + weight re-layout in one pass, 256 final conv + loss in one launch
     float* xf_alt; char* xt_alt;
     char* wk_out;   // weights of final_layer.3 in the MFMA operand order for favae_conv_out_ll (rebuilt whenever the layer changes)
+    char* fold0; size_t fold0_bytes; hipEvent_t ev_x; bool x_folded;   // encoder.0's folded input batch, gathered on the side stream while the forward pass runs
     char* fold; size_t fold_bytes;   // [pixels][32] tap-folded operand of the two image-side weight gradients (side stream only)   // second batch buffer: the next gather must not overwrite what wgrad(encoder.0) still reads
     const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(SH + L[l].wc_off * esz); }
     const void* Wt(int l) const { return (const void*)(SH + L[l].wt_off * esz); }
@@ -180,6 +181,8 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
     v.wk_out = (char*)c.take(9 * 16 * 16 * 4);
     v.fold_bytes = favae_conv_wgrad_folded_scratch(B, 64, 64, v.dtype);
     v.fold = (char*)c.take(v.fold_bytes);
+    v.fold0_bytes = (size_t)B * 32 * 32 * 32 * v.esz;
+    v.fold0 = (char*)c.take(v.fold0_bytes);
     v.zlat = (char*)c.take((size_t)B * v.z * v.esz);
     v.stdq = (float*)c.take((size_t)B * v.z * 4);
     v.s1s2 = (float*)c.take(2 * 1024 * 4);
@@ -398,6 +401,10 @@ int adam_layer(Vae& v, int l, void* st) {
 int wgrad_launch(Vae& v, int l, const void* in, int B, void* st) {
     const Layer& L = v.L[l];
     float* dw = v.G + L.w_off;
+    if (l == 0 && v.x_folded) {   // the batch was folded at the start of the step (train_stages)
+        // (256 slices of the 65536-pixel reduction, the automatic choice: 64 to 1024 measured the same or slower)
+        return favae_conv_wgrad_prefolded(v.draw[0], L.Cout, L.Cout, v.fold0, 32, 9 * L.Cin, dw, (long long)B * L.Hout * L.Hout, -1, v.dtype, st);
+    }
     if ((v.fuse & 64u) && v.ch <= 3 && (l == 0 || l == L_OUT))   // image-sized channel count on one side: one GEMM over folded taps
         return favae_conv_wgrad_folded(v.draw[l], L.Cout, in, L.Cin, dw, B, L.Hout, L.Hout, L.Hin, L.Hin, l == 0 ? 2 : 1, -1, v.dtype,
                                        v.fold, v.fold_bytes, st);
@@ -511,6 +518,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.dp_epoch = false;
     v.ev_join_ext = nullptr;
     v.ev_fence_ok = false;
+    v.x_folded = false;
     {
         const char* d = getenv("FAVAE_DG_EVENTS");
         v.dg_all = d && d[0] == '1';
@@ -520,6 +528,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     if (v.overlap) {
         // the side streams themselves are created at the first training step (ensure_streams), next to the caller's stream
         bool ok = hipEventCreateWithFlags(&v.ev_comm, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&v.ev_x, hipEventDisableTiming) == hipSuccess;
         for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_wg[l], hipEventDisableTiming) == hipSuccess;
         for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_fork[l], hipEventDisableTiming) == hipSuccess;
         for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_dg[l], hipEventDisableTiming) == hipSuccess;
@@ -540,6 +549,7 @@ extern "C" int favae_vae_destroy(favae_vae* h) {
         for (hipStream_t q : {h->v.side, h->v.side2, h->v.side3})
             if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
         (void)hipEventDestroy(h->v.ev_comm);
+        (void)hipEventDestroy(h->v.ev_x);
         for (int l = 0; l < NL; ++l) { (void)hipEventDestroy(h->v.ev_fork[l]); (void)hipEventDestroy(h->v.ev_dg[l]); (void)hipEventDestroy(h->v.ev_wg[l]); }
         (void)hipEventDestroy(h->v.ev_join);
     }
@@ -580,6 +590,15 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
         FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, (hipStream_t)st));
         if (epoch) { std::swap(v.xf, v.xf_alt); std::swap(v.xt, v.xt_alt); }
         RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, v.xf, v.xt, v.dtype, st));
+        v.x_folded = false;
+        if (v.overlap && (v.fuse & 64u) && !(v.fuse & 0x200u) && v.ch <= 3) {
+            // encoder.0's weight gradient ends the step: its tap gather needs the batch only, so it runs now, on the
+            // weight-gradient stream (idle during the forward pass; in order behind the previous step's last reader of fold0)
+            FAVAE_HIP(hipEventRecord(v.ev_x, (hipStream_t)st));
+            FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_x, 0));
+            RC(favae_conv_fold_taps(v.xt, v.fold0, v.fold0_bytes, B, 32, 32, 64, 64, v.ch, 2, 0, v.dtype, (void*)v.side));
+            v.x_folded = true;
+        }
         if (v.join_pending) {   // the previous step's weight gradients / updates, still running next to the two launches above
             FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_join_ext ? v.ev_join_ext : v.ev_join, 0));
             v.join_pending = false;

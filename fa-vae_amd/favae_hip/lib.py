@@ -111,3 +111,20 @@ def conv_wgrad_folded(rows, cols, dw, Nb, Hs, Ws, Hl, Wl, stride, splitk=0):
                                        stream_ptr()))
     torch.cuda.current_stream().synchronize()     # scratch is freed on return
     return dw
+
+
+def conv_fold_taps(src, Nb, Hs, Ws, Hl, Wl, stride, shifted=0):
+    """favae_conv_fold_taps: [Nb*Hs*Ws][32] matrix of the 9 taps x C (<= 3) channels of src."""
+    C = src.shape[-1]
+    dst = torch.empty(Nb * Hs * Ws, 32, dtype=src.dtype, device=src.device)
+    check(_lib.favae_conv_fold_taps(ptr(src), ptr(dst), ctypes.c_size_t(dst.numel() * dst.element_size()), _i(Nb), _i(Hs), _i(Ws),
+                                    _i(Hl), _i(Wl), _i(C), _i(stride), _i(shifted), _i(dtype_code(src)), stream_ptr()))
+    return dst
+
+
+def conv_wgrad_prefolded(rows, cols, dw, Rst, Cst, splitk=0):
+    """favae_conv_wgrad_prefolded: dw [Rst][Cst] += rows^T cols over the K rows of two plain matrices."""
+    assert rows.dtype == cols.dtype and dw.dtype == torch.float32 and rows.shape[0] == cols.shape[0]
+    check(_lib.favae_conv_wgrad_prefolded(ptr(rows), _i(rows.shape[1]), _i(Rst), ptr(cols), _i(cols.shape[1]), _i(Cst), ptr(dw),
+                                          ctypes.c_longlong(rows.shape[0]), _i(splitk), _i(dtype_code(rows)), stream_ptr()))
+    return dw

@@ -85,6 +85,19 @@ size_t favae_conv_wgrad_folded_scratch(int Nb, int Hl, int Wl, int dtype);
 int favae_conv_wgrad_folded(const void* rows, int Rc, const void* cols, int Cc, float* dw, int Nb, int Hs, int Ws, int Hl,
                             int Wl, int stride, int splitk, int dtype, void* scratch, size_t scratch_bytes, void* stream);
 
+/* The two halves of favae_conv_wgrad_folded on their own, so that the gather of an operand that does not depend on the
+ * backward pass (the input batch of encoder.0) can run long before its gradient GEMM:
+ *   fold_taps: dst [Nb*Hs*Ws][32] <- the 9 taps x C (<= 3) channels of src; shifted = 0: src on the large grid
+ *     [Nb,Hl,Wl,C] read at (s*h-1+kh, s*w-1+kw), column tap*C+c; shifted = 1 (stride 1, Hs = Hl): src read at
+ *     (h+1-kh, w+1-kw), column c*9+tap.  Columns past 9*C are zero.
+ *   wgrad_prefolded: dw [Rst][Cst] += sum_k rows[k][r] * cols[k][c] over K pixel rows of two plain matrices
+ *     ([K][Rc], [K][Cc]; Rst <= Rc, Cst <= Cc: the padding columns are not stored).  splitk: 0 auto, > 0 that many
+ *     slices of the reduction, -1 auto with dw known to be zero, < -1 that many slices with dw known to be zero. */
+int favae_conv_fold_taps(const void* src, void* dst, size_t dst_bytes, int Nb, int Hs, int Ws, int Hl, int Wl, int C,
+                         int stride, int shifted, int dtype, void* stream);
+int favae_conv_wgrad_prefolded(const void* rows, int Rc, int Rst, const void* cols, int Cc, int Cst, float* dw, long long K,
+                               int splitk, int dtype, void* stream);
+
 /* Live HIP-event timing of the GEMM launches (measurement only; no reference counterpart). Every stride-th launch of
  * each kernel class is timed on its launch stream; collect() synchronises and returns [16][3] = launches, seconds,
  * algorithmic flops per class (classes: see csrc/igemm.hip). */

@@ -336,6 +336,29 @@ def test_folded_weight_gradient_encoder0(dt, tol, Nb, H, Cs):
 
 
 @pytest.mark.parametrize("dt,tol", DT)
+@pytest.mark.parametrize("split", [0, -1, -7, 5])
+def test_fold_then_gemm_in_two_calls(dt, tol, split):
+    """favae_conv_fold_taps + favae_conv_wgrad_prefolded (what the training step does for encoder.0: the gather of the
+    batch runs at the start of the step, the GEMM at its end) against autograd; every split-K convention."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(57)
+    Nb, H, Cs, Cout = 5, 32, 3, 64
+    x = q(torch.rand(Nb, Cs, H, H, generator=g), dt)
+    w = torch.randn(Cout, Cs, 3, 3, generator=g, requires_grad=True)
+    dy = q(torch.randn(Nb, Cout, H // 2, H // 2, generator=g), dt)
+    F.conv2d(x, w, None, stride=2, padding=1).backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, 27)
+    xd = nhwc(x).to(dt).cuda()
+    folded = lib.conv_fold_taps(xd, Nb, H // 2, H // 2, H, H, 2)
+    # the folded matrix itself: column tap*Cs+c of pixel (n, h, w) is x[n, 2h-1+kh, 2w-1+kw, c] (zero outside, zero padding columns)
+    want = F.unfold(x, 3, padding=1, stride=2).reshape(Nb, Cs, 9, -1).permute(0, 3, 2, 1).reshape(-1, 27)
+    assert torch.equal(folded[:, :27].float().cpu(), want) and not folded[:, 27:].any()
+    dw = torch.zeros(Cout, 27, device="cuda")
+    lib.conv_wgrad_prefolded(nhwc(dy).to(dt).cuda().reshape(-1, Cout), folded, dw, Cout, 27, split)
+    assert_close(dw.cpu(), ref, tol)
+
+
+@pytest.mark.parametrize("dt,tol", DT)
 @pytest.mark.parametrize("Nb,H,Co", [(2, 64, 3), (3, 18, 2), (64, 64, 3)])
 def test_folded_weight_gradient_final_conv(dt, tol, Nb, H, Co):
     """final_layer.3 (Conv2d 64 -> Co, k3 s1 p1): the narrow operand is the output gradient, shifted per tap."""
