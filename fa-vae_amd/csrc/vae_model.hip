@@ -712,7 +712,7 @@ extern "C" int favae_vae_train_stages(favae_vae* h, const float* data_nhwc, cons
 /* Orders `waiting` behind everything queued so far on `st` (the stream the step is issued on) and on the internal
  * weight-gradient stream, without blocking either: the collective of a gradient bucket is enqueued on `waiting`. */
 extern "C" int favae_vae_fence(favae_vae* h, void* st, void* waiting) {
-    FAVAE_CHECK_ARG(h && waiting, "favae_vae_fence: null pointer");
+    FAVAE_CHECK_ARG(h, "favae_vae_fence: null handle");   // (a null `waiting` is the default stream)
     Vae& v = h->v;
     if (!v.ev_fence_ok) {
         FAVAE_HIP(hipEventCreateWithFlags(&v.ev_fence[0], hipEventDisableTiming));
