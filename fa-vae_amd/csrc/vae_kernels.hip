@@ -1078,10 +1078,11 @@ __global__ void sigmoid_only(const float* __restrict__ raw, float* __restrict__ 
 }
 
 // ---- Adam (torch.optim.Adam defaults, :131,250) over the flat parameter arena ---------------------------------
-template <bool CLEAR_G>
+template <bool CLEAR_G, bool COPY = false>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t n4, float b1, float b2, float eps,
-                                                   float step_size, float bc2_sqrt) {
+                                                   float step_size, float bc2_sqrt, bf16_t* __restrict__ copy = nullptr,
+                                                   size_t ncopy4 = 0) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         float4 P = ((float4*)p)[i], G = ((const float4*)g)[i], M = ((float4*)m)[i], V = ((float4*)v)[i];
         float* pp = (float*)&P; float* gg = (float*)&G; float* mm = (float*)&M; float* vv = (float*)&V;
@@ -1094,6 +1095,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         }
         ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V;
         if (CLEAR_G) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (COPY && i < ncopy4) {   // bf16 shadow of the leading (weight) part of the slice, same layout
+            ushort4 c;
+            c.x = f32_to_bf16(pp[0]); c.y = f32_to_bf16(pp[1]); c.z = f32_to_bf16(pp[2]); c.w = f32_to_bf16(pp[3]);
+            ((ushort4*)copy)[i] = c;
+        }
     }
 }
 
@@ -1612,6 +1618,22 @@ extern "C" int favae_adam_step_clear(float* p, float* g, float* m, float* v, lon
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
     hipLaunchKernelGGL(adam_kernel<true>, dim3(ew_grid((size_t)n / 4)), dim3(256), 0, ST, p, g, m, v, (size_t)n / 4, beta1, beta2, eps, step_size, bc2_sqrt);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_adam_step_copy(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                                    float eps, long long step, int clear_g, void* copy_bf16, long long ncopy, void* stream) {
+    FAVAE_CHECK_ARG(p && g && m && v && copy_bf16 && n > 0 && n % 4 == 0 && step >= 1, "favae_adam_step_copy: bad argument (n must be a multiple of 4)");
+    FAVAE_CHECK_ARG(ncopy > 0 && ncopy <= n && ncopy % 4 == 0 && ((uintptr_t)copy_bf16 % 8) == 0, "favae_adam_step_copy: ncopy (multiple of 4, <= n), copy 8-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    if (clear_g)
+        hipLaunchKernelGGL((adam_kernel<true, true>), dim3(ew_grid((size_t)n / 4)), dim3(256), 0, ST, p, g, m, v, (size_t)n / 4, beta1, beta2, eps,
+                           step_size, bc2_sqrt, (bf16_t*)copy_bf16, (size_t)ncopy / 4);
+    else
+        hipLaunchKernelGGL((adam_kernel<false, true>), dim3(ew_grid((size_t)n / 4)), dim3(256), 0, ST, p, g, m, v, (size_t)n / 4, beta1, beta2, eps,
+                           step_size, bc2_sqrt, (bf16_t*)copy_bf16, (size_t)ncopy / 4);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

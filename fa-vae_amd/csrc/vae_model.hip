@@ -101,7 +101,7 @@ struct Vae {
     bool dp_epoch;   // steps of favae_vae_train_epoch_dp: gradients cleared by the bucket-wise Adam, joins through the communication stream
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
     hipEvent_t ev_join_ext;   // when set: the event join_pending refers to (the communicator's), else ev_join
-    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients (0x200: do not hoist encoder.0's gather to the start of the step), 128 Adam + weight re-layout in one pass, 256 final conv + loss in one launch
+    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients (0x200: do not hoist encoder.0's gather to the start of the step; 0x800: encoder.0's update and its bf16 shadow as two launches), 128 Adam + weight re-layout in one pass, 256 final conv + loss in one launch
     float* xf_alt; char* xt_alt;
     char* wk_out;   // weights of final_layer.3 in the MFMA operand order for favae_conv_out_ll (rebuilt whenever the layer changes)
     char* fold0; size_t fold0_bytes; hipEvent_t ev_x; bool x_folded;   // encoder.0's folded input batch, gathered on the side stream while the forward pass runs
@@ -391,6 +391,10 @@ int adam_layer(Vae& v, int l, void* st) {
     if ((v.fuse & 128u) && L.Cin % 4 == 0 && L.Cout % 4 == 0 && (c || t))   // one pass: update + dtype copy + transpose (never L_OUT: Cout <= 4)
         return favae_adam_wprep(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, L.Cout, L.taps, L.Cin, c, t, v.ada.epoch ? 1 : 0,
                                 v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, v.dtype, st);
+    if (c && !t && v.dtype == FAVAE_BF16 && !(v.fuse & 0x800u) && ((long long)L.Cout * L.taps * L.Cin) % 4 == 0)
+        // encoder.0 (no input gradient, so no transposed shadow): its update ends the step, the bf16 copy rides along
+        return favae_adam_step_copy(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step,
+                                    v.ada.epoch ? 1 : 0, c, (long long)L.Cout * L.taps * L.Cin, st);
     if (v.ada.epoch) RC(favae_adam_step_clear(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, st));
     else RC(favae_adam_step(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, st));
     if (c || t) RC(favae_weight_prep(v.P + L.w_off, c, t, L.Cout, L.taps, L.Cin, v.dtype, st));

@@ -194,6 +194,12 @@ int favae_adam_step(float* p, const float* g, float* m, float* v, long long n, f
  * of the iteration that follows, so that an epoch of steps needs no memset of the gradients. */
 int favae_adam_step_clear(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                           float eps, long long step, void* stream);
+
+/* favae_adam_step (clear_g: + the zeroing of favae_adam_step_clear) that also writes the bf16 copy of the first `ncopy`
+ * updated parameters (a layer's weights, same [Cout][tap][Cin] layout) in the same pass: the optimiser step and the
+ * dtype shadow of encoder.0, whose update is the last link of a training step (optim.step(), :250). */
+int favae_adam_step_copy(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                         long long step, int clear_g, void* copy_bf16, long long ncopy, void* stream);
 /* Adam step over the arena slice of ONE layer (n floats starting with its weight tensor [Co][taps][Ci], then bias / BN
  * affine) fused with the re-layout of the fresh weights (favae_weight_prep): the weights are read and written once.
  * clear_grad != 0 also zeroes the consumed gradients (see favae_adam_step_clear).  Ci, Co, n multiples of 4. */

@@ -211,3 +211,29 @@ def test_adam_fused_with_weight_prep(dt, Co, taps, Ci, extra):
     for a, b in ((pa, pb), (ma, mb), (va, vb), (ga, gb), (wca, wcb), (wta, wtb)):
         assert torch.equal(a, b)
     assert float(gb.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("clear", [0, 1])
+def test_adam_with_bf16_copy_of_the_weights(clear):
+    """favae_adam_step_copy (encoder.0: 64 x 9 x 3 weights + bias + BN affine) == favae_adam_step(_clear) followed by
+    favae_weight_prep of the weight part, bit for bit."""
+    L = _L()
+    raw_ = L.raw()
+    dev = "cuda"
+    Co, taps, Ci = 64, 9, 3
+    nw, n = Co * taps * Ci, Co * taps * Ci + 3 * 64
+    g = torch.Generator().manual_seed(5)
+    p0, g0 = torch.randn(n, generator=g).to(dev), (torch.randn(n, generator=g) * 0.1).to(dev)
+    m0, v0 = (torch.randn(n, generator=g) * 0.01).to(dev), (torch.rand(n, generator=g) * 1e-3).to(dev)
+    pa, ga, ma, va = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    step = raw_.favae_adam_step_clear if clear else raw_.favae_adam_step
+    L.check(step(L.ptr(pa), L.ptr(ga), L.ptr(ma), L.ptr(va), ll_(n), f_(1e-3), f_(0.9), f_(0.999), f_(1e-8), ll_(3), L.stream_ptr()))
+    wca = torch.zeros(nw, dtype=torch.bfloat16, device=dev)
+    L.check(raw_.favae_weight_prep(L.ptr(pa), L.ptr(wca), None, i_(Co), i_(taps), i_(Ci), i_(1), L.stream_ptr()))
+    pb, gb, mb, vb = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    wcb = torch.zeros(nw, dtype=torch.bfloat16, device=dev)
+    L.check(raw_.favae_adam_step_copy(L.ptr(pb), L.ptr(gb), L.ptr(mb), L.ptr(vb), ll_(n), f_(1e-3), f_(0.9), f_(0.999), f_(1e-8), ll_(3),
+                                      i_(clear), L.ptr(wcb), ll_(nw), L.stream_ptr()))
+    for a, b in ((pa, pb), (ma, mb), (va, vb), (ga, gb), (wca, wcb)):
+        assert torch.equal(a, b)
+    assert (float(gb.abs().max()) == 0.0) == bool(clear)
