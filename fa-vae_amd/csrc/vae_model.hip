@@ -91,7 +91,7 @@ struct Vae {
     bool stats_fused[NL], grad_fused[NL];
     // weight gradients run on a second stream next to the dgrad -> BN-backward chain of the main stream
     // and the layer-wise optimiser steps of an epoch on a third (side2), behind the weight gradient of their layer
-    hipStream_t side, side2, side3; hipEvent_t ev_comm; hipEvent_t ev_fork[NL]; hipEvent_t ev_dg[NL]; hipEvent_t ev_wg[NL]; hipEvent_t ev_join; bool overlap;
+    hipStream_t side, side2, side3; hipEvent_t ev_comm; hipEvent_t ev_fork[NL]; hipEvent_t ev_dg[NL]; hipEvent_t ev_wg[NL]; hipEvent_t ev_join; hipEvent_t ev_join2; bool overlap;   // ev_join2: end of the weight-gradient stream when encoder.0's update ran there
     // single-device epochs: Adam + weight re-layout of a layer follow its weight gradient on the side stream
     // epoch: steps of one epoch run back to back: Adam clears the gradients it has consumed (no memset per step) and the
     // main stream joins the side stream only when the next step's forward pass is about to read the weights
@@ -100,6 +100,7 @@ struct Vae {
     bool join_pending; bool dg_all;
     bool dp_epoch;   // steps of favae_vae_train_epoch_dp: gradients cleared by the bucket-wise Adam, joins through the communication stream
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
+    bool join2;   // ev_join2 was recorded in the last step
     hipEvent_t ev_join_ext;   // when set: the event join_pending refers to (the communicator's), else ev_join
     unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients (0x200: do not hoist encoder.0's gather to the start of the step; 0x800: encoder.0's update and its bf16 shadow as two launches), 128 Adam + weight re-layout in one pass, 256 final conv + loss in one launch
     float* xf_alt; char* xt_alt;
@@ -521,6 +522,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.join_pending = false;
     v.dp_epoch = false;
     v.ev_join_ext = nullptr;
+    v.join2 = false;
     v.ev_fence_ok = false;
     v.x_folded = false;
     {
@@ -537,6 +539,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
         for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_fork[l], hipEventDisableTiming) == hipSuccess;
         for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_dg[l], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&v.ev_join, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&v.ev_join2, hipEventDisableTiming) == hipSuccess;
         if (!ok) {
             delete h;
             favae_set_error("favae_vae_create: could not create the side stream / events");
@@ -556,6 +559,7 @@ extern "C" int favae_vae_destroy(favae_vae* h) {
         (void)hipEventDestroy(h->v.ev_x);
         for (int l = 0; l < NL; ++l) { (void)hipEventDestroy(h->v.ev_fork[l]); (void)hipEventDestroy(h->v.ev_dg[l]); (void)hipEventDestroy(h->v.ev_wg[l]); }
         (void)hipEventDestroy(h->v.ev_join);
+        (void)hipEventDestroy(h->v.ev_join2);
     }
     delete h;
     return FAVAE_OK;
@@ -585,6 +589,17 @@ namespace {
 // side streams (with stage_hi == N_STAGES).
 constexpr int N_STAGES = 13;
 
+// the caller's stream waits for the end of the previous step on the other streams
+int wait_join(Vae& v, hipStream_t st) {
+    if (v.ev_join_ext) {
+        FAVAE_HIP(hipStreamWaitEvent(st, v.ev_join_ext, 0));
+    } else {
+        FAVAE_HIP(hipStreamWaitEvent(st, v.ev_join, 0));
+        if (v.join2) FAVAE_HIP(hipStreamWaitEvent(st, v.ev_join2, 0));
+    }
+    return FAVAE_OK;
+}
+
 int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const float* eps, const double* prior, float tau,
                  float beta, float var_x, double* metrics2_out, int stage_lo, int stage_hi, void* st) {
     const bool epoch = (v.overlap && v.ada.on && v.ada.epoch) || v.dp_epoch;
@@ -604,7 +619,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             v.x_folded = true;
         }
         if (v.join_pending) {   // the previous step's weight gradients / updates, still running next to the two launches above
-            FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_join_ext ? v.ev_join_ext : v.ev_join, 0));
+            RC(wait_join(v, (hipStream_t)st));
             v.join_pending = false;
         }
         RC(encoder_fwd(v, B, true, st, true));
@@ -672,16 +687,21 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
                 FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[v.ada.pending], 0));
                 RC(adam_layer(v, v.ada.pending, (void*)v.side2));
             }
-            FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[0], 0));
-            RC(adam_layer(v, 0, (void*)v.side2));
+            // encoder.0's update follows its weight gradient on the same stream: it is the last link of the step, and an
+            // event hop to the optimiser stream is a few microseconds of step time
+            v.join2 = !(v.fuse & 0x1000u);
+            if (!v.join2) FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[0], 0));
+            RC(adam_layer(v, 0, (void*)(v.join2 ? v.side : v.side2)));
             v.ada.pending = -1;
-            // every weight gradient of the side stream is awaited by the update of its layer, so side2 ends the step
+            // every other weight gradient of the side stream is awaited by the update of its layer on side2
             FAVAE_HIP(hipEventRecord(v.ev_join, v.side2));
+            if (v.join2) FAVAE_HIP(hipEventRecord(v.ev_join2, v.side));
         } else {
+            v.join2 = false;
             FAVAE_HIP(hipEventRecord(v.ev_join, v.side));
         }
         if (epoch) v.join_pending = true;   // favae_vae_train_epoch joins before the next forward pass / at its end
-        else FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_join, 0));
+        else RC(wait_join(v, (hipStream_t)st));
     }
     return FAVAE_OK;
 }
@@ -757,7 +777,7 @@ extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const
             v.ada.on = false;
             v.ada.epoch = false;
             if (rc != FAVAE_OK || o + batch >= n) {   // last step (or failure): the caller's stream waits for the side stream
-                if (v.join_pending) (void)hipStreamWaitEvent((hipStream_t)st, v.ev_join, 0);
+                if (v.join_pending) (void)wait_join(v, (hipStream_t)st);
                 v.join_pending = false;
             }
             RC(rc);
@@ -821,7 +841,7 @@ extern "C" int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float
     }
     v.dp_epoch = false;
     if (v.join_pending) {
-        (void)hipStreamWaitEvent((hipStream_t)st, v.ev_join_ext ? v.ev_join_ext : v.ev_join, 0);
+        (void)wait_join(v, (hipStream_t)st);
         v.join_pending = false;
     }
     v.ev_join_ext = nullptr;
