@@ -102,9 +102,10 @@ struct Vae {
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
     bool join2;   // ev_join2 was recorded in the last step
     hipEvent_t ev_join_ext;   // when set: the event join_pending refers to (the communicator's), else ev_join
-    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients (0x200: do not hoist encoder.0's gather to the start of the step; 0x800: encoder.0's update and its bf16 shadow as two launches), 128 Adam + weight re-layout in one pass, 256 final conv + loss in one launch
+    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients (0x200: do not hoist encoder.0's gather to the start of the step; 0x800: encoder.0's update and its bf16 shadow as two launches; 0x1000: encoder.0's update on the optimiser stream; 0x2000: encoder.0's weight gradient + update on the weight-gradient stream instead of the caller's, memset / batch gather of the next step on the caller's), 128 Adam + weight re-layout in one pass, 256 final conv + loss in one launch
     float* xf_alt; char* xt_alt;
     char* wk_out;   // weights of final_layer.3 in the MFMA operand order for favae_conv_out_ll (rebuilt whenever the layer changes)
+    char* fold0_buf[2]; int fold_sel; hipEvent_t ev_batch, ev_fold; bool inline_tail;   // see train_stages
     char* fold0; size_t fold0_bytes; hipEvent_t ev_x; bool x_folded;   // encoder.0's folded input batch, gathered on the side stream while the forward pass runs
     char* fold; size_t fold_bytes;   // [pixels][32] tap-folded operand of the two image-side weight gradients (side stream only)   // second batch buffer: the next gather must not overwrite what wgrad(encoder.0) still reads
     const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(SH + L[l].wc_off * esz); }
@@ -183,7 +184,9 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
     v.fold_bytes = favae_conv_wgrad_folded_scratch(B, 64, 64, v.dtype);
     v.fold = (char*)c.take(v.fold_bytes);
     v.fold0_bytes = (size_t)B * 32 * 32 * 32 * v.esz;
-    v.fold0 = (char*)c.take(v.fold0_bytes);
+    v.fold0_buf[0] = (char*)c.take(v.fold0_bytes);
+    v.fold0_buf[1] = (char*)c.take(v.fold0_bytes);
+    v.fold0 = v.fold0_buf[0];
     v.zlat = (char*)c.take((size_t)B * v.z * v.esz);
     v.stdq = (float*)c.take((size_t)B * v.z * 4);
     v.s1s2 = (float*)c.take(2 * 1024 * 4);
@@ -525,6 +528,8 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.join2 = false;
     v.ev_fence_ok = false;
     v.x_folded = false;
+    v.inline_tail = false;
+    v.fold_sel = 0;
     {
         const char* d = getenv("FAVAE_DG_EVENTS");
         v.dg_all = d && d[0] == '1';
@@ -535,6 +540,8 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
         // the side streams themselves are created at the first training step (ensure_streams), next to the caller's stream
         bool ok = hipEventCreateWithFlags(&v.ev_comm, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&v.ev_x, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&v.ev_batch, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&v.ev_fold, hipEventDisableTiming) == hipSuccess;
         for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_wg[l], hipEventDisableTiming) == hipSuccess;
         for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_fork[l], hipEventDisableTiming) == hipSuccess;
         for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_dg[l], hipEventDisableTiming) == hipSuccess;
@@ -557,6 +564,8 @@ extern "C" int favae_vae_destroy(favae_vae* h) {
             if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
         (void)hipEventDestroy(h->v.ev_comm);
         (void)hipEventDestroy(h->v.ev_x);
+        (void)hipEventDestroy(h->v.ev_batch);
+        (void)hipEventDestroy(h->v.ev_fold);
         for (int l = 0; l < NL; ++l) { (void)hipEventDestroy(h->v.ev_fork[l]); (void)hipEventDestroy(h->v.ev_dg[l]); (void)hipEventDestroy(h->v.ev_wg[l]); }
         (void)hipEventDestroy(h->v.ev_join);
         (void)hipEventDestroy(h->v.ev_join2);
@@ -605,20 +614,45 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
     const bool epoch = (v.overlap && v.ada.on && v.ada.epoch) || v.dp_epoch;
     if (v.overlap) RC(ensure_streams(v, (hipStream_t)st));
     if (stage_lo == 0) {
-        if (!epoch) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));
-        FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, (hipStream_t)st));
-        if (epoch) { std::swap(v.xf, v.xf_alt); std::swap(v.xt, v.xt_alt); }
-        RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, v.xf, v.xt, v.dtype, st));
+        const bool can_fold = v.overlap && (v.fuse & 64u) && !(v.fuse & 0x200u) && v.ch <= 3;
+        // Single-device epochs: encoder.0's weight gradient and update, the last links of a step, stay on the caller's
+        // stream (no event hop on that chain); what used to hide under them -- the zero-pool memset, the batch gather and
+        // the tap gather of the NEXT step -- moves to the weight-gradient stream, which is idle at that point.
+        v.inline_tail = epoch && !v.dp_epoch && can_fold && !(v.fuse & 0x2000u);
         v.x_folded = false;
-        if (v.overlap && (v.fuse & 64u) && !(v.fuse & 0x200u) && v.ch <= 3) {
-            // encoder.0's weight gradient ends the step: its tap gather needs the batch only, so it runs now, on the
-            // weight-gradient stream (idle during the forward pass; in order behind the previous step's last reader of fold0)
-            FAVAE_HIP(hipEventRecord(v.ev_x, (hipStream_t)st));
-            FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_x, 0));
+        if (v.inline_tail) {
+            std::swap(v.xf, v.xf_alt); std::swap(v.xt, v.xt_alt);
+            v.fold_sel ^= 1;
+            v.fold0 = v.fold0_buf[v.fold_sel];   // the previous step's gradient GEMM may still read the other one
+            if (v.join_pending) {
+                // behind the previous step's last reader of the zero pool (BN backward of encoder.0), not behind its tail
+                FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_fork[0], 0));
+            } else {
+                FAVAE_HIP(hipEventRecord(v.ev_x, (hipStream_t)st));
+                FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_x, 0));
+            }
+            FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, v.side));
+            RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, v.xf, v.xt, v.dtype, (void*)v.side));
+            FAVAE_HIP(hipEventRecord(v.ev_batch, v.side));
             RC(favae_conv_fold_taps(v.xt, v.fold0, v.fold0_bytes, B, 32, 32, 64, 64, v.ch, 2, 0, v.dtype, (void*)v.side));
+            FAVAE_HIP(hipEventRecord(v.ev_fold, v.side));
             v.x_folded = true;
+            FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_batch, 0));
+        } else {
+            if (!epoch) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));
+            FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, (hipStream_t)st));
+            if (epoch) { std::swap(v.xf, v.xf_alt); std::swap(v.xt, v.xt_alt); }
+            RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, v.xf, v.xt, v.dtype, st));
+            if (can_fold) {
+                // encoder.0's weight gradient ends the step: its tap gather needs the batch only, so it runs now, on the
+                // weight-gradient stream (idle during the forward pass; in order behind the previous step's last reader of fold0)
+                FAVAE_HIP(hipEventRecord(v.ev_x, (hipStream_t)st));
+                FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_x, 0));
+                RC(favae_conv_fold_taps(v.xt, v.fold0, v.fold0_bytes, B, 32, 32, 64, 64, v.ch, 2, 0, v.dtype, (void*)v.side));
+                v.x_folded = true;
+            }
         }
-        if (v.join_pending) {   // the previous step's weight gradients / updates, still running next to the two launches above
+        if (v.join_pending) {   // the previous step's weight gradients / updates, still running next to the launches above
             RC(wait_join(v, (hipStream_t)st));
             v.join_pending = false;
         }
@@ -678,7 +712,13 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             RC(after_dgrad(v, l, st));
         } else {
             RC(bn_bwd(v, 0, B, st));
-            RC(wgrad(v, 0, v.xt, B, st));
+            if (v.inline_tail) {
+                FAVAE_HIP(hipEventRecord(v.ev_fork[0], (hipStream_t)st));   // the next step's memset / gather may start here
+                FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_fold, 0));
+                RC(wgrad_launch(v, 0, v.xt, B, st));
+            } else {
+                RC(wgrad(v, 0, v.xt, B, st));
+            }
         }
     }
     if (stage_hi == N_STAGES && v.overlap && !v.dp_epoch) {   // (data-parallel epochs join through favae_vae_fence)
@@ -689,9 +729,13 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             }
             // encoder.0's update follows its weight gradient on the same stream: it is the last link of the step, and an
             // event hop to the optimiser stream is a few microseconds of step time
-            v.join2 = !(v.fuse & 0x1000u);
-            if (!v.join2) FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[0], 0));
-            RC(adam_layer(v, 0, (void*)(v.join2 ? v.side : v.side2)));
+            v.join2 = !v.inline_tail && !(v.fuse & 0x1000u);
+            if (v.inline_tail) {
+                RC(adam_layer(v, 0, st));
+            } else {
+                if (!v.join2) FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[0], 0));
+                RC(adam_layer(v, 0, (void*)(v.join2 ? v.side : v.side2)));
+            }
             v.ada.pending = -1;
             // every other weight gradient of the side stream is awaited by the update of its layer on side2
             FAVAE_HIP(hipEventRecord(v.ev_join, v.side2));
