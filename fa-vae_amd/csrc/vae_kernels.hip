@@ -619,17 +619,19 @@ struct ColsumCastF {
 };
 
 // ---- reparameterise + KL(q || N(mu_P, 1/tau)) : celeba_deepvanilla_vae.py:86-92,137-150,231-232 --------------
-// one block; B*z is at most a few tens of thousands of elements
+// one block of 1024 threads (B*z is 1280 elements at batch 64: the launch is a chain of dependent loads, idx -> prior row,
+// and a double-precision log; more lanes shorten that chain); B*z is at most a few tens of thousands of elements
+constexpr int RKF_THREADS = 1024;
 template <class T>
-__global__ __launch_bounds__(256) void reparam_kl_fwd(const float* __restrict__ fc, const float* __restrict__ eps,
+__global__ __launch_bounds__(RKF_THREADS) void reparam_kl_fwd(const float* __restrict__ fc, const float* __restrict__ eps,
                                                       const double* __restrict__ prior, const int* __restrict__ idx,
                                                       float tau, int B, int z, T* __restrict__ zlat,
                                                       float* __restrict__ stdq, double* __restrict__ kl_out) {
-    __shared__ double sm[4];
+    __shared__ double sm[RKF_THREADS / 64];
     const double std_p = sqrt((double)(1.0f / tau));
     const double sp = fmin(fmax(std_p, 1e-6), 1e20);
     double acc = 0.0;
-    for (int i = threadIdx.x; i < B * z; i += 256) {
+    for (int i = threadIdx.x; i < B * z; i += RKF_THREADS) {
         const int b = i / z, k = i - b * z;
         const float mu = fc[b * 2 * z + k];
         const float lv = fc[b * 2 * z + z + k] + 1e-6f;
@@ -645,7 +647,12 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd(const float* __restrict__ 
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) *kl_out = (sm[0] + sm[1] + sm[2] + sm[3]) / B;
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < RKF_THREADS / 64; ++w) t += sm[w];
+        *kl_out = t / B;
+    }
 }
 
 template <class T>
@@ -1462,9 +1469,9 @@ extern "C" int favae_reparam_kl_fwd(const float* fc, const float* eps, const dou
                                     int z, void* zlat, float* stdq, double* kl_out, int dtype, void* stream) {
     FAVAE_CHECK_ARG(fc && eps && zlat && stdq && kl_out && B > 0 && z > 0 && tau > 0, "favae_reparam_kl_fwd: bad argument");
     if (dtype == FAVAE_F32)
-        hipLaunchKernelGGL(reparam_kl_fwd<float>, dim3(1), dim3(256), 0, ST, fc, eps, prior, idx, tau, B, z, (float*)zlat, stdq, kl_out);
+        hipLaunchKernelGGL(reparam_kl_fwd<float>, dim3(1), dim3(RKF_THREADS), 0, ST, fc, eps, prior, idx, tau, B, z, (float*)zlat, stdq, kl_out);
     else
-        hipLaunchKernelGGL(reparam_kl_fwd<bf16_t>, dim3(1), dim3(256), 0, ST, fc, eps, prior, idx, tau, B, z, (bf16_t*)zlat, stdq, kl_out);
+        hipLaunchKernelGGL(reparam_kl_fwd<bf16_t>, dim3(1), dim3(RKF_THREADS), 0, ST, fc, eps, prior, idx, tau, B, z, (bf16_t*)zlat, stdq, kl_out);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }
