@@ -655,6 +655,68 @@ __global__ __launch_bounds__(RKF_THREADS) void reparam_kl_fwd(const float* __res
     }
 }
 
+// The same + decoder_input (:41-45, nn.Linear z -> N): every block recomputes z = eps * std + mu (B*z elements, rounded to
+// the GEMM dtype as the stand-alone path stores it) into LDS and produces 64 of the N output columns for all B rows with
+// K = z FMAs per output; block 0 also writes zlat / stdq and the KL term.  One launch instead of two on the main chain of
+// the training step, both of which are chains of dependent loads rather than work (K = 20).
+constexpr int RKD_ZMAX = 32;
+template <class T>
+__global__ __launch_bounds__(RKF_THREADS) void reparam_kl_decin(const float* __restrict__ fc, const float* __restrict__ eps,
+                                                                 const double* __restrict__ prior, const int* __restrict__ idx,
+                                                                 float tau, int B, int z, T* __restrict__ zlat,
+                                                                 float* __restrict__ stdq, double* __restrict__ kl_out,
+                                                                 const T* __restrict__ w, const float* __restrict__ bias,
+                                                                 T* __restrict__ out, int N) {
+    extern __shared__ float zs[];   // [B][z]
+    __shared__ double sm[RKF_THREADS / 64];
+    const bool first = blockIdx.x == 0;
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), bg = threadIdx.x >> 6;
+    // the weight row and the bias of this thread's column travel while z is computed
+    float wr[RKD_ZMAX];
+#pragma unroll
+    for (int k = 0; k < RKD_ZMAX; ++k) wr[k] = (k < z && n < N) ? to_f32<T>(w[(size_t)n * z + k]) : 0.f;
+    const float bn = n < N ? bias[n] : 0.f;
+    const double std_p = sqrt((double)(1.0f / tau));
+    const double sp = fmin(fmax(std_p, 1e-6), 1e20);
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < B * z; i += RKF_THREADS) {
+        const int b = i / z, k = i - b * z;
+        const float mu = fc[b * 2 * z + k];
+        const float lv = fc[b * 2 * z + z + k] + 1e-6f;
+        const float sd = expf(0.5f * lv);
+        const T zt = from_f32<T>(eps[i] * sd + mu);
+        zs[i] = to_f32<T>(zt);
+        if (first) {
+            stdq[i] = sd;
+            zlat[i] = zt;
+            const double mp = prior ? prior[(size_t)(idx ? idx[b] : b) * z + k] : 0.0;
+            const double sq = fmin(fmax((double)sd, 1e-6), 1e20);
+            const double vr = (sq / sp) * (sq / sp);
+            const double t1 = ((double)mu - mp) / sp;
+            acc += 0.5 * (vr + t1 * t1 - 1.0 - log(vr));
+        }
+    }
+    if (first) {
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    }
+    __syncthreads();
+    if (first && threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < RKF_THREADS / 64; ++q) t += sm[q];
+        *kl_out = t / B;
+    }
+    if (n >= N) return;
+    for (int b = bg; b < B; b += RKF_THREADS / 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < RKD_ZMAX; ++k)
+            if (k < z) a = fmaf(zs[b * z + k], wr[k], a);
+        out[(size_t)b * N + n] = from_f32<T>(a + bn);
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void reparam_kl_bwd(const float* __restrict__ fc, const float* __restrict__ eps,
                                                       const double* __restrict__ prior, const int* __restrict__ idx,
@@ -1472,6 +1534,24 @@ extern "C" int favae_reparam_kl_fwd(const float* fc, const float* eps, const dou
         hipLaunchKernelGGL(reparam_kl_fwd<float>, dim3(1), dim3(RKF_THREADS), 0, ST, fc, eps, prior, idx, tau, B, z, (float*)zlat, stdq, kl_out);
     else
         hipLaunchKernelGGL(reparam_kl_fwd<bf16_t>, dim3(1), dim3(RKF_THREADS), 0, ST, fc, eps, prior, idx, tau, B, z, (bf16_t*)zlat, stdq, kl_out);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_reparam_kl_decoder_input(const float* fc, const float* eps, const double* prior, const int* idx, float tau,
+                                              int B, int z, void* zlat, float* stdq, double* kl_out, const void* w,
+                                              const float* bias, void* out, int N, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(fc && eps && zlat && stdq && kl_out && w && bias && out && B > 0 && z > 0 && N > 0 && tau > 0,
+                    "favae_reparam_kl_decoder_input: bad argument");
+    FAVAE_CHECK_ARG(z <= RKD_ZMAX && (size_t)B * z * sizeof(float) <= 48 * 1024, "favae_reparam_kl_decoder_input: z <= %d, B*z <= 12288", RKD_ZMAX);
+    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_reparam_kl_decoder_input: dtype");
+    const size_t lds = (size_t)B * z * sizeof(float);
+    if (dtype == FAVAE_F32)
+        hipLaunchKernelGGL(reparam_kl_decin<float>, dim3((N + 63) / 64), dim3(RKF_THREADS), lds, ST, fc, eps, prior, idx, tau, B, z, (float*)zlat,
+                           stdq, kl_out, (const float*)w, bias, (float*)out, N);
+    else
+        hipLaunchKernelGGL(reparam_kl_decin<bf16_t>, dim3((N + 63) / 64), dim3(RKF_THREADS), lds, ST, fc, eps, prior, idx, tau, B, z, (bf16_t*)zlat,
+                           stdq, kl_out, (const bf16_t*)w, bias, (bf16_t*)out, N);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

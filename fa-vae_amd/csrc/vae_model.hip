@@ -102,7 +102,7 @@ struct Vae {
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
     bool join2;   // ev_join2 was recorded in the last step
     hipEvent_t ev_join_ext;   // when set: the event join_pending refers to (the communicator's), else ev_join
-    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients (0x200: do not hoist encoder.0's gather to the start of the step; 0x800: encoder.0's update and its bf16 shadow as two launches; 0x1000: encoder.0's update on the optimiser stream; 0x2000: encoder.0's weight gradient + update on the weight-gradient stream instead of the caller's, memset / batch gather of the next step on the caller's), 128 Adam + weight re-layout in one pass, 256 final conv + loss in one launch
+    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients (0x200: do not hoist encoder.0's gather to the start of the step; 0x800: encoder.0's update and its bf16 shadow as two launches; 0x1000: encoder.0's update on the optimiser stream; 0x2000: encoder.0's weight gradient + update on the weight-gradient stream instead of the caller's, memset / batch gather of the next step on the caller's; 0x4000: reparameterise + KL and decoder_input as two launches), 128 Adam + weight re-layout in one pass, 256 final conv + loss in one launch
     float* xf_alt; char* xt_alt;
     char* wk_out;   // weights of final_layer.3 in the MFMA operand order for favae_conv_out_ll (rebuilt whenever the layer changes)
     char* fold0_buf[2]; int fold_sel; hipEvent_t ev_batch, ev_fold; bool inline_tail;   // see train_stages
@@ -320,8 +320,8 @@ int encoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false) {
     return conv_fwd(v, L_FC, in, B, st, pooled);
 }
 
-int decoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false, bool skip_out = false) {
-    {   // decoder_input (:41-45) has no BN / activation: the GEMM stores its result in the dtype the next layer reads
+int decoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false, bool skip_out = false, bool skip_in = false) {
+    if (!skip_in) {   // decoder_input (:41-45) has no BN / activation: the GEMM stores its result in the dtype the next layer reads
         const Layer& L = v.L[L_DI];
         RC(favae_conv_igemm(v.zlat, v.Wf(L_DI), v.P + L.b_off, (float*)v.act[L_DI], B, 1, 1, L.Cin, 1, 1, L.Cout, 1, 1, 0, 0, 0,
                             v.dtype | (v.dtype == FAVAE_BF16 ? FAVAE_OUT_BF16 : 0), st));
@@ -657,9 +657,14 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             v.join_pending = false;
         }
         RC(encoder_fwd(v, B, true, st, true));
-        RC(favae_reparam_kl_fwd(v.raw[L_FC], eps, prior, idx, tau, B, v.z, v.zlat, v.stdq, metrics2_out + 1, v.dtype, st));
+        const bool decin = !(v.fuse & 0x4000u) && v.z <= 32 && (long long)B * v.z <= 12288;   // reparameterise + KL + decoder_input in one launch
+        if (decin)
+            RC(favae_reparam_kl_decoder_input(v.raw[L_FC], eps, prior, idx, tau, B, v.z, v.zlat, v.stdq, metrics2_out + 1, v.Wf(L_DI),
+                                              v.P + v.L[L_DI].b_off, v.act[L_DI], v.L[L_DI].Cout, v.dtype, st));
+        else
+            RC(favae_reparam_kl_fwd(v.raw[L_FC], eps, prior, idx, tau, B, v.z, v.zlat, v.stdq, metrics2_out + 1, v.dtype, st));
         const bool out_ll = (v.fuse & 0x100u) != 0;
-        RC(decoder_fwd(v, B, true, st, true, out_ll));
+        RC(decoder_fwd(v, B, true, st, true, out_ll, decin));
         const long long D = (long long)64 * 64 * v.ch;
         if (out_ll) {   // final conv + sigmoid + log-likelihood + gradient + bias gradient in one launch
             RC(favae_conv_out_ll(v.act[11], v.wk_out, v.P + v.L[L_OUT].b_off, v.xf, B, 64, 64, v.ch, var_x, v.raw[L_OUT], v.draw[L_OUT],

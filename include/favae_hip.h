@@ -155,6 +155,12 @@ int favae_colsum_cast(const float* x, void* y, long long R, int C, float* out, d
  * Outputs zlat [B][z] (dtype), stdq [B][z], *kl_out = mean_b sum_z KL (fp64). */
 int favae_reparam_kl_fwd(const float* fc, const float* eps, const double* prior, const int* idx, float tau, int B, int z,
                          void* zlat, float* stdq, double* kl_out, int dtype, void* stream);
+/* favae_reparam_kl_fwd followed by decoder_input (nn.Linear z -> N, :41-45, the first layer of decode(), :100-104) in one
+ * launch: out [B][N] (dtype) = zlat (as stored, i.e. rounded to dtype) @ w^T + bias, w [N][z] dtype, bias [N] fp32.
+ * z <= 32, B*z <= 12288.  Same results as the two calls up to the summation order of the z products. */
+int favae_reparam_kl_decoder_input(const float* fc, const float* eps, const double* prior, const int* idx, float tau, int B,
+                                   int z, void* zlat, float* stdq, double* kl_out, const void* w, const float* bias, void* out,
+                                   int N, int dtype, void* stream);
 /* Gradient of (rec + beta*KL) w.r.t. fc given dz = d rec / d zlat; dfc [B][2z] (dtype). */
 int favae_reparam_kl_bwd(const float* fc, const float* eps, const double* prior, const int* idx, const float* stdq,
                          const float* dz, float tau, float beta, int B, int z, void* dfc, int dtype, void* stream);

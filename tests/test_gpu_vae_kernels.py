@@ -109,6 +109,36 @@ def test_reparam_kl_forward_backward(with_prior):
     assert _err(dbias, fc.grad.sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,z,N,with_prior", [(64, 20, 4096, True), (37, 32, 200, False), (512, 20, 4096, True)])
+def test_reparam_kl_with_decoder_input_in_one_launch(dt, B, z, N, with_prior):
+    """favae_reparam_kl_decoder_input: zlat / stdq / KL identical to favae_reparam_kl_fwd, and
+    out = decoder_input(zlat) (nn.Linear z -> N, celeba_deepvanilla_vae.py:41-45) on the stored (dtype-rounded) latent."""
+    L = _L()
+    raw_ = L.raw()
+    dev = "cuda"
+    g = torch.Generator().manual_seed(B + z)
+    fc = (torch.randn(B, 2 * z, generator=g) * 0.7).to(dev)
+    eps = torch.randn(B, z, generator=g).to(dev)
+    prior = torch.randn(700, z, generator=g, dtype=torch.float64).to(dev) if with_prior else None
+    idx = torch.randint(0, 700, (B,), generator=g, dtype=torch.int32).to(dev) if with_prior else None
+    w = (torch.randn(N, z, generator=g) * 0.2).to(dt).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    code = 0 if dt == torch.float32 else 1
+    z0, s0, k0 = torch.zeros(B, z, dtype=dt, device=dev), torch.zeros(B, z, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
+    L.check(raw_.favae_reparam_kl_fwd(L.ptr(fc), L.ptr(eps), L.ptr(prior), L.ptr(idx), f_(1.3), i_(B), i_(z), L.ptr(z0), L.ptr(s0), L.ptr(k0),
+                                      i_(code), L.stream_ptr()))
+    z1, s1, k1 = torch.zeros_like(z0), torch.zeros_like(s0), torch.zeros_like(k0)
+    out = torch.zeros(B, N, dtype=dt, device=dev)
+    L.check(raw_.favae_reparam_kl_decoder_input(L.ptr(fc), L.ptr(eps), L.ptr(prior), L.ptr(idx), f_(1.3), i_(B), i_(z), L.ptr(z1), L.ptr(s1),
+                                                L.ptr(k1), L.ptr(w), L.ptr(bias), L.ptr(out), i_(N), i_(code), L.stream_ptr()))
+    assert torch.equal(z0, z1) and torch.equal(s0, s1)
+    assert abs(k0.item() - k1.item()) <= 1e-12 * abs(k0.item())
+    want = z0.double() @ w.double().t() + bias.double()
+    tol = 1e-5 if dt == torch.float32 else 5e-3          # bf16: one rounding of the result
+    assert _err(out.double(), want) < tol
+
+
 def test_colsum_cast():
     L = _L()
     raw_ = L.raw()
