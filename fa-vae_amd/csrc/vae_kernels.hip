@@ -745,13 +745,12 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd(const float* __restrict__ 
 // The same gradient in one block that also sums its columns: dbias [2z] = bias gradient of the encoder head (fc_mu | fc_var
 // rows of dfc).  Element-parallel first (values parked in LDS), then one thread per column adds its rows in order.
 constexpr int RKB_THREADS = 1024, RKB_MAX = 8192;   // B * 2z <= RKB_MAX
-template <class T>
-__global__ __launch_bounds__(RKB_THREADS) void reparam_kl_bwd_bias(const float* __restrict__ fc, const float* __restrict__ eps,
-                                                                   const double* __restrict__ prior, const int* __restrict__ idx,
-                                                                   const float* __restrict__ stdq, const float* __restrict__ dz,
-                                                                   float tau, float beta, int B, int z, T* __restrict__ dfc,
-                                                                   float* __restrict__ dbias) {
-    __shared__ float vals[RKB_MAX];
+template <class T, bool ATOMIC_DZ>
+__device__ __forceinline__ void reparam_bwd_bias_body(const float* __restrict__ fc, const float* __restrict__ eps,
+                                                      const double* __restrict__ prior, const int* __restrict__ idx,
+                                                      const float* __restrict__ stdq, const float* dz, float tau, float beta, int B,
+                                                      int z, T* __restrict__ dfc, float* __restrict__ dbias, float* vals /* [B*2z] */,
+                                                      double* part /* [4*256] */) {
     const double std_p = sqrt((double)(1.0f / tau));
     const double sp = fmin(fmax(std_p, 1e-6), 1e20);
     const double w = (double)beta / B;
@@ -765,7 +764,7 @@ __global__ __launch_bounds__(RKB_THREADS) void reparam_kl_bwd_bias(const float* 
         const double sq = fmin(fmax((double)sd, 1e-6), 1e20);
         const float dkl_mu = (float)(w * ((double)mu - mp) / (sp * sp));
         const float dkl_sd = in_rng ? (float)(w * (sq / (sp * sp) - 1.0 / sq)) : 0.f;
-        const float g = dz[i];
+        const float g = ATOMIC_DZ ? __hip_atomic_load(dz + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : dz[i];
         const float dmu = g + dkl_mu;
         const float dls = (g * eps[i] + dkl_sd) * 0.5f * sd;
         dfc[b * z2 + k] = from_f32<T>(dmu);
@@ -775,7 +774,6 @@ __global__ __launch_bounds__(RKB_THREADS) void reparam_kl_bwd_bias(const float* 
     }
     __syncthreads();
     // 4 partial sums per column (rows b % 4 == part), combined in a fixed order
-    __shared__ double part[4 * 256];
     const int c = threadIdx.x % 256, p4 = threadIdx.x / 256;
     if (c < z2) {
         double t = 0.0;
@@ -784,6 +782,84 @@ __global__ __launch_bounds__(RKB_THREADS) void reparam_kl_bwd_bias(const float* 
     }
     __syncthreads();
     if ((int)threadIdx.x < z2) dbias[threadIdx.x] = (float)((part[threadIdx.x] + part[256 + threadIdx.x]) + (part[512 + threadIdx.x] + part[768 + threadIdx.x]));
+}
+
+template <class T>
+__global__ __launch_bounds__(RKB_THREADS) void reparam_kl_bwd_bias(const float* __restrict__ fc, const float* __restrict__ eps,
+                                                                   const double* __restrict__ prior, const int* __restrict__ idx,
+                                                                   const float* __restrict__ stdq, const float* __restrict__ dz,
+                                                                   float tau, float beta, int B, int z, T* __restrict__ dfc,
+                                                                   float* __restrict__ dbias) {
+    __shared__ float vals[RKB_MAX];
+    __shared__ double part[4 * 256];
+    reparam_bwd_bias_body<T, false>(fc, eps, prior, idx, stdq, dz, tau, beta, B, z, dfc, dbias, vals, part);
+}
+
+// Backward of decoder_input (:41-45) and of the reparameterisation in one launch (the middle of the backward pass is a chain
+// of latency-bound launches).  Block j owns 64 of the N columns for all B rows: it stores the dtype copy of the incoming
+// gradient (operand of the weight gradient), sums its columns (bias gradient, fixed order), and adds its share of
+// dz = d @ W (fp32 atomics into the zeroed dz, as the split-K GEMM did); the block that takes the last ticket then has the
+// complete dz and runs the reparameterisation / KL backward + the bias gradient of the encoder head.
+template <class T>
+__global__ __launch_bounds__(RKB_THREADS) void decin_bwd_reparam(const float* __restrict__ dact, const T* __restrict__ w,
+                                                                 T* __restrict__ draw, float* __restrict__ dbias_di, float* dz,
+                                                                 unsigned* ticket, const float* __restrict__ fc,
+                                                                 const float* __restrict__ eps, const double* __restrict__ prior,
+                                                                 const int* __restrict__ idx, const float* __restrict__ stdq,
+                                                                 float tau, float beta, int B, int z, int N, T* __restrict__ dfc,
+                                                                 float* __restrict__ dbias_fc) {
+    constexpr int ZP = RKD_ZMAX + 1;
+    __shared__ __attribute__((aligned(16))) char smem[RKB_MAX * 4 + 4 * 256 * 8];   // 40 KB: two phases share it
+    __shared__ int is_last;
+    float* ds = (float*)smem;                              // [64][65]
+    float* ws = ds + 64 * 65;                              // [64][ZP]
+    double* colpart = (double*)(smem + 26 * 1024);         // [16][64]
+    const int tid = threadIdx.x, c = tid & 63, r = tid >> 6, n0 = blockIdx.x * 64;
+    for (int i = tid; i < 64 * z; i += RKB_THREADS) {
+        const int cc = i / z, k = i - cc * z;
+        ws[cc * ZP + k] = to_f32<T>(w[(size_t)(n0 + cc) * z + k]);
+    }
+    double colacc = 0.0;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int bl = r + 16 * j, b = b0 + bl;
+            float dr = 0.f;
+            if (b < B) {
+                const float d = dact[(size_t)b * N + n0 + c];
+                const T dt = from_f32<T>(d);
+                draw[(size_t)b * N + n0 + c] = dt;
+                dr = to_f32<T>(dt);
+                colacc += (double)d;
+            }
+            ds[bl * 65 + c] = dr;
+        }
+        __syncthreads();
+        for (int o = tid; o < 64 * z; o += RKB_THREADS) {
+            const int bl = o / z, k = o - bl * z;
+            if (b0 + bl < B) {
+                float a = 0.f;
+#pragma unroll 16
+                for (int cc = 0; cc < 64; ++cc) a = fmaf(ds[bl * 65 + cc], ws[cc * ZP + k], a);
+                atomicAdd(dz + (size_t)(b0 + bl) * z + k, a);
+            }
+        }
+        __syncthreads();
+    }
+    colpart[r * 64 + c] = colacc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the atomics above are complete before the ticket is taken
+    __syncthreads();
+    if (tid < 64) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += colpart[q * 64 + tid];
+        dbias_di[n0 + tid] = (float)t;
+    }
+    if (tid == 0) is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    reparam_bwd_bias_body<T, true>(fc, eps, prior, idx, stdq, dz, tau, beta, B, z, dfc, dbias_fc, (float*)smem, (double*)(smem + RKB_MAX * 4));
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // eval-mode head of update_x: mu and var = std^2 as float64 rows of X.mean / X.cov (:331-358)
@@ -1577,6 +1653,28 @@ extern "C" int favae_reparam_kl_bwd_bias(const float* fc, const float* eps, cons
         hipLaunchKernelGGL(reparam_kl_bwd_bias<float>, dim3(1), dim3(RKB_THREADS), 0, ST, fc, eps, prior, idx, stdq, dz, tau, beta, B, z, (float*)dfc, dbias);
     else
         hipLaunchKernelGGL(reparam_kl_bwd_bias<bf16_t>, dim3(1), dim3(RKB_THREADS), 0, ST, fc, eps, prior, idx, stdq, dz, tau, beta, B, z, (bf16_t*)dfc, dbias);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_decoder_input_bwd_reparam(const float* dact, const void* w, void* draw, float* dbias_di, float* dz,
+                                               const float* fc, const float* eps, const double* prior, const int* idx,
+                                               const float* stdq, float tau, float beta, int B, int z, int N, void* dfc,
+                                               float* dbias_fc, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(dact && w && draw && dbias_di && dz && fc && eps && stdq && dfc && dbias_fc && B > 0 && z > 0 && N > 0 && tau > 0,
+                    "favae_decoder_input_bwd_reparam: bad argument");
+    FAVAE_CHECK_ARG(z <= RKD_ZMAX && N % 64 == 0 && (long long)B * 2 * z <= RKB_MAX,
+                    "favae_decoder_input_bwd_reparam: z <= %d, N a multiple of 64, B * 2z <= %d", RKD_ZMAX, RKB_MAX);
+    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_decoder_input_bwd_reparam: dtype");
+    unsigned* ticket = nullptr;
+    int trc = ticket_base(1, &ticket);
+    if (trc) return trc;
+    if (dtype == FAVAE_F32)
+        hipLaunchKernelGGL(decin_bwd_reparam<float>, dim3(N / 64), dim3(RKB_THREADS), 0, ST, dact, (const float*)w, (float*)draw, dbias_di, dz,
+                           ticket, fc, eps, prior, idx, stdq, tau, beta, B, z, N, (float*)dfc, dbias_fc);
+    else
+        hipLaunchKernelGGL(decin_bwd_reparam<bf16_t>, dim3(N / 64), dim3(RKB_THREADS), 0, ST, dact, (const bf16_t*)w, (bf16_t*)draw, dbias_di, dz,
+                           ticket, fc, eps, prior, idx, stdq, tau, beta, B, z, N, (bf16_t*)dfc, dbias_fc);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

@@ -100,9 +100,10 @@ struct Vae {
     bool join_pending; bool dg_all;
     bool dp_epoch;   // steps of favae_vae_train_epoch_dp: gradients cleared by the bucket-wise Adam, joins through the communication stream
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
+    bool rk_done;   // stage 6 of this step already ran the reparameterisation backward (fused launch)
     bool join2;   // ev_join2 was recorded in the last step
     hipEvent_t ev_join_ext;   // when set: the event join_pending refers to (the communicator's), else ev_join
-    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients (0x200: do not hoist encoder.0's gather to the start of the step; 0x800: encoder.0's update and its bf16 shadow as two launches; 0x1000: encoder.0's update on the optimiser stream; 0x2000: encoder.0's weight gradient + update on the weight-gradient stream instead of the caller's, memset / batch gather of the next step on the caller's; 0x4000: reparameterise + KL and decoder_input as two launches), 128 Adam + weight re-layout in one pass, 256 final conv + loss in one launch
+    unsigned fuse;   // FAVAE_FUSE_MASK (tuning / A-B knob): 1 fwd statistics, 2 bwd sums, 4 bwd sums on the thin-input path, 8 LL+bias, 16 KL+bias, 32 colsum+cast, 64 tap-folded image-side weight gradients (0x200: do not hoist encoder.0's gather to the start of the step; 0x800: encoder.0's update and its bf16 shadow as two launches; 0x1000: encoder.0's update on the optimiser stream; 0x2000: encoder.0's weight gradient + update on the weight-gradient stream instead of the caller's, memset / batch gather of the next step on the caller's; 0x4000: reparameterise + KL and decoder_input as two launches; 0x8000: their backward as three launches), 128 Adam + weight re-layout in one pass, 256 final conv + loss in one launch
     float* xf_alt; char* xt_alt;
     char* wk_out;   // weights of final_layer.3 in the MFMA operand order for favae_conv_out_ll (rebuilt whenever the layer changes)
     char* fold0_buf[2]; int fold_sel; hipEvent_t ev_batch, ev_fold; bool inline_tail;   // see train_stages
@@ -526,6 +527,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.dp_epoch = false;
     v.ev_join_ext = nullptr;
     v.join2 = false;
+    v.rk_done = false;
     v.ev_fence_ok = false;
     v.x_folded = false;
     v.inline_tail = false;
@@ -689,6 +691,14 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1], v.dact_bf[l - 1], l > 7 ? l - 1 : -1));
             RC(after_dgrad(v, l, st));
         } else if (sg == 6) {
+            v.rk_done = !(v.fuse & 0x8000u) && (v.fuse & 16u) && v.z <= 32 && (long long)B * 2 * v.z <= 8192;
+            if (v.rk_done) {   // decoder_input backward (cast, bias gradient, dz) + reparameterisation / KL backward in one launch
+                RC(favae_decoder_input_bwd_reparam(v.dact[L_DI], v.Wf(L_DI), v.draw[L_DI], v.G + v.L[L_DI].b_off, v.dz, v.raw[L_FC], eps, prior,
+                                                   idx, v.stdq, tau, beta, B, v.z, v.L[L_DI].Cout, v.draw[L_FC], v.G + v.L[L_FC].b_off, v.dtype, st));
+                RC(wgrad(v, L_DI, v.zlat, B, st));
+                RC(after_dgrad(v, L_DI, st));
+                continue;
+            }
             if (v.fuse & 32u) {
                 RC(favae_colsum_cast(v.dact[L_DI], v.draw[L_DI], B, 4096, v.G + v.L[L_DI].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
             } else {
@@ -699,7 +709,9 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             RC(dgrad(v, L_DI, v.dz, B, st, true));
             RC(after_dgrad(v, L_DI, st));
         } else if (sg == 7) {
-            if ((v.fuse & 16u) && 2 * v.z <= 256 && (long long)B * 2 * v.z <= 8192) {
+            if (v.rk_done) {
+                v.rk_done = false;
+            } else if ((v.fuse & 16u) && 2 * v.z <= 256 && (long long)B * 2 * v.z <= 8192) {
                 RC(favae_reparam_kl_bwd_bias(v.raw[L_FC], eps, prior, idx, v.stdq, v.dz, tau, beta, B, v.z, v.draw[L_FC],
                                              v.G + v.L[L_FC].b_off, v.dtype, st));
             } else {

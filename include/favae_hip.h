@@ -161,6 +161,13 @@ int favae_reparam_kl_fwd(const float* fc, const float* eps, const double* prior,
 int favae_reparam_kl_decoder_input(const float* fc, const float* eps, const double* prior, const int* idx, float tau, int B,
                                    int z, void* zlat, float* stdq, double* kl_out, const void* w, const float* bias, void* out,
                                    int N, int dtype, void* stream);
+/* Backward of decoder_input and of the reparameterisation in one launch (autograd of :41-45 and :89-92/:137-150 under
+ * loss.backward(), :249): given dact [B][N] fp32 (gradient w.r.t. the decoder_input output) and w [N][z] (dtype):
+ * draw [B][N] = dact as dtype, dbias_di [N] = column sums of dact, dz [B][z] += draw @ w (fp32 atomics, dz ZERO on entry),
+ * then, as favae_reparam_kl_bwd_bias with that dz: dfc [B][2z] (dtype) and dbias_fc [2z].  z <= 32, N % 64 == 0, B*2z <= 8192. */
+int favae_decoder_input_bwd_reparam(const float* dact, const void* w, void* draw, float* dbias_di, float* dz, const float* fc,
+                                    const float* eps, const double* prior, const int* idx, const float* stdq, float tau,
+                                    float beta, int B, int z, int N, void* dfc, float* dbias_fc, int dtype, void* stream);
 /* Gradient of (rec + beta*KL) w.r.t. fc given dz = d rec / d zlat; dfc [B][2z] (dtype). */
 int favae_reparam_kl_bwd(const float* fc, const float* eps, const double* prior, const int* idx, const float* stdq,
                          const float* dz, float tau, float beta, int B, int z, void* dfc, int dtype, void* stream);

@@ -139,6 +139,46 @@ def test_reparam_kl_with_decoder_input_in_one_launch(dt, B, z, N, with_prior):
     assert _err(out.double(), want) < tol
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,z,N,with_prior", [(64, 20, 4096, True), (37, 32, 192, False), (100, 20, 4096, True)])
+def test_decoder_input_backward_with_reparam_backward_in_one_launch(dt, B, z, N, with_prior):
+    """favae_decoder_input_bwd_reparam == favae_colsum_cast + (dz = draw @ W) + favae_reparam_kl_bwd_bias; called twice
+    in a row (the ticket word must be left at zero)."""
+    L = _L()
+    raw_ = L.raw()
+    dev = "cuda"
+    g = torch.Generator().manual_seed(B + z + N)
+    fc = (torch.randn(B, 2 * z, generator=g) * 0.7).to(dev)
+    eps = torch.randn(B, z, generator=g).to(dev)
+    prior = torch.randn(700, z, generator=g, dtype=torch.float64).to(dev) if with_prior else None
+    idx = torch.randint(0, 700, (B,), generator=g, dtype=torch.int32).to(dev) if with_prior else None
+    stdq = torch.exp(0.5 * (fc[:, z:] + 1e-6)).contiguous()
+    w = (torch.randn(N, z, generator=g) * 0.2).to(dt).to(dev)
+    dact = (torch.randn(B, N, generator=g) * 0.05).to(dev)
+    code = 0 if dt == torch.float32 else 1
+    tau, beta = 1.3, 0.7
+    # the separate calls
+    draw0, db0 = torch.zeros(B, N, dtype=dt, device=dev), torch.zeros(N, device=dev)
+    scratch = torch.zeros(2 * 1024 * 64 + 4096, dtype=torch.float64, device=dev)
+    L.check(raw_.favae_colsum_cast(L.ptr(dact), L.ptr(draw0), ll_(B), i_(N), L.ptr(db0), L.ptr(scratch), sz_(scratch.numel()), i_(code),
+                                   L.stream_ptr()))
+    dz0 = (draw0.double() @ w.double()).float().contiguous()
+    dfc0, dbf0 = torch.zeros(B, 2 * z, dtype=dt, device=dev), torch.zeros(2 * z, device=dev)
+    L.check(raw_.favae_reparam_kl_bwd_bias(L.ptr(fc), L.ptr(eps), L.ptr(prior), L.ptr(idx), L.ptr(stdq), L.ptr(dz0), f_(tau), f_(beta),
+                                           i_(B), i_(z), L.ptr(dfc0), L.ptr(dbf0), i_(code), L.stream_ptr()))
+    for _ in range(2):
+        draw1, db1, dz1 = torch.zeros_like(draw0), torch.zeros_like(db0), torch.zeros(B, z, device=dev)
+        dfc1, dbf1 = torch.zeros_like(dfc0), torch.zeros_like(dbf0)
+        L.check(raw_.favae_decoder_input_bwd_reparam(L.ptr(dact), L.ptr(w), L.ptr(draw1), L.ptr(db1), L.ptr(dz1), L.ptr(fc), L.ptr(eps),
+                                                     L.ptr(prior), L.ptr(idx), L.ptr(stdq), f_(tau), f_(beta), i_(B), i_(z), i_(N),
+                                                     L.ptr(dfc1), L.ptr(dbf1), i_(code), L.stream_ptr()))
+        assert torch.equal(draw0, draw1)
+        assert _err(db1, db0) < 1e-6
+        assert _err(dz1, dz0) < 1e-5
+        assert _err(dfc1, dfc0) < (1e-5 if dt == torch.float32 else 1e-2)
+        assert _err(dbf1, dbf0) < 1e-5
+
+
 def test_colsum_cast():
     L = _L()
     raw_ = L.raw()
