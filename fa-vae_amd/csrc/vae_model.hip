@@ -861,8 +861,12 @@ extern "C" int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float
     hipStream_t cs = v.side3;          // collectives + the bucket-wise optimiser step behind them
     hipEvent_t done = v.ev_comm;
     // (arena_lo, arena_hi, first layer, last layer, stage_hi): the slice is complete once backward stages < stage_hi ran
-    const long long w3 = v.L[3].w_off, w6 = v.L[6].w_off;
-    const struct { long long lo, hi; int l0, l1, stage_hi; } bk[3] = {{w6, v.nparam, 6, NL - 1, 7}, {w3, w6, 3, 5, 10}, {0, w3, 0, 2, N_STAGES}};
+    // decoder (25.6 MB, travels under the whole encoder backward) | enc.4 + heads (19.6 MB, under enc.3 .. enc.0) | enc.3 (4.7 MB)
+    // | enc.0-2 (1.6 MB: the only collective that is not hidden behind kernels of the same step)
+    const long long w3 = v.L[3].w_off, w4 = v.L[4].w_off, w6 = v.L[6].w_off;
+    constexpr int NBK = 4;
+    const struct { long long lo, hi; int l0, l1, stage_hi; } bk[NBK] = {
+        {w6, v.nparam, 6, NL - 1, 7}, {w4, w6, 4, 5, 9}, {w3, w4, 3, 3, 10}, {0, w3, 0, 2, N_STAGES}};
     FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));   // the bucket-wise Adam keeps it cleared
     int rc = FAVAE_OK;
     long long s = 0;
@@ -870,7 +874,7 @@ extern "C" int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float
     for (long long o = 0; o < n && rc == FAVAE_OK; o += batch, ++s) {
         const int B = (int)std::min<long long>(batch, n - o);
         int lo = 0;
-        for (int b = 0; b < 3 && rc == FAVAE_OK; ++b) {
+        for (int b = 0; b < NBK && rc == FAVAE_OK; ++b) {
             rc = train_stages(v, data_nhwc, perm + o, B, eps + o * v.z, prior, tau, beta, var_x, metrics + 2 * s, lo, bk[b].stage_hi, st);
             lo = bk[b].stage_hi;
             if (rc) break;

@@ -228,10 +228,10 @@ class VaeEngine:
 
     def grad_buckets(self):
         """(arena_lo, arena_hi, stage_hi): the gradient slice that is complete once backward stages < stage_hi have run.
-        Decoder first (its gradients are ready while the encoder is still in its backward pass), then enc.3-4 + heads,
-        then the small first encoder layers."""
+        Decoder first (its gradients are ready while the encoder is still in its backward pass), then enc.4 + heads,
+        enc.3, and the small first encoder layers (the same four buckets as favae_vae_train_epoch_dp)."""
         w = [d["w"] for d in self.layers]
-        return [(w[6], self.nparam, 7), (w[3], w[6], 10), (0, w[3], self.N_STAGES)]
+        return [(w[6], self.nparam, 7), (w[4], w[6], 9), (w[3], w[4], 10), (0, w[3], self.N_STAGES)]
 
     def adam(self, lr):
         self.step += 1

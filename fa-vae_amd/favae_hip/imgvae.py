@@ -282,7 +282,7 @@ class ImgVAE(VAE):
                 # the same through torch.distributed (gloo rehearsals, or when the native communicator is not available):
                 # every rank runs its own mini-batch of 64, gradients are averaged before the (replicated) Adam step; BN
                 # batch statistics stay per rank (group size 64, as :218)
-                # The gradient arena is averaged in three buckets; the all-reduce of a bucket runs on a communication
+                # The gradient arena is averaged in four buckets; the all-reduce of a bucket runs on a communication
                 # stream while the layers behind it are still in their backward pass (decoder bucket under the whole
                 # encoder backward).
                 if getattr(self, "_comm_stream", None) is None:

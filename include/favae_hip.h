@@ -278,7 +278,7 @@ int favae_comm_destroy(favae_comm* c);
 /* In-place all-reduce (sum, or mean with average != 0) of n floats on `stream`. */
 int favae_allreduce_f32(favae_comm* c, float* buf, long long n, int average, void* stream);
 /* favae_vae_train_epoch for data-parallel training (each rank passes its own shard / permutation / eps): per step the
- * gradient arena is averaged over the ranks in three buckets (decoder | enc.3-4 + heads | enc.0-2); a bucket's all-reduce
+ * gradient arena is averaged over the ranks in four buckets (decoder | enc.4 + heads | enc.3 | enc.0-2); a bucket's all-reduce
  * and the Adam step + weight re-layout of its layers run on the communicator's stream as soon as its last weight
  * gradient is complete, under the backward pass of the layers behind it; the next forward pass waits for that stream.
  * Same arithmetic as fwd/bwd -> all-reduce(mean) -> Adam (replicated parameters stay bit-identical across ranks). */

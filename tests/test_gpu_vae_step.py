@@ -104,7 +104,7 @@ def test_training_steps_match_oracle(dtype, tol_loss, tol_bulk, min_cos):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_staged_step_equals_the_whole_step(dtype):
-    """favae_vae_train_stages in the three pieces the data-parallel trainloop uses, with a fence before each gradient
+    """favae_vae_train_stages in the pieces the data-parallel trainloop uses, with a fence before each gradient
     bucket is read on another stream (as the RCCL all-reduce does), gives the gradients of favae_vae_train_fwdbwd.
     Same kernels, same order; only split-K / binned atomics reorder sums, hence 1e-4 (fp32) / 5e-3 (bf16) of scale."""
     z, Bn = 20, 64
