@@ -438,33 +438,38 @@ struct BnBwdApplyF {
 
 // ---------------------------------------------------------------------------------------------------------
 // "Channel-owner" BatchNorm kernels for the small layers (R <= 1024 rows: the 4x4 and 2x2 feature maps at batch 64).
-// One 512-thread block owns 16 channels and ALL rows, keeps its elements in registers between the statistics and the
+// One 512-thread block owns OWN_CT (8) channels and ALL rows, keeps its elements in registers between the statistics and the
 // apply phase, and needs no hand-over between blocks: statistics + apply (forward) or both reduction passes + apply
 // (backward) are one launch instead of two, which is what counts for tensors of 0.25-0.5 M elements.
 // Sums are fp64 in a fixed order (bit-reproducible), as in colreduce.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int OWN_THREADS = 512, OWN_CT = 16, OWN_RG = OWN_THREADS / 4, OWN_MAXP = 8, OWN_WAVES = OWN_THREADS / 64;
+// channels per block: 8 measured best on MI355X (64 blocks for the 512-channel layers; 16 -> 8: -1.0 % step time, 4: -0.5 %)
+#ifndef FAVAE_OWN_CT
+#define FAVAE_OWN_CT 8
+#endif
+constexpr int OWN_THREADS = 512, OWN_CT = FAVAE_OWN_CT, OWN_TPR = OWN_CT / 4 /* threads per row */, OWN_RG = OWN_THREADS / OWN_TPR,
+              OWN_MAXP = 1024 / OWN_RG, OWN_WAVES = OWN_THREADS / 64;
 
 // sum the per-thread fp64 partials val[NQ][4] over the row groups of the block; result for channel (tl*4+j) of
-// quantity q lands in tot[q][16] (shared), valid after the trailing barrier
+// quantity q lands in tot[q][OWN_CT] (shared), valid after the trailing barrier
 template <int NQ>
-__device__ __forceinline__ void own_reduce(double (*val)[4], double* sm /* [NQ][OWN_WAVES][16] */, double* tot /* [NQ][16] */) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = tid & 3;
+__device__ __forceinline__ void own_reduce(double (*val)[4], double* sm /* [NQ][OWN_WAVES][OWN_CT] */, double* tot /* [NQ][OWN_CT] */) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = tid % OWN_TPR;
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             double t = val[q][j];
-            for (int o = 4; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
-            if (lane < 4) sm[(q * OWN_WAVES + wave) * 16 + tl * 4 + j] = t;
+            for (int o = OWN_TPR; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+            if (lane < OWN_TPR) sm[(q * OWN_WAVES + wave) * OWN_CT + tl * 4 + j] = t;
         }
     __syncthreads();
-    if (tid < NQ * 16) {
-        const int q = tid >> 4, c = tid & 15;
+    if (tid < NQ * OWN_CT) {
+        const int q = tid / OWN_CT, c = tid % OWN_CT;
         double t = 0.0;
 #pragma unroll
-        for (int w = 0; w < OWN_WAVES; ++w) t += sm[(q * OWN_WAVES + w) * 16 + c];
-        tot[q * 16 + c] = t;
+        for (int w = 0; w < OWN_WAVES; ++w) t += sm[(q * OWN_WAVES + w) * OWN_CT + c];
+        tot[q * OWN_CT + c] = t;
     }
     __syncthreads();
 }
@@ -475,9 +480,9 @@ __global__ __launch_bounds__(OWN_THREADS) void bn_fwd_owner(const float* __restr
                                                             float* __restrict__ mean, float* __restrict__ invstd,
                                                             float* __restrict__ run_mean, float* __restrict__ run_var, int R,
                                                             int C, float eps, float mom) {
-    __shared__ double sm[2 * OWN_WAVES * 16], tot[2 * 16];
-    __shared__ float ab[2 * 16];
-    const int tid = threadIdx.x, tl = tid & 3, rg = tid >> 2;
+    __shared__ double sm[2 * OWN_WAVES * OWN_CT], tot[2 * OWN_CT];
+    __shared__ float ab[2 * OWN_CT];
+    const int tid = threadIdx.x, tl = tid % OWN_TPR, rg = tid / OWN_TPR;
     const int c0 = blockIdx.x * OWN_CT + tl * 4;
     float x[OWN_MAXP][4];
     double val[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -491,10 +496,10 @@ __global__ __launch_bounds__(OWN_THREADS) void bn_fwd_owner(const float* __restr
         }
     }
     own_reduce<2>(val, sm, tot);
-    if (tid < 16) {
+    if (tid < OWN_CT) {
         const int c = blockIdx.x * OWN_CT + tid;
         const double Rd = (double)R, m = tot[tid] / Rd;
-        double var = tot[16 + tid] / Rd - m * m;
+        double var = tot[OWN_CT + tid] / Rd - m * m;
         if (var < 0) var = 0;
         const float is = (float)(1.0 / sqrt(var + (double)eps));
         mean[c] = (float)m;
@@ -506,12 +511,12 @@ __global__ __launch_bounds__(OWN_THREADS) void bn_fwd_owner(const float* __restr
         }
         const float a = is * gamma[c];
         ab[tid] = a;
-        ab[16 + tid] = beta[c] - (float)m * a;
+        ab[OWN_CT + tid] = beta[c] - (float)m * a;
     }
     __syncthreads();
     float a[4], b[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { a[j] = ab[tl * 4 + j]; b[j] = ab[16 + tl * 4 + j]; }
+    for (int j = 0; j < 4; ++j) { a[j] = ab[tl * 4 + j]; b[j] = ab[OWN_CT + tl * 4 + j]; }
 #pragma unroll
     for (int p = 0; p < OWN_MAXP; ++p) {
         const int r = rg + p * OWN_RG;
@@ -530,8 +535,8 @@ __global__ __launch_bounds__(OWN_THREADS) void bn_bwd_owner(const float* __restr
                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                             T* __restrict__ draw, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ dbias, int R, int C) {
-    __shared__ double sm[2 * OWN_WAVES * 16], tot[2 * 16];
-    const int tid = threadIdx.x, tl = tid & 3, rg = tid >> 2;
+    __shared__ double sm[2 * OWN_WAVES * OWN_CT], tot[2 * OWN_CT];
+    const int tid = threadIdx.x, tl = tid % OWN_TPR, rg = tid / OWN_TPR;
     const int c0 = blockIdx.x * OWN_CT + tl * 4;
     float mu[4], is[4], gi[4];
 #pragma unroll
@@ -556,15 +561,15 @@ __global__ __launch_bounds__(OWN_THREADS) void bn_bwd_owner(const float* __restr
         }
     }
     own_reduce<2>(val, sm, tot);
-    if (tid < 16) {
+    if (tid < OWN_CT) {
         const int c = blockIdx.x * OWN_CT + tid;
         dbeta[c] = (float)tot[tid];
-        dgamma[c] = (float)tot[16 + tid];
+        dgamma[c] = (float)tot[OWN_CT + tid];
     }
     const float invR = (float)(1.0 / (double)R);
     float k1[4], k2[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { k1[j] = (float)tot[tl * 4 + j] * invR; k2[j] = (float)tot[16 + tl * 4 + j] * invR; }
+    for (int j = 0; j < 4; ++j) { k1[j] = (float)tot[tl * 4 + j] * invR; k2[j] = (float)tot[OWN_CT + tl * 4 + j] * invR; }
     double gs[1][4] = {{0, 0, 0, 0}};
 #pragma unroll
     for (int p = 0; p < OWN_MAXP; ++p) {
@@ -579,7 +584,7 @@ __global__ __launch_bounds__(OWN_THREADS) void bn_bwd_owner(const float* __restr
     if (dbias) {   // uniform
         __syncthreads();   // tot is re-used
         own_reduce<1>(gs, sm, tot);
-        if (tid < 16) dbias[blockIdx.x * OWN_CT + tid] = (float)tot[tid];
+        if (tid < OWN_CT) dbias[blockIdx.x * OWN_CT + tid] = (float)tot[tid];
     }
 }
 
