@@ -102,6 +102,63 @@ def test_training_steps_match_oracle(dtype, tol_loss, tol_bulk, min_cos):
                 assert _rel(got[k].numpy(), Bf[k].numpy()) <= 1e-4, (step, k)
 
 
+@pytest.mark.parametrize("dtype,tol_loss,min_cos", [("f32", 1e-4, 0.9999), ("bf16", 1e-2, 0.97)])
+def test_one_channel_images(dtype, tol_loss, min_cos):
+    """Grayscale data (ImgVAE takes the channel count from the data, cA/favae.py:265): one training step against the
+    oracle, then the same step through the epoch entry point (weight gradients / updates on the side streams, tap-folded
+    image-side gradients with one channel) against step + Adam."""
+    from favae_hip.engine import VaeEngine
+    z, Bn = 20, 64
+    torch.manual_seed(1)
+    np.random.seed(1)
+    P, Bf = vt.init_state(z, 1)
+    names = list(P.keys())
+    sd = {k: v.detach().clone() for k, v in P.items()}
+    sd.update({k: v.clone() for k, v in Bf.items()})
+    img3, _ = img_inputs(3 * Bn)
+    img = np.ascontiguousarray(img3[:, 1:2])
+    prior = torch.from_numpy(np.random.RandomState(7).randn(3 * Bn, z) * 0.5)
+    tau = torch.Tensor(np.asarray(np.array([1.7])))
+    eps = torch.randn(3 * Bn, z, generator=torch.Generator().manual_seed(9))
+    eng = VaeEngine(z, 1, batch_max=Bn, dtype=dtype)
+    eng.load_state_dict(sd)
+    data = eng.upload_images(img)
+    idx = torch.arange(3 * Bn, dtype=torch.int32, device="cuda")
+    eps_d, prior_d = eps.cuda(), prior.cuda()
+    loss, rec_err, kl, mu, std, zz, rec = vt.loss_terms(P, Bf, torch.tensor(img[:Bn]), prior[:Bn], tau, 0.01, 1, eps=eps[:Bn])
+    loss.backward()
+    m = eng.train_fwdbwd(data, idx[:Bn], Bn, eps_d[:Bn], prior_d[:Bn], 1.7, 1.0, 0.01).cpu().numpy()
+    assert abs(m[0] - rec_err.item()) <= tol_loss * abs(rec_err.item()), (m, rec_err.item())
+    assert abs(m[1] - kl.item()) <= tol_loss * abs(kl.item()) + 1e-6, (m, kl.item())
+    g = eng.unpack(eng.G)
+    for k in names:
+        if k not in NOISE_ONLY:
+            assert _cos(g[k].numpy(), P[k].grad.numpy()) >= min_cos, (k, _cos(g[k].numpy(), P[k].grad.numpy()))
+    # The epoch entry point (weight gradients / layer-wise Adam on the side streams) against step + Adam on one stream,
+    # after ONE optimiser step.  Adam's first step moves every entry by +-lr whatever the gradient magnitude, so entries
+    # whose gradient is rounding noise (split-K atomics reorder sums) differ by 2*lr between ANY two runs, of the same
+    # path too (tools/dbg_epoch_vs_steps.py): everything else must agree, and such entries must stay rare.
+    eng.load_state_dict(sd)
+    eng.step = 0
+    ms = torch.zeros(1, 2, dtype=torch.float64, device="cuda")
+    eng.train_epoch(data, idx[:Bn], eps_d[:Bn], prior_d[:Bn], 1.7, 1.0, 0.01, 1e-3, Bn, ms)
+    torch.cuda.synchronize()
+    assert np.allclose(ms[0].cpu().numpy(), m, rtol=1e-6)
+    got = {k: v.clone() for k, v in eng.state_dict().items()}
+    eng2 = VaeEngine(z, 1, batch_max=Bn, dtype=dtype)
+    eng2.load_state_dict(sd)
+    data2 = eng2.upload_images(img)
+    eng2.train_fwdbwd(data2, idx[:Bn], Bn, eps_d[:Bn], prior_d[:Bn], 1.7, 1.0, 0.01)
+    eng2.adam(1e-3)
+    want = eng2.state_dict()
+    for k in names:
+        if k in NOISE_ONLY:
+            continue
+        d = np.abs(got[k].numpy() - want[k].numpy())
+        assert d.max() <= 2.1e-3, (k, d.max())
+        assert (d > 1e-4).sum() <= max(3, 0.02 * d.size), (k, int((d > 1e-4).sum()), d.size)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_staged_step_equals_the_whole_step(dtype):
     """favae_vae_train_stages in the pieces the data-parallel trainloop uses, with a fence before each gradient
