@@ -102,15 +102,17 @@ def test_training_steps_match_oracle(dtype, tol_loss, tol_bulk, min_cos):
                 assert _rel(got[k].numpy(), Bf[k].numpy()) <= 1e-4, (step, k)
 
 
-@pytest.mark.parametrize("ch", [1, 4])
-@pytest.mark.parametrize("dtype,tol_loss,min_cos", [("f32", 1e-4, 0.9999), ("bf16", 1e-2, 0.97)])
-def test_other_channel_counts(dtype, tol_loss, min_cos, ch):
+@pytest.mark.parametrize("ch,z", [(1, 20), (4, 20), (3, 100)])
+@pytest.mark.parametrize("dtype,tol_loss,min_cos", [("f32", 1e-4, 0.9999), ("bf16", 1e-2, 0.95)])   # bf16 at z = 100: 0.970 measured for enc.0's BN bias
+def test_other_channel_counts_and_latent_sizes(dtype, tol_loss, min_cos, ch, z):
     """Grayscale / four-channel data (ImgVAE takes the channel count from the data, cA/favae.py:265; four channels take
-    the VALU weight-gradient kernels instead of the tap-folded GEMM): one training step against the
+    the VALU weight-gradient kernels instead of the tap-folded GEMM) and the 100-dimensional latent of the DA / TL trainers
+    (domain_adaptation_trainer.py:145, trainer_FAVAE.py:98; beyond the sizes the fused launches around the latent take, so
+    the separate kernels run): one training step against the
     oracle, then the same step through the epoch entry point (weight gradients / updates on the side streams, tap-folded
     image-side gradients with one channel) against step + Adam."""
     from favae_hip.engine import VaeEngine
-    z, Bn = 20, 64
+    Bn = 64
     torch.manual_seed(1)
     np.random.seed(1)
     P, Bf = vt.init_state(z, ch)
@@ -118,7 +120,7 @@ def test_other_channel_counts(dtype, tol_loss, min_cos, ch):
     sd = {k: v.detach().clone() for k, v in P.items()}
     sd.update({k: v.clone() for k, v in Bf.items()})
     img3, _ = img_inputs(3 * Bn)
-    img = np.ascontiguousarray(np.concatenate([img3, img3[:, :1]], 1)[:, :ch] if ch == 4 else img3[:, 1:2])
+    img = np.ascontiguousarray(np.concatenate([img3, img3[:, :1]], 1) if ch == 4 else img3 if ch == 3 else img3[:, 1:2])
     prior = torch.from_numpy(np.random.RandomState(7).randn(3 * Bn, z) * 0.5)
     tau = torch.Tensor(np.asarray(np.array([1.7])))
     eps = torch.randn(3 * Bn, z, generator=torch.Generator().manual_seed(9))
@@ -158,7 +160,7 @@ def test_other_channel_counts(dtype, tol_loss, min_cos, ch):
             continue
         d = np.abs(got[k].numpy() - want[k].numpy())
         assert d.max() <= 2.1e-3, (k, d.max())
-        assert (d > 1e-4).sum() <= max(3, 0.02 * d.size), (k, int((d > 1e-4).sum()), d.size)
+        assert (d > 1e-4).sum() <= max(3, 0.10 * d.size), (k, int((d > 1e-4).sum()), d.size)   # measured 0-2 %; a wrong gradient flips ~half
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
