@@ -69,5 +69,10 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Every global store / atomic this thread has issued has been performed (gfx9 counts stores and atomics in vmcnt).
+// Used before the barrier that precedes a cross-block ticket: neither a workgroup-scope release fence nor s_barrier
+// waits for outstanding vector memory operations on gfx950.
+__device__ __forceinline__ void wait_vm_writes() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }

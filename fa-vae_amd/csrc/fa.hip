@@ -22,16 +22,20 @@ __device__ __forceinline__ f64x4 mfma_f64(double a, double b, f64x4 c) {
 
 // ---------------------------------------------------------------------------------------------------------
 // C[da][dbp] = A^T [B | 1]   (dbp = db + ones)
-// One wave per (row slab, tile group): TI x TJ tiles of 16x16 accumulate over the slab's rows, 4 rows per MFMA
-// (lane l supplies row l>>4, column l&15 of both operands straight from global memory: 128-B row segments).
-// Slabs are summed in slab order by atb_finish => bitwise reproducible.
+// One block = 4 waves per (row slab, tile group).  Every wave accumulates TI x TJ tiles of 16x16 over its share of the
+// slab's rows (groups of 4 rows, interleaved between the waves), 4 rows per MFMA: lane l supplies row l>>4, column l&15
+// of both operands straight from global memory (128-B row segments; the operands are read exactly once, so there is
+// nothing to stage).  The four waves are added through LDS in wave order, the slabs in slab order by atb_finish =>
+// bitwise reproducible.  HBM-bound: 8 B * N * (da + db) read, 8 B * nslab * da * dbp of partials written and re-read.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int TI = 4, TJ = 4;
+constexpr int ATB_WAVES = 4;
 
-__global__ __launch_bounds__(64) void atb_kernel(const double* __restrict__ A, int lda, int da, const double* __restrict__ B,
-                                                 int ldb, int db, int ones, long long N, int rps, int gj,
-                                                 double* __restrict__ partial) {
-    const int lane = threadIdx.x, lr = lane >> 4, lc = lane & 15;
+__global__ __launch_bounds__(64 * ATB_WAVES) void atb_kernel(const double* __restrict__ A, int lda, int da,
+                                                             const double* __restrict__ B, int ldb, int db, int ones, long long N,
+                                                             int rps, int gj, double* __restrict__ partial) {
+    __shared__ double red[ATB_WAVES][TJ * 4][64];   // 32 KB: one row of tiles (TJ x 4 registers) of every wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane >> 4, lc = lane & 15;
     const int dbp = db + ones;
     const int i0 = (blockIdx.y / gj) * (TI * 16), j0 = (blockIdx.y % gj) * (TJ * 16);
     const long long n0 = (long long)blockIdx.x * rps, n1 = min(N, n0 + (long long)rps);
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(64) void atb_kernel(const double* __restrict__ A, i
     for (int a = 0; a < TI; ++a)
 #pragma unroll
         for (int b = 0; b < TJ; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-    for (long long n = n0; n < n1; n += 4) {
+    for (long long n = n0 + 4 * wave; n < n1; n += 4 * ATB_WAVES) {
         const long long r = n + lr;
         const bool ok = r < n1;
         double av[TI], bv[TJ];
@@ -62,14 +66,21 @@ __global__ __launch_bounds__(64) void atb_kernel(const double* __restrict__ A, i
     // C/D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
     double* out = partial + (size_t)blockIdx.x * da * dbp;
 #pragma unroll
-    for (int a = 0; a < TI; ++a)
+    for (int a = 0; a < TI; ++a) {
 #pragma unroll
         for (int b = 0; b < TJ; ++b)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int i = i0 + a * 16 + lr + 4 * g, j = j0 + b * 16 + lc;
-                if (i < da && j < dbp) out[(size_t)i * dbp + j] = acc[a][b][g];
-            }
+            for (int g = 0; g < 4; ++g) red[wave][b * 4 + g][lane] = acc[a][b][g];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TJ * 4 / ATB_WAVES; ++k) {
+            const int bg = wave + ATB_WAVES * k, b = bg >> 2, g = bg & 3;
+            const double t = (red[0][bg][lane] + red[1][bg][lane]) + (red[2][bg][lane] + red[3][bg][lane]);
+            const int i = i0 + a * 16 + lr + 4 * g, j = j0 + b * 16 + lc;
+            if (i < da && j < dbp) out[(size_t)i * dbp + j] = t;
+        }
+        __syncthreads();
+    }
 }
 
 __global__ void atb_finish(const double* __restrict__ partial, int nslab, int n, double* __restrict__ C) {
@@ -425,13 +436,14 @@ inline int ew_grid(size_t n) { return (int)std::min<size_t>(2048, std::max<size_
 
 #define ST ((hipStream_t)stream)
 
+// slabs of rows: ~1024 blocks of 4 waves over the (tile group, slab) grid fill the chip; at least 256 rows per slab
 static void atb_geom(long long N, int da, int dbp, int* nslab, int* rps, int* gi, int* gj) {
     *gi = cdiv(cdiv(da, 16), TI);
     *gj = cdiv(cdiv(dbp, 16), TJ);
     const int groups = (*gi) * (*gj);
-    long long ns = std::max(1LL, std::min<long long>(cdivll(N, 64), std::max(1, 4096 / groups)));
+    long long ns = std::max(1LL, std::min<long long>(cdivll(N, 256), std::max(1, 1024 / groups)));
     long long r = cdivll(N, ns);
-    r = (r + 3) & ~3LL;
+    r = (r + 15) & ~15LL;
     *rps = (int)r;
     *nslab = (int)cdivll(N, r);
 }
@@ -442,20 +454,26 @@ extern "C" long long favae_fa_atb_scratch_doubles(long long N, int da, int db, i
     return (long long)nslab * da * (db + (ones ? 1 : 0));
 }
 
-extern "C" int favae_fa_atb(const double* A, int lda, int da, const double* B, int ldb, int db, int ones, long long N, double* C,
-                            double* scratch, size_t scratch_doubles, void* stream) {
-    FAVAE_CHECK_ARG(A && C && scratch && N > 0 && da > 0 && db >= 0 && (B || db == 0) && (db > 0 || ones), "favae_fa_atb: bad argument");
+static int atb_run(const double* A, int lda, int da, const double* B, int ldb, int db, int ones, long long N, double* C,
+                   double* scratch, size_t scratch_doubles, const char* who, void* stream) {
     const int dbp = db + (ones ? 1 : 0);
     int nslab, rps, gi, gj;
     atb_geom(N, da, dbp, &nslab, &rps, &gi, &gj);
-    FAVAE_CHECK_ARG((size_t)nslab * da * dbp <= scratch_doubles, "favae_fa_atb: scratch too small (%zu < %zu)", scratch_doubles,
+    FAVAE_CHECK_ARG((size_t)nslab * da * dbp <= scratch_doubles, "%s: scratch too small (%zu < %zu doubles)", who, scratch_doubles,
                     (size_t)nslab * da * dbp);
-    hipLaunchKernelGGL(atb_kernel, dim3(nslab, gi * gj), dim3(64), 0, ST, A, lda, da, B ? B : A, ldb, db, ones ? 1 : 0, N, rps, gj, scratch);
+    FAVAE_CHECK_ARG(lda >= da && (db == 0 || ldb >= db), "%s: leading dimension smaller than the row", who);
+    hipLaunchKernelGGL(atb_kernel, dim3(nslab, gi * gj), dim3(64 * ATB_WAVES), 0, ST, A, lda, da, B ? B : A, ldb, db, ones ? 1 : 0, N, rps, gj, scratch);
     FAVAE_LAUNCH_CHECK();
     const int n = da * dbp;
     hipLaunchKernelGGL(atb_finish, dim3(cdiv(n, 8)), dim3(256), 0, ST, scratch, nslab, n, C);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
+}
+
+extern "C" int favae_fa_atb(const double* A, int lda, int da, const double* B, int ldb, int db, int ones, long long N, double* C,
+                            double* scratch, size_t scratch_doubles, void* stream) {
+    FAVAE_CHECK_ARG(A && C && scratch && N > 0 && da > 0 && db >= 0 && (B || db == 0) && (db > 0 || ones), "favae_fa_atb: bad argument");
+    return atb_run(A, lda, da, B, ldb, db, ones, N, C, scratch, scratch_doubles, "favae_fa_atb", stream);
 }
 
 extern "C" int favae_fa_rows_gemm(const double* X, int ldx, int d, const double* P, int ldp, int K, const double* c, double alpha,

@@ -119,8 +119,10 @@ __global__ __launch_bounds__(RED_THREADS) void colreduce(int R, int C, int TPR, 
             }
     }
     // The partial sums travel between blocks as agent-scope (write-through / cache-bypassing) atomic stores and loads, so
-    // only their completion has to be awaited before the ticket is taken: no L2 write-back fence per block.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // only their completion has to be awaited before the ticket is taken: no L2 write-back fence per block.  A
+    // workgroup-scope release fence emits no wait on gfx9, and s_barrier does not wait for memory either: every thread
+    // waits for its own stores explicitly, then the barrier, then the ticket.
+    wait_vm_writes();
     __syncthreads();
     if (tid == 0) is_last = __hip_atomic_fetch_add(&tickets[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nslab - 1);
     __syncthreads();
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(RKB_THREADS) void decin_bwd_reparam(const float* __
         __syncthreads();
     }
     colpart[r * 64 + c] = colacc;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the atomics above are complete before the ticket is taken
+    wait_vm_writes();   // this thread's dz atomics have been performed before the barrier that precedes the ticket
     __syncthreads();
     if (tid < 64) {
         double t = 0.0;
@@ -863,6 +865,7 @@ __global__ __launch_bounds__(RKB_THREADS) void decin_bwd_reparam(const float* __
     if (tid == 0) is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
     if (!is_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // dz is read with plain loads below: drop any cached copy
     reparam_bwd_bias_body<T, true>(fc, eps, prior, idx, stdq, dz, tau, beta, B, z, dfc, dbias_fc, (float*)smem, (double*)(smem + RKB_MAX * 4));
     if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -942,7 +945,7 @@ __global__ __launch_bounds__(256) void sigmoid_ll_bias(const float* __restrict__
         __hip_atomic_store(&partial[(size_t)blockIdx.x * 5 + threadIdx.x],
                            (sm[threadIdx.x * 4] + sm[threadIdx.x * 4 + 1]) + (sm[threadIdx.x * 4 + 2] + sm[threadIdx.x * 4 + 3]),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    wait_vm_writes();   // partial stores performed before the barrier that precedes the ticket
     __syncthreads();
     if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
@@ -1018,7 +1021,7 @@ __device__ __forceinline__ void conv_out_ll_tail(const float4v acc, const float*
         __hip_atomic_store(&partial[(size_t)blockIdx.x * 5 + threadIdx.x],
                            (sm[threadIdx.x * 4] + sm[threadIdx.x * 4 + 1]) + (sm[threadIdx.x * 4 + 2] + sm[threadIdx.x * 4 + 3]),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    wait_vm_writes();   // partial stores performed before the barrier that precedes the ticket
     __syncthreads();
     if (threadIdx.x == 0) *is_last_p = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();

@@ -227,7 +227,12 @@ int ensure_streams(Vae& v, hipStream_t main) {
     if (v.side) return FAVAE_OK;
     constexpr int NC = 4, NS = NC + 1;
     hipStream_t s[NS] = {main, nullptr, nullptr, nullptr, nullptr};
-    for (int i = 1; i < NS; ++i) FAVAE_HIP(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
+    for (int i = 1; i < NS; ++i)
+        if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) {
+            for (int j = 1; j < i; ++j) (void)hipStreamDestroy(s[j]);
+            favae_set_error("favae: could not create the side streams");
+            return FAVAE_ERR_HIP;
+        }
     unsigned long long* buf = (unsigned long long*)v.scratch;      // NS*NS stamps; the scratch is idle before the first step
     unsigned long long host[NS * NS];
     bool beside[NS][NS];
@@ -236,18 +241,19 @@ int ensure_streams(Vae& v, hipStream_t main) {
     for (int i = 0; i < NS; ++i)
         for (int j = 0; j < NS; ++j) beside[i][j] = i != j;
     if (probe) {
-        FAVAE_HIP(hipDeviceSynchronize());
-        for (int i = 0; i < NS; ++i) {
+        // a failing probe is not fatal: the streams are kept and the unprobed choice (the first three) is used
+        bool ok = hipDeviceSynchronize() == hipSuccess;
+        for (int i = 0; i < NS && ok; ++i) {
             hipLaunchKernelGGL(probe_spin, dim3(1), dim3(64), 0, s[i], 15000ULL, buf + i * NS + i);   // 100 MHz clock: 150 us
             for (int j = 0; j < NS; ++j)
                 if (j != i) hipLaunchKernelGGL(probe_stamp, dim3(1), dim3(64), 0, s[j], buf + i * NS + j);
-            FAVAE_HIP(hipGetLastError());
-            FAVAE_HIP(hipDeviceSynchronize());
+            ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
         }
-        FAVAE_HIP(hipMemcpy(host, buf, sizeof(host), hipMemcpyDeviceToHost));
-        for (int i = 0; i < NS; ++i)
-            for (int j = 0; j < NS; ++j)
-                if (i != j) beside[i][j] = host[i * NS + j] < host[i * NS + i];
+        ok = ok && hipMemcpy(host, buf, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok)
+            for (int i = 0; i < NS; ++i)
+                for (int j = 0; j < NS; ++j)
+                    if (i != j) beside[i][j] = host[i * NS + j] < host[i * NS + i];
     }
     auto ok2 = [&](int a, int b) { return beside[a][b] && beside[b][a]; };
     int pick[3] = {-1, -1, -1}, best = -1;
@@ -550,7 +556,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
         ok = ok && hipEventCreateWithFlags(&v.ev_join, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&v.ev_join2, hipEventDisableTiming) == hipSuccess;
         if (!ok) {
-            delete h;
+            (void)favae_vae_destroy(h);   // null-safe: destroys the events that were created
             favae_set_error("favae_vae_create: could not create the side stream / events");
             return FAVAE_ERR_HIP;
         }
@@ -560,18 +566,15 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
 }
 
 extern "C" int favae_vae_destroy(favae_vae* h) {
-    if (h && h->v.ev_fence_ok) { (void)hipEventDestroy(h->v.ev_fence[0]); (void)hipEventDestroy(h->v.ev_fence[1]); }
-    if (h && h->v.overlap) {
-        for (hipStream_t q : {h->v.side, h->v.side2, h->v.side3})
-            if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
-        (void)hipEventDestroy(h->v.ev_comm);
-        (void)hipEventDestroy(h->v.ev_x);
-        (void)hipEventDestroy(h->v.ev_batch);
-        (void)hipEventDestroy(h->v.ev_fold);
-        for (int l = 0; l < NL; ++l) { (void)hipEventDestroy(h->v.ev_fork[l]); (void)hipEventDestroy(h->v.ev_dg[l]); (void)hipEventDestroy(h->v.ev_wg[l]); }
-        (void)hipEventDestroy(h->v.ev_join);
-        (void)hipEventDestroy(h->v.ev_join2);
-    }
+    if (!h) return FAVAE_OK;
+    Vae& v = h->v;
+    auto kill = [](hipEvent_t& e) { if (e) { (void)hipEventDestroy(e); e = nullptr; } };   // handles are value-initialised to null
+    if (v.ev_fence_ok) { kill(v.ev_fence[0]); kill(v.ev_fence[1]); }
+    for (hipStream_t q : {v.side, v.side2, v.side3})
+        if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+    kill(v.ev_comm); kill(v.ev_x); kill(v.ev_batch); kill(v.ev_fold);
+    for (int l = 0; l < NL; ++l) { kill(v.ev_fork[l]); kill(v.ev_dg[l]); kill(v.ev_wg[l]); }
+    kill(v.ev_join); kill(v.ev_join2);
     delete h;
     return FAVAE_OK;
 }

@@ -64,6 +64,14 @@ class ImgVAE(VAE):
 
     def __init__(self, dimx=2, channels=1, var_x=0.01, lr=1e-5, h=None, w=None, dataset=None, latentspace_lr=1,
                  precision=None):
+        # shape limits of the HIP executor (favae_vae_create): stated here so that they fail at construction, not at the
+        # first GPU call
+        if int(dimx) < 2 or int(dimx) % 2:
+            raise ValueError("ImgVAE: the HIP executor needs an even latent size >= 2 (got dimx=%r)" % (dimx,))
+        if not 1 <= int(channels) <= 4:
+            raise ValueError("ImgVAE: the HIP executor handles 1..4 image channels (got %r)" % (channels,))
+        if (h is not None and int(h) != 64) or (w is not None and int(w) != 64):
+            raise ValueError("ImgVAE: the network is the reference's 64x64 architecture (got h=%r, w=%r)" % (h, w))
         super().__init__(channels=channels, h=h, w=w, zDim=dimx, dataset=dataset, latentspace_lr=latentspace_lr)
         self.lr, self.dimx, self.var_x = lr, dimx, var_x
         self.optim = torch.optim.Adam(self.parameters(), self.lr)
@@ -86,7 +94,7 @@ class ImgVAE(VAE):
         self._pull()
         st = self.__dict__.copy()
         st["_stale"] = False
-        for k in ("_eng", "_data_dev", "x_mean_dev", "x_cov_dev", "_ckp", "_img_src"):
+        for k in ("_eng", "_data_dev", "x_mean_dev", "x_cov_dev", "_ckp", "_img_src", "_comm_stream"):
             st[k] = None
         st["_synced_version"], st["_img_key"] = None, None
         return st
