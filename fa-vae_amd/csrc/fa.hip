@@ -476,6 +476,33 @@ extern "C" int favae_fa_atb(const double* A, int lda, int da, const double* B, i
     return atb_run(A, lda, da, B, ldb, db, ones, N, C, scratch, scratch_doubles, "favae_fa_atb", stream);
 }
 
+// ---- favae_fa_atb for callers that cannot allocate (HIP graph capture, serving loops) ---------------------------------
+// The slab partials live in a file-scope device array instead of a caller-supplied scratch buffer.  One array per GPU
+// (each device holds its own copy at its own address), shared by every call on that GPU: calls that overlap on one GPU
+// (two streams) race on it.  Nothing in it has to start at zero: atb_kernel overwrites every partial that atb_finish reads.
+constexpr size_t ATB_STATIC_DOUBLES = (size_t)1 << 22;   // 32 MB; atb_geom never needs more while da * (db + ones) <= 4194304
+static __device__ __align__(256) double g_atb_static[ATB_STATIC_DOUBLES];
+static double* g_atb_static_ptr[64] = {nullptr};          // host: device address of the array on device i (not the symbol)
+
+extern "C" int favae_fa_atb_static(const double* A, int lda, int da, const double* B, int ldb, int db, int ones, long long N,
+                                   double* C, void* stream) {
+    FAVAE_CHECK_ARG(A && C && N > 0 && da > 0 && db >= 0 && (B || db == 0) && (db > 0 || ones), "favae_fa_atb_static: bad argument");
+    const size_t dbp = (size_t)db + (ones ? 1 : 0);
+    FAVAE_CHECK_ARG((size_t)da * dbp <= ATB_STATIC_DOUBLES,
+                    "favae_fa_atb_static: da * (db + ones) = %zu exceeds the static scratch of %zu doubles; use favae_fa_atb with a "
+                    "caller-owned scratch", (size_t)da * dbp, ATB_STATIC_DOUBLES);
+    int dev = 0;
+    FAVAE_HIP(hipGetDevice(&dev));
+    FAVAE_CHECK_ARG(dev >= 0 && dev < 64, "favae_fa_atb_static: device index %d", dev);
+    if (!g_atb_static_ptr[dev]) {   // once per device, with that device current (no allocation: the array came with the code object)
+        double* p = nullptr;
+        FAVAE_HIP(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_atb_static)));
+        FAVAE_CHECK_ARG(p != nullptr, "favae_fa_atb_static: no device address for the static scratch");
+        g_atb_static_ptr[dev] = p;
+    }
+    return atb_run(A, lda, da, B, ldb, db, ones, N, C, g_atb_static_ptr[dev], ATB_STATIC_DOUBLES, "favae_fa_atb_static", stream);
+}
+
 extern "C" int favae_fa_rows_gemm(const double* X, int ldx, int d, const double* P, int ldp, int K, const double* c, double alpha,
                                   const double* base, int ldbase, double beta, double* out, int ldo, long long N, int accumulate,
                                   void* stream) {

@@ -311,6 +311,14 @@ int favae_vae_debug_ptr(favae_vae* h, int which, int layer, void** out);
 long long favae_fa_atb_scratch_doubles(long long N, int da, int db, int ones);
 int favae_fa_atb(const double* A, int lda, int da, const double* B, int ldb, int db, int ones, long long N, double* C,
                  double* scratch, size_t scratch_doubles, void* stream);
+/* favae_fa_atb for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  The slab partials go to a file-scope device array of
+ * the library (32 MB = 4 194 304 doubles per GPU, held until the process ends) instead of a caller-supplied scratch; the
+ * call allocates nothing and returns an error if da * (db + ones) > 4 194 304 (any N fits below that).  Same kernels and
+ * geometry as favae_fa_atb: bit-identical results.  Every call on a GPU shares that GPU's array: calls that overlap on
+ * one GPU (two streams) race; calls on one stream, or on different GPUs, do not. */
+int favae_fa_atb_static(const double* A, int lda, int da, const double* B, int ldb, int db, int ones, long long N, double* C,
+                        void* stream);
 /* out[N][K] = alpha (X[N][d] P[d][K] + c[K]) + beta base[N][K]; accumulate=1: out += alpha X P.  K <= 208.
  * q.Z['mean'] (cA/favae.py:986-987), the predictive means (:996-997), the FA prior Z W^T + b
  * (cA/celeba_deepvanilla_vae.py:209) and Z W^T + b of the multilabel update (cA/favae.py:1212). */
