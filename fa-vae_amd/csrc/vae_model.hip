@@ -3,8 +3,13 @@
 // igemm.hip and vae_kernels.hip.  The host passes device buffers (PyTorch tensors used as memory); this file owns
 // the layer table, the carve-up of the workspace and the launch order.  Nothing here allocates device memory.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
+#include <cstring>
+#include <functional>
 #include <new>
+#include <thread>
 #include <vector>
 #include "common.h"
 #include "favae_hip.h"
@@ -67,6 +72,68 @@ void build_layers(int z, int ch, Layer* L, long long* nparam, long long* nbuf, l
     *nparam = po; *nbuf = bo; *nshadow = so;
 }
 
+// ---- enqueue worker -----------------------------------------------------------------------------------------------
+// A batch-64 step is ~100 launches plus ~45 event records / cross-stream waits.  Measured on the MI355X box
+// (tools/micro/host_cost.hip): a launch costs the host 2.4 us, an event record 0.9 us, but a record + wait pair that makes
+// another stream depend on it 7.4 us and the first launch behind such a wait several more: the side-stream traffic
+// (weight gradients, layer-wise Adam, weight re-layout, the next batch's gather) is 3/4 of the 0.8 ms of host time per step.
+// During an epoch those calls are issued by a second host thread: the caller's thread keeps only the main chain (launches
+// + one event record per fork, ~0.2 ms per step), hands each side-stream job over as a closure, and meets the worker once
+// per step (the events the main stream waits on must have been recorded, and each event's previous use consumed).
+// (A captured hipGraph of the step was measured instead and is slower on this ROCm: 1.27 vs 1.08 ms per step, and
+// hipGraphLaunch returns only when the previous launch of the graph has drained.)
+struct Worker {
+    static constexpr unsigned CAP = 512;
+    std::function<int()> q[CAP];
+    std::atomic<unsigned> head{0}, tail{0};   // tail: next slot the caller fills; head: next slot the worker runs
+    std::atomic<int> rc{0};
+    std::atomic<bool> stop{false};
+    char err[512] = "";
+    std::thread th;
+    double busy = 0.0, drain_wait = 0.0; long long jobs = 0;   // FAVAE_VERBOSE accounting
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void run(int dev) {
+        (void)hipSetDevice(dev);
+        for (;;) {
+            const unsigned h = head.load(std::memory_order_relaxed);
+            if (h == tail.load(std::memory_order_acquire)) {
+                if (stop.load(std::memory_order_acquire)) return;
+                __builtin_ia32_pause();
+                continue;
+            }
+            std::function<int()>& f = q[h % CAP];
+            if (rc.load(std::memory_order_relaxed) == 0) {   // after a failure the remaining jobs are dropped
+                const double t0 = now();
+                const int r = f();
+                busy += now() - t0; ++jobs;
+                if (r != FAVAE_OK) { strncpy(err, favae_last_error(), sizeof(err) - 1); rc.store(r, std::memory_order_release); }
+            }
+            f = nullptr;
+            head.store(h + 1, std::memory_order_release);
+        }
+    }
+    void start(int dev) { th = std::thread([this, dev] { run(dev); }); }
+    void push(std::function<int()> f) {
+        const unsigned t = tail.load(std::memory_order_relaxed);
+        while (t - head.load(std::memory_order_acquire) >= CAP) __builtin_ia32_pause();
+        q[t % CAP] = std::move(f);
+        tail.store(t + 1, std::memory_order_release);
+    }
+    // everything handed over so far has been issued (its HIP calls have returned)
+    int drain() {
+        const unsigned t = tail.load(std::memory_order_relaxed);
+        const double t0 = now();
+        while (head.load(std::memory_order_acquire) != t) __builtin_ia32_pause();
+        drain_wait += now() - t0;
+        const int r = rc.load(std::memory_order_acquire);
+        if (r != FAVAE_OK) favae_set_error("%s", err);
+        return r;
+    }
+    void finish() { stop.store(true, std::memory_order_release); if (th.joinable()) th.join(); }
+};
+
+struct Ada { bool on; float lr, b1, b2, eps; long long step; bool epoch; };
+
 struct Vae {
     int z, ch, Bmax, dtype, esz;
     Layer L[NL];
@@ -95,7 +162,9 @@ struct Vae {
     // single-device epochs: Adam + weight re-layout of a layer follow its weight gradient on the side stream
     // epoch: steps of one epoch run back to back: Adam clears the gradients it has consumed (no memset per step) and the
     // main stream joins the side stream only when the next step's forward pass is about to read the weights
-    struct { bool on; float lr, b1, b2, eps; long long step; int pending; bool epoch; } ada;
+    Ada ada;
+    int pending;   // layer whose optimiser step waits for the next fork event (-1: none); touched by side-stream jobs only
+    Worker* wk;    // non-null while an epoch hands its side-stream calls to the enqueue worker
     int stream_score;   // ensure_streams: 21 = all three side streams run beside the main stream and each other
     bool join_pending; bool dg_all;
     bool dp_epoch;   // steps of favae_vae_train_epoch_dp: gradients cleared by the bucket-wise Adam, joins through the communication stream
@@ -109,8 +178,13 @@ struct Vae {
     char* fold0_buf[2]; int fold_sel; hipEvent_t ev_batch, ev_fold; bool inline_tail;   // see train_stages
     char* fold0; size_t fold0_bytes; hipEvent_t ev_x; bool x_folded;   // encoder.0's folded input batch, gathered on the side stream while the forward pass runs
     char* fold; size_t fold_bytes;   // [pixels][32] tap-folded operand of the two image-side weight gradients (side stream only)   // second batch buffer: the next gather must not overwrite what wgrad(encoder.0) still reads
-    const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(SH + L[l].wc_off * esz); }
-    const void* Wt(int l) const { return (const void*)(SH + L[l].wt_off * esz); }
+    // The dtype copies / transposes of the weights exist twice.  In single-device epochs the optimiser step of a layer follows
+    // its weight gradient on the same stream and writes the re-laid weights into the half the running step does not read
+    // (the input-gradient GEMM of that layer may still be queued on the main stream): no event between the two streams for it.
+    size_t sh_half; int sh_sel; bool merged; int upd_half;
+    char* shp(int half) const { return SH + (size_t)half * sh_half; }
+    const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(shp(sh_sel) + L[l].wc_off * esz); }
+    const void* Wt(int l) const { return (const void*)(shp(sh_sel) + L[l].wt_off * esz); }
     long long rows(int l, int B) const { return (long long)B * L[l].Hout * L[l].Hout; }
 };
 
@@ -357,59 +431,77 @@ int bn_bwd(Vae& v, int l, int B, void* st) {
 }
 
 int wgrad_launch(Vae& v, int l, const void* in, int B, void* st);
+int adam_layer(Vae& v, int l, void* st, const Ada& a, int half);
+
+// a job of side-stream calls: handed to the enqueue worker during a threaded epoch, run in place otherwise
+template <class F> int side_do(Vae& v, F&& f) {
+    if (v.wk) { v.wk->push(std::function<int()>(std::forward<F>(f))); return FAVAE_OK; }
+    return f();
+}
 
 // weight gradient of layer l given draw[l] (just produced on the main stream) and the layer input; with overlap on it
 // is queued on the side stream behind an event, so the main stream continues with the input gradient at once
-int adam_layer(Vae& v, int l, void* st);
-
 int wgrad(Vae& v, int l, const void* in, int B, void* st) {
     if (!v.overlap) return wgrad_launch(v, l, in, B, st);
     FAVAE_HIP(hipEventRecord(v.ev_fork[l], (hipStream_t)st));
-    FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_fork[l], 0));
-    RC(wgrad_launch(v, l, in, B, (void*)v.side));
-    if (!v.ada.on) return FAVAE_OK;
-    FAVAE_HIP(hipEventRecord(v.ev_wg[l], v.side));
-    // Layer-wise optimiser step on the third stream.  The layer whose weight gradient was queued before this one may be
-    // updated once that gradient is complete (ev_wg) and its input-gradient GEMM, the last reader of its weight shadows,
-    // has run: this fork event was recorded after that GEMM was queued on the main stream.  Its BN / bias gradients
-    // were complete before its own fork.
-    if (v.ada.pending >= 0) {
-        FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_fork[l], 0));
-        FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[v.ada.pending], 0));
-        RC(adam_layer(v, v.ada.pending, (void*)v.side2));
-        v.ada.pending = -1;
-    }
-    if (!(v.dg_all || l == 1)) v.ada.pending = l;
-    return FAVAE_OK;
+    const Ada ada = v.ada;
+    const bool merged = v.merged; const int half = v.upd_half;
+    return side_do(v, [&v, l, in, B, ada, merged, half]() -> int {
+        FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_fork[l], 0));
+        RC(wgrad_launch(v, l, in, B, (void*)v.side));
+        if (!ada.on) return FAVAE_OK;
+        if (merged && (v.fuse & 0x20000u)) return adam_layer(v, l, (void*)v.side, ada, half);   // same stream: no further event
+        FAVAE_HIP(hipEventRecord(v.ev_wg[l], v.side));
+        if (merged) {   // optimiser stream, one wait: the update writes the shadow half no queued GEMM reads
+            FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[l], 0));
+            return adam_layer(v, l, (void*)v.side2, ada, half);
+        }
+        // Layer-wise optimiser step on the third stream.  The layer whose weight gradient was queued before this one may be
+        // updated once that gradient is complete (ev_wg) and its input-gradient GEMM, the last reader of its weight shadows,
+        // has run: this fork event was recorded after that GEMM was queued on the main stream.  Its BN / bias gradients
+        // were complete before its own fork.
+        if (v.pending >= 0) {
+            FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_fork[l], 0));
+            FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[v.pending], 0));
+            RC(adam_layer(v, v.pending, (void*)v.side2, ada, half));
+            v.pending = -1;
+        }
+        if (!(v.dg_all || l == 1)) v.pending = l;
+        return FAVAE_OK;
+    });
 }
 
 // after the input-gradient GEMM of layer l is queued on the main stream: layers that do not wait for the next fork
 // (encoder.1, whose update would otherwise sit between the last weight gradient and the end of the step) get an event
 int after_dgrad(Vae& v, int l, void* st) {
-    if (!(v.overlap && v.ada.on && (v.dg_all || l == 1))) return FAVAE_OK;
+    if (!(v.overlap && v.ada.on && !v.merged && (v.dg_all || l == 1))) return FAVAE_OK;
     FAVAE_HIP(hipEventRecord(v.ev_dg[l], (hipStream_t)st));
-    FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_dg[l], 0));
-    FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[l], 0));
-    return adam_layer(v, l, (void*)v.side2);
+    const Ada ada = v.ada;
+    const int half = v.upd_half;
+    return side_do(v, [&v, l, ada, half]() -> int {
+        FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_dg[l], 0));
+        FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[l], 0));
+        return adam_layer(v, l, (void*)v.side2, ada, half);
+    });
 }
 
 // Adam over the arena slice of layer l (weights, bias, BN affine) + its dtype shadows
-int adam_layer(Vae& v, int l, void* st) {
+int adam_layer(Vae& v, int l, void* st, const Ada& a, int half) {
     const Layer& L = v.L[l];
     const long long lo = L.w_off, hi = l + 1 < NL ? v.L[l + 1].w_off : v.nparam;
-    void* c = L.wc_off >= 0 ? v.SH + L.wc_off * v.esz : nullptr;
-    void* t = L.wt_off >= 0 ? v.SH + L.wt_off * v.esz : nullptr;
+    void* c = L.wc_off >= 0 ? v.shp(half) + L.wc_off * v.esz : nullptr;
+    void* t = L.wt_off >= 0 ? v.shp(half) + L.wt_off * v.esz : nullptr;
     if ((v.fuse & 128u) && L.Cin % 4 == 0 && L.Cout % 4 == 0 && (c || t))   // one pass: update + dtype copy + transpose (never L_OUT: Cout <= 4)
-        return favae_adam_wprep(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, L.Cout, L.taps, L.Cin, c, t, v.ada.epoch ? 1 : 0,
-                                v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, v.dtype, st);
+        return favae_adam_wprep(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, L.Cout, L.taps, L.Cin, c, t, a.epoch ? 1 : 0,
+                                a.lr, a.b1, a.b2, a.eps, a.step, v.dtype, st);
     if (c && !t && v.dtype == FAVAE_BF16 && !(v.fuse & 0x800u) && ((long long)L.Cout * L.taps * L.Cin) % 4 == 0)
         // encoder.0 (no input gradient, so no transposed shadow): its update ends the step, the bf16 copy rides along
-        return favae_adam_step_copy(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step,
-                                    v.ada.epoch ? 1 : 0, c, (long long)L.Cout * L.taps * L.Cin, st);
-    if (v.ada.epoch) RC(favae_adam_step_clear(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, st));
-    else RC(favae_adam_step(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, v.ada.lr, v.ada.b1, v.ada.b2, v.ada.eps, v.ada.step, st));
+        return favae_adam_step_copy(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, a.lr, a.b1, a.b2, a.eps, a.step,
+                                    a.epoch ? 1 : 0, c, (long long)L.Cout * L.taps * L.Cin, st);
+    if (a.epoch) RC(favae_adam_step_clear(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, a.lr, a.b1, a.b2, a.eps, a.step, st));
+    else RC(favae_adam_step(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, a.lr, a.b1, a.b2, a.eps, a.step, st));
     if (c || t) RC(favae_weight_prep(v.P + L.w_off, c, t, L.Cout, L.taps, L.Cin, v.dtype, st));
-    if (l == L_OUT) RC(favae_conv_out_wprep(v.Wf(L_OUT), v.wk_out, v.ch, v.dtype, st));
+    if (l == L_OUT) RC(favae_conv_out_wprep(c ? (const void*)c : (const void*)(v.P + L.w_off), v.wk_out, v.ch, v.dtype, st));
     return FAVAE_OK;
 }
 
@@ -479,7 +571,8 @@ extern "C" long long favae_vae_buffer_count(int z, int channels) {
 extern "C" long long favae_vae_shadow_bytes(int z, int channels, int dtype) {
     Layer L[NL]; long long a, b, c;
     build_layers(z, channels, L, &a, &b, &c, dtype == FAVAE_F32);
-    return c * (dtype == FAVAE_F32 ? 4 : 2) + 256;
+    const long long half = (c * (dtype == FAVAE_F32 ? 4 : 2) + 255) & ~255LL;
+    return 2 * half + 256;   // two halves, see Vae::shp
 }
 extern "C" long long favae_vae_workspace_bytes(int z, int channels, int batch_max, int dtype) {
     Vae v{};
@@ -518,9 +611,11 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.P = params; v.G = grads; v.M = adam_m; v.V = adam_v; v.BUF = bn_buffers; v.SH = (char*)shadow;
     size_t need;
     carve(v, (char*)workspace, workspace_bytes, &need);
-    if (need > workspace_bytes || (size_t)v.nshadow * v.esz > shadow_bytes) {
+    v.sh_half = ((size_t)v.nshadow * v.esz + 255) & ~(size_t)255;
+    v.sh_sel = 0; v.merged = false; v.upd_half = 0;
+    if (need > workspace_bytes || 2 * v.sh_half > shadow_bytes) {
         delete h;
-        favae_set_error("favae_vae_create: workspace %zu < %zu or shadow %zu < %zu", workspace_bytes, need, shadow_bytes, (size_t)v.nshadow * v.esz);
+        favae_set_error("favae_vae_create: workspace %zu < %zu or shadow %zu < %zu", workspace_bytes, need, shadow_bytes, 2 * v.sh_half);
         return FAVAE_ERR_ARG;
     }
     const char* e = getenv("FAVAE_SINGLE_STREAM");
@@ -528,7 +623,9 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.side = nullptr;
     v.side2 = nullptr;
     v.side3 = nullptr;
-    v.ada = {false, 0.f, 0.f, 0.f, 0.f, 0, -1, false};
+    v.ada = {false, 0.f, 0.f, 0.f, 0.f, 0, false};
+    v.pending = -1;
+    v.wk = nullptr;
     v.join_pending = false;
     v.dp_epoch = false;
     v.ev_join_ext = nullptr;
@@ -587,8 +684,8 @@ extern "C" int favae_vae_refresh_weights(favae_vae* h, void* st) {
     int n = 0;
     for (int l = 0; l < NL; ++l) {
         const Layer& L = v.L[l];
-        void* c = L.wc_off >= 0 ? v.SH + L.wc_off * v.esz : nullptr;
-        void* t = L.wt_off >= 0 ? v.SH + L.wt_off * v.esz : nullptr;
+        void* c = L.wc_off >= 0 ? v.shp(v.sh_sel) + L.wc_off * v.esz : nullptr;
+        void* t = L.wt_off >= 0 ? v.shp(v.sh_sel) + L.wt_off * v.esz : nullptr;
         if (!c && !t) continue;
         w[n] = v.P + L.w_off; wc[n] = c; wt[n] = t; Co[n] = L.Cout; taps[n] = L.taps; Ci[n] = L.Cin;
         ++n;
@@ -625,23 +722,32 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
         // the tap gather of the NEXT step -- moves to the weight-gradient stream, which is idle at that point.
         v.inline_tail = epoch && !v.dp_epoch && can_fold && !(v.fuse & 0x2000u);
         v.x_folded = false;
+        // single-device epochs: a layer's update follows its weight gradient at once (optimiser stream, one event wait) and
+        // writes the other shadow half (FAVAE_FUSE_MASK bit 0x10000: in place, behind the layer's input-gradient GEMM, i.e.
+        // two more waits per layer; bit 0x20000: on the weight-gradient stream itself, no wait)
+        v.merged = epoch && !v.dp_epoch && v.ada.on && !(v.fuse & 0x10000u);
+        v.upd_half = v.merged ? (v.sh_sel ^ 1) : v.sh_sel;
         if (v.inline_tail) {
             std::swap(v.xf, v.xf_alt); std::swap(v.xt, v.xt_alt);
             v.fold_sel ^= 1;
             v.fold0 = v.fold0_buf[v.fold_sel];   // the previous step's gradient GEMM may still read the other one
-            if (v.join_pending) {
+            const bool jp = v.join_pending;
+            if (!jp) FAVAE_HIP(hipEventRecord(v.ev_x, (hipStream_t)st));
+            float* xf = v.xf; char* xt = v.xt; char* fold0 = v.fold0;
+            RC(side_do(v, [&v, jp, xf, xt, fold0, data_nhwc, idx, B]() -> int {
                 // behind the previous step's last reader of the zero pool (BN backward of encoder.0), not behind its tail
-                FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_fork[0], 0));
-            } else {
-                FAVAE_HIP(hipEventRecord(v.ev_x, (hipStream_t)st));
-                FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_x, 0));
-            }
-            FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, v.side));
-            RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, v.xf, v.xt, v.dtype, (void*)v.side));
-            FAVAE_HIP(hipEventRecord(v.ev_batch, v.side));
-            RC(favae_conv_fold_taps(v.xt, v.fold0, v.fold0_bytes, B, 32, 32, 64, 64, v.ch, 2, 0, v.dtype, (void*)v.side));
-            FAVAE_HIP(hipEventRecord(v.ev_fold, v.side));
+                FAVAE_HIP(hipStreamWaitEvent(v.side, jp ? v.ev_fork[0] : v.ev_x, 0));
+                FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, v.side));
+                RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, xf, xt, v.dtype, (void*)v.side));
+                FAVAE_HIP(hipEventRecord(v.ev_batch, v.side));
+                RC(favae_conv_fold_taps(xt, fold0, v.fold0_bytes, B, 32, 32, 64, 64, v.ch, 2, 0, v.dtype, (void*)v.side));
+                FAVAE_HIP(hipEventRecord(v.ev_fold, v.side));
+                return FAVAE_OK;
+            }));
             v.x_folded = true;
+            // the worker has issued everything of the previous step and the job above: ev_batch / ev_fold / ev_join are
+            // recorded, and every event of the previous step has been consumed before this step records it again
+            if (v.wk) RC(v.wk->drain());
             FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_batch, 0));
         } else {
             if (!epoch) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));
@@ -652,10 +758,14 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
                 // encoder.0's weight gradient ends the step: its tap gather needs the batch only, so it runs now, on the
                 // weight-gradient stream (idle during the forward pass; in order behind the previous step's last reader of fold0)
                 FAVAE_HIP(hipEventRecord(v.ev_x, (hipStream_t)st));
-                FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_x, 0));
-                RC(favae_conv_fold_taps(v.xt, v.fold0, v.fold0_bytes, B, 32, 32, 64, 64, v.ch, 2, 0, v.dtype, (void*)v.side));
+                char* xt = v.xt; char* fold0 = v.fold0;
+                RC(side_do(v, [&v, xt, fold0, B]() -> int {
+                    FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_x, 0));
+                    return favae_conv_fold_taps(xt, fold0, v.fold0_bytes, B, 32, 32, 64, 64, v.ch, 2, 0, v.dtype, (void*)v.side);
+                }));
                 v.x_folded = true;
             }
+            if (v.wk) RC(v.wk->drain());
         }
         if (v.join_pending) {   // the previous step's weight gradients / updates, still running next to the launches above
             RC(wait_join(v, (hipStream_t)st));
@@ -742,30 +852,51 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
         }
     }
     if (stage_hi == N_STAGES && v.overlap && !v.dp_epoch) {   // (data-parallel epochs join through favae_vae_fence)
-        if (v.ada.on) {   // encoder.0: no input gradient reads its shadows
-            if (v.ada.pending >= 0 && v.ada.pending != 0) {
-                FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[v.ada.pending], 0));
-                RC(adam_layer(v, v.ada.pending, (void*)v.side2));
-            }
+        if (v.ada.on && v.merged) {
+            // every update has been queued behind its weight gradient on the weight-gradient stream; encoder.0's (no input
+            // gradient reads its shadows) follows its gradient on the caller's stream when the tail of the step runs there
+            const Ada ada = v.ada;
+            const int half = v.upd_half;
+            if (v.inline_tail) RC(adam_layer(v, 0, st, ada, half));
+            v.join2 = false;
+            // (the optimiser stream has waited for every weight gradient of the weight-gradient stream)
+            RC(side_do(v, [&v]() -> int { FAVAE_HIP(hipEventRecord(v.ev_join, (v.fuse & 0x20000u) ? v.side : v.side2)); return FAVAE_OK; }));
+            v.sh_sel = half;   // the next step reads the half this step's updates wrote
+        } else if (v.ada.on) {   // encoder.0: no input gradient reads its shadows
+            const Ada ada = v.ada;
+            const int half = v.upd_half;
+            RC(side_do(v, [&v, ada, half]() -> int {
+                if (v.pending >= 0 && v.pending != 0) {
+                    FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[v.pending], 0));
+                    RC(adam_layer(v, v.pending, (void*)v.side2, ada, half));
+                }
+                v.pending = -1;
+                return FAVAE_OK;
+            }));
             // encoder.0's update follows its weight gradient on the same stream: it is the last link of the step, and an
             // event hop to the optimiser stream is a few microseconds of step time
             v.join2 = !v.inline_tail && !(v.fuse & 0x1000u);
+            const bool join2 = v.join2;
             if (v.inline_tail) {
-                RC(adam_layer(v, 0, st));
+                RC(adam_layer(v, 0, st, ada, half));
             } else {
-                if (!v.join2) FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[0], 0));
-                RC(adam_layer(v, 0, (void*)(v.join2 ? v.side : v.side2)));
+                RC(side_do(v, [&v, ada, join2, half]() -> int {
+                    if (!join2) FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[0], 0));
+                    return adam_layer(v, 0, (void*)(join2 ? v.side : v.side2), ada, half);
+                }));
             }
-            v.ada.pending = -1;
             // every other weight gradient of the side stream is awaited by the update of its layer on side2
-            FAVAE_HIP(hipEventRecord(v.ev_join, v.side2));
-            if (v.join2) FAVAE_HIP(hipEventRecord(v.ev_join2, v.side));
+            RC(side_do(v, [&v, join2]() -> int {
+                FAVAE_HIP(hipEventRecord(v.ev_join, v.side2));
+                if (join2) FAVAE_HIP(hipEventRecord(v.ev_join2, v.side));
+                return FAVAE_OK;
+            }));
         } else {
             v.join2 = false;
-            FAVAE_HIP(hipEventRecord(v.ev_join, v.side));
+            RC(side_do(v, [&v]() -> int { FAVAE_HIP(hipEventRecord(v.ev_join, v.side)); return FAVAE_OK; }));
         }
         if (epoch) v.join_pending = true;   // favae_vae_train_epoch joins before the next forward pass / at its end
-        else RC(wait_join(v, (hipStream_t)st));
+        else { if (v.wk) RC(v.wk->drain()); RC(wait_join(v, (hipStream_t)st)); }
     }
     return FAVAE_OK;
 }
@@ -833,24 +964,52 @@ extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const
     Vae& v = h->v;
     long long s = 0;
     if (v.overlap) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));   // the steps keep it cleared
-    for (long long o = 0; o < n; o += batch, ++s) {
+    // epochs of more than a few steps hand their side-stream calls to an enqueue worker (see struct Worker)
+    const char* et = getenv("FAVAE_ENQUEUE_THREAD");   // "0": every call from the caller's thread (A/B and debugging)
+    const bool threaded = !(et && et[0] == '0');
+    Worker* wk = nullptr;
+    if (v.overlap && threaded && (n + batch - 1) / batch >= 4) {
+        RC(ensure_streams(v, (hipStream_t)st));
+        int dev = 0;
+        FAVAE_HIP(hipGetDevice(&dev));
+        wk = new (std::nothrow) Worker();
+        if (wk) { wk->start(dev); v.wk = wk; }
+    }
+    int rc = FAVAE_OK;
+    for (long long o = 0; o < n && rc == FAVAE_OK; o += batch, ++s) {
         const int B = (int)std::min<long long>(batch, n - o);
         if (v.overlap) {   // optimiser step layer by layer behind the weight gradients (same arithmetic, see adam_layer)
-            v.ada = {true, lr, 0.9f, 0.999f, 1e-8f, step0 + s + 1, -1, true};
-            const int rc = favae_vae_train_fwdbwd(h, data_nhwc, perm + o, B, eps + o * v.z, prior, tau, beta, var_x, metrics + 2 * s, st);
+            v.ada = {true, lr, 0.9f, 0.999f, 1e-8f, step0 + s + 1, true};
+            rc = favae_vae_train_fwdbwd(h, data_nhwc, perm + o, B, eps + o * v.z, prior, tau, beta, var_x, metrics + 2 * s, st);
             v.ada.on = false;
             v.ada.epoch = false;
-            if (rc != FAVAE_OK || o + batch >= n) {   // last step (or failure): the caller's stream waits for the side stream
-                if (v.join_pending) (void)wait_join(v, (hipStream_t)st);
-                v.join_pending = false;
-            }
-            RC(rc);
         } else {
-            RC(favae_vae_train_fwdbwd(h, data_nhwc, perm + o, B, eps + o * v.z, prior, tau, beta, var_x, metrics + 2 * s, st));
-            RC(favae_vae_adam(h, lr, 0.9f, 0.999f, 1e-8f, step0 + s + 1, st));
+            rc = favae_vae_train_fwdbwd(h, data_nhwc, perm + o, B, eps + o * v.z, prior, tau, beta, var_x, metrics + 2 * s, st);
+            if (rc == FAVAE_OK) rc = favae_vae_adam(h, lr, 0.9f, 0.999f, 1e-8f, step0 + s + 1, st);
         }
     }
-    return FAVAE_OK;
+    if (wk) {   // everything handed over has been issued; the worker ends with the epoch
+        const int wrc = wk->drain();
+        wk->finish();
+        if (getenv("FAVAE_VERBOSE"))
+            fprintf(stderr, "favae: enqueue worker: %lld jobs, %.1f us busy per step; caller waited %.1f us per step for it\n", wk->jobs,
+                    1e6 * wk->busy / (double)s, 1e6 * wk->drain_wait / (double)s);
+        v.wk = nullptr;
+        delete wk;
+        if (rc == FAVAE_OK) rc = wrc;
+    }
+    if (v.overlap && v.join_pending) {   // last step (or failure): the caller's stream waits for the side streams
+        (void)wait_join(v, (hipStream_t)st);
+        v.join_pending = false;
+    }
+    v.pending = -1;
+    v.merged = false;
+    if (v.sh_sel != 0) {   // outside an epoch half 0 is the current one (a second executor may share the shadow buffer)
+        v.sh_sel = 0;
+        const int r2 = favae_vae_refresh_weights(h, st);
+        if (rc == FAVAE_OK) rc = r2;
+    }
+    return rc;
 }
 
 /* Data-parallel epoch (see include/favae_hip.h). */
@@ -892,8 +1051,8 @@ extern "C" int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float
             int k = 0;
             for (int l = bk[b].l0; l <= bk[b].l1; ++l) {
                 const Layer& L = v.L[l];
-                void* cc = L.wc_off >= 0 ? v.SH + L.wc_off * v.esz : nullptr;
-                void* tt = L.wt_off >= 0 ? v.SH + L.wt_off * v.esz : nullptr;
+                void* cc = L.wc_off >= 0 ? v.shp(v.sh_sel) + L.wc_off * v.esz : nullptr;
+                void* tt = L.wt_off >= 0 ? v.shp(v.sh_sel) + L.wt_off * v.esz : nullptr;
                 if (!cc && !tt) continue;
                 w[k] = v.P + L.w_off; wc[k] = cc; wt[k] = tt; Co[k] = L.Cout; taps[k] = L.taps; Ci[k] = L.Cin;
                 ++k;
