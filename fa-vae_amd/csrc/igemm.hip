@@ -160,7 +160,10 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = (blockIdx.x / p.ntn) * BM, n0 = (blockIdx.x % p.ntn) * BN;
-    const int py = TR ? (int)(blockIdx.z >> 1) : 0, px = TR ? (int)(blockIdx.z & 1) : 0;
+    // parity classes in the order 4, 2, 2, 1 taps: the blocks with the longest reduction are dispatched first
+    // (unsplit reductions only: with split-K, measured on MI355X, the light classes first is the faster order)
+    const int zc = TR ? (p.splitk == 1 ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z) : 0;
+    const int py = zc >> 1, px = zc & 1;
     // valid taps of this launch slice
     int nkh, nkw;
     if (TR && p.stride == 2) { nkh = 1 + py; nkw = 1 + px; } else { nkh = p.ks; nkw = p.ks; }
