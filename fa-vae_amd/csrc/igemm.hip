@@ -140,8 +140,13 @@ struct KcParams {
 // ---------------------------------------------------------------------------------------------------------
 // K-contiguous implicit GEMM (gather / scatter forms)
 // ---------------------------------------------------------------------------------------------------------
-template <class T, int BM, int BN, int WM, int WN, bool TR, bool SLOW>
-__global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
+// KG = 2: the block has two groups of 4 waves; the groups take alternate reduction chunks of the same output tile through LDS
+// stages of their own and are added through LDS at the end (split-K inside the block).  The batch-64 layers are 256-512 tiles
+// of 9-36 chunks on 256 CUs, i.e. one or two 4-wave blocks per CU, and with that few waves nothing of a chunk overlaps
+// (LDS write -> barrier -> LDS read -> MFMA runs serially, ~0.5 us per chunk measured); a second group of waves per tile
+// doubles the waves per SIMD without atomics or more tiles.
+template <class T, int BM, int BN, int WM, int WN, bool TR, bool SLOW, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
     constexpr int VE = 16 / sizeof(T);
     constexpr int VPR = BK / VE;
     constexpr int RS = BK * sizeof(T) + 16;
@@ -155,9 +160,13 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
     constexpr int D = SLOW ? 1 : ((VA + VB) * 4 <= 16 ? 4 : (VA + VB) * 4 <= 32 ? 3 : 2);
     constexpr int STAGE = (BM + BN) * RS;
     constexpr int NBUF = 2 * STAGE <= 65536 ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) char lds[NBUF * STAGE];
+    static_assert(KG == 1 || (BM == 64 && BN == 64 && !SLOW), "two reduction groups: 64x64 tiles only");
+    __shared__ __attribute__((aligned(16))) char lds_all[KG * NBUF * STAGE];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);          // reduction group of this wave
+    const int tid = KG == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 255);   // thread index inside the group
+    const int lane = tid & 63, wave = tid >> 6;
+    char* const lds = lds_all + grp * (NBUF * STAGE);
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = (blockIdx.x / p.ntn) * BM, n0 = (blockIdx.x % p.ntn) * BN;
     // parity classes in the order 4, 2, 2, 1 taps: the blocks with the longest reduction are dispatched first
@@ -279,40 +288,48 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // group g reduces chunks c_begin + g, c_begin + g + KG, ...; every group runs the same number of iterations (barriers)
     uint4 va[D][VA], vb[D][VB];
     unsigned am[D];
+    const int n_it = (max(c_end - c_begin, 0) + KG - 1) / KG;
+    auto chunk_of = [&](int j) { return c_begin + grp + KG * j; };
 #pragma unroll
     for (int d = 0; d < D; ++d)
-        if (c_begin + d < c_end) am[d] = load_chunk(c_begin + d, va[d], vb[d]);
+        if (chunk_of(d) < c_end) am[d] = load_chunk(chunk_of(d), va[d], vb[d]);
     int buf = 0;
-    for (int c = c_begin; c < c_end; c += D) {
+    for (int j0 = 0; j0 < n_it; j0 += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const int cc = c + d;
-            if (cc < c_end) {   // block-uniform
+            const int j = j0 + d;
+            if (j < n_it) {   // block-uniform
+                const bool mine = KG == 1 || chunk_of(j) < c_end;   // group-uniform
                 char* ldsA = lds + buf * STAGE;
                 char* ldsB = ldsA + BM * RS;
+                if (mine) {
 #pragma unroll
-                for (int i = 0; i < VA; ++i)
-                    if (NVA % 256 == 0 || (tid + i * 256) < NVA)
-                        *(uint4*)(ldsA + ((tid + i * 256) / VPR) * RS + vecA * 16) = keep_if((am[d] >> i) & 1u, va[d][i]);
+                    for (int i = 0; i < VA; ++i)
+                        if (NVA % 256 == 0 || (tid + i * 256) < NVA)
+                            *(uint4*)(ldsA + ((tid + i * 256) / VPR) * RS + vecA * 16) = keep_if((am[d] >> i) & 1u, va[d][i]);
 #pragma unroll
-                for (int j = 0; j < VB; ++j)
-                    if (NVB % 256 == 0 || (tid + j * 256) < NVB) *(uint4*)(ldsB + ((tid + j * 256) / VPR) * RS + vecA * 16) = keep_if(b_ok[j], vb[d][j]);
+                    for (int jj = 0; jj < VB; ++jj)
+                        if (NVB % 256 == 0 || (tid + jj * 256) < NVB) *(uint4*)(ldsB + ((tid + jj * 256) / VPR) * RS + vecA * 16) = keep_if(b_ok[jj], vb[d][jj]);
+                }
                 __syncthreads();
-                if (cc + D < c_end) am[d] = load_chunk(cc + D, va[d], vb[d]);  // D chunks ahead of the MFMAs below
+                if (chunk_of(j + D) < c_end) am[d] = load_chunk(chunk_of(j + D), va[d], vb[d]);  // D chunks ahead of the MFMAs below
+                if (mine) {
 #pragma unroll
-                for (int kk = 0; kk < BK / 16; ++kk) {
-                    Frag<T> fa[TM], fb[TN];
-                    const int koff = (kk * 16 + 8 * (lane >> 5)) * (int)sizeof(T);
+                    for (int kk = 0; kk < BK / 16; ++kk) {
+                        Frag<T> fa[TM], fb[TN];
+                        const int koff = (kk * 16 + 8 * (lane >> 5)) * (int)sizeof(T);
 #pragma unroll
-                    for (int a = 0; a < TM; ++a) frag_kc(fa[a], ldsA + (wm * WTM + a * 32 + (lane & 31)) * RS + koff);
+                        for (int a = 0; a < TM; ++a) frag_kc(fa[a], ldsA + (wm * WTM + a * 32 + (lane & 31)) * RS + koff);
 #pragma unroll
-                    for (int b = 0; b < TN; ++b) frag_kc(fb[b], ldsB + (wn * WTN + b * 32 + (lane & 31)) * RS + koff);
+                        for (int b = 0; b < TN; ++b) frag_kc(fb[b], ldsB + (wn * WTN + b * 32 + (lane & 31)) * RS + koff);
 #pragma unroll
-                    for (int a = 0; a < TM; ++a)
+                        for (int a = 0; a < TM; ++a)
 #pragma unroll
-                        for (int b = 0; b < TN; ++b) mma32(acc[a][b], fa[a], fb[b]);
+                            for (int b = 0; b < TN; ++b) mma32(acc[a][b], fa[a], fb[b]);
+                    }
                 }
                 if (NBUF == 1) __syncthreads(); else buf ^= 1;
             }
@@ -328,12 +345,16 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
         if (p.splitk == 1 && (p.Cout & 3) == 0) {
             constexpr int TS = BN + 4;   // floats per LDS row
             static_assert(BM * TS * 4 <= STAGE, "output tile must fit the staging buffer");
-            float* tile = (float*)lds;
+            float* tile = (float*)lds;   // (each reduction group stages its own partial tile)
             __syncthreads();             // every wave is done with the operand stages
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 tile[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TS + wn * 32 + (lane & 31)] = acc[0][0][r];
             __syncthreads();
+            const float* tile0 = (const float*)lds_all;
+            const float* tile1 = (const float*)(lds_all + NBUF * STAGE);   // KG == 2 only
+            const int ftid = (int)threadIdx.x;                             // all 256 * KG threads store the tile
+            constexpr int RPP = 16 * KG, NPASS = BM / RPP;                 // rows per pass, passes
             const int c4 = (tid & 15) * 4, n = n0 + c4;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (add_bias && n < p.Cout) bv = *(const float4*)(p.bias + n);
@@ -342,8 +363,8 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
             float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
             if (red == 2 && n < p.Cout) { mu = *(const float4*)(p.red_mean + n); is = *(const float4*)(p.red_invstd + n); }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = (tid >> 4) + 16 * i, m = m0 + row;
+            for (int i = 0; i < NPASS; ++i) {
+                const int row = (ftid >> 4) + RPP * i, m = m0 + row;
                 if (m >= p.M || n >= p.Cout) continue;
                 size_t opix = (size_t)m;
                 if (TR) {
@@ -351,7 +372,11 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
                     const int nb = m / hw, rem = m - nb * hw, yy = rem / p.WoC, xx = rem - yy * p.WoC;
                     opix = ((size_t)nb * p.Ho + (yy * p.stride + py)) * p.Wo + (xx * p.stride + px);
                 }
-                float4 v = *(const float4*)(tile + row * TS + c4);
+                float4 v = *(const float4*)(tile0 + row * TS + c4);
+                if constexpr (KG == 2) {
+                    const float4 u = *(const float4*)(tile1 + row * TS + c4);
+                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                }
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 if (p.out_bf16) {
                     uint2 u;
@@ -393,7 +418,9 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
             if (red) {
                 // lanes tid, tid^16, tid^32 hold the same 4 columns; then the 4 waves through LDS; 128 atomics per block
                 // into one of red_nbin bins, so that a few dozen blocks at most meet on an address
-                __shared__ double redsm[4 * 2 * 64];
+                static_assert(BM * TS * 4 + 4 * KG * 2 * 64 * 8 <= NBUF * STAGE, "the sums are staged behind group 0's output tile");
+                double* redsm = (double*)(lds_all + BM * TS * 4);   // [4 * KG waves][2][64]
+                const int fwave = ftid >> 6;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     rs[j] += __shfl_xor(rs[j], 16, 64); rs[j] += __shfl_xor(rs[j], 32, 64);
@@ -401,14 +428,17 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
                 }
                 if (lane < 16) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { redsm[(wave * 2 + 0) * 64 + c4 + j] = rs[j]; redsm[(wave * 2 + 1) * 64 + c4 + j] = rq[j]; }
+                    for (int j = 0; j < 4; ++j) { redsm[(fwave * 2 + 0) * 64 + c4 + j] = rs[j]; redsm[(fwave * 2 + 1) * 64 + c4 + j] = rq[j]; }
                 }
                 __syncthreads();
-                if (tid < 128) {
-                    const int qq = tid >> 6, col = tid & 63;
+                if (ftid < 128) {
+                    const int qq = ftid >> 6, col = ftid & 63;
                     if (n0 + col < p.Cout) {
-                        const double t = (redsm[(0 * 2 + qq) * 64 + col] + redsm[(1 * 2 + qq) * 64 + col]) +
-                                         (redsm[(2 * 2 + qq) * 64 + col] + redsm[(3 * 2 + qq) * 64 + col]);
+                        double t = (redsm[(0 * 2 + qq) * 64 + col] + redsm[(1 * 2 + qq) * 64 + col]) +
+                                   (redsm[(2 * 2 + qq) * 64 + col] + redsm[(3 * 2 + qq) * 64 + col]);
+                        if constexpr (KG == 2)
+                            t += (redsm[(4 * 2 + qq) * 64 + col] + redsm[(5 * 2 + qq) * 64 + col]) +
+                                 (redsm[(6 * 2 + qq) * 64 + col] + redsm[(7 * 2 + qq) * 64 + col]);
                         const int bin = (int)((blockIdx.x / p.ntn + blockIdx.z * 5u) % (unsigned)p.red_nbin);
                         unsafeAtomicAdd(p.red_bins + ((size_t)bin * 2 + qq) * p.Cout + n0 + col, t);
                     }
@@ -416,6 +446,18 @@ __global__ __launch_bounds__(256) void igemm_kc(const KcParams p) {
             }
             return;
         }
+    }
+    if constexpr (KG == 2) {
+        float* hand = (float*)(lds_all + NBUF * STAGE);   // [16][256] floats in group 1's stages (both groups are done with them)
+        __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hand[r * 256 + tid] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += hand[r * 256 + tid];
     }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
@@ -601,14 +643,14 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
         }
 }
 
-template <class T, bool TR, bool SLOW, int BM, int BN, int WM, int WN>
+template <class T, bool TR, bool SLOW, int BM, int BN, int WM, int WN, int KG = 1>
 int launch_kc(const KcParams& p, int classes, hipStream_t st) {
     dim3 grid(cdiv(p.M, BM) * p.ntn, p.splitk, classes);
     const int cls = SLOW ? (TR ? 9 : 8) : (TR ? 4 : 0) + (BM == 64 ? 2 : 3);
     // algorithmic work, dense-tap convention: gather form ks*ks taps per output pixel, stride-2 scatter form 9/4
     const double taps = (TR && p.stride == 2) ? 2.25 : (double)(p.ks * p.ks);
     ProfScope prof(cls, 2.0 * p.Nb * p.Ho * p.Wo * (double)p.Cout * taps * p.Cin, st);
-    hipLaunchKernelGGL((igemm_kc<T, BM, BN, WM, WN, TR, SLOW>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_kc<T, BM, BN, WM, WN, TR, SLOW, KG>), grid, dim3(256 * KG), 0, st, p);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }
@@ -642,6 +684,16 @@ int dispatch_kc(KcParams p, int classes, int target_blocks, int* fused, hipStrea
     if constexpr (!TR) {
         if (narrow_n) return launch_kc<T, TR, false, 128, 32, 4, 1>(p, classes, st);
     }
+    // two reduction groups per tile where the grid leaves the CUs with one or two 4-wave blocks and a block's share of
+    // the reduction is long enough to be worth halving (FAVAE_KG: 1 never, 2 always)
+    static const int kg_env = getenv("FAVAE_KG") ? atoi(getenv("FAVAE_KG")) : 0;
+    const int per_block = cdiv(nchunk, p.splitk);
+    // Measured on MI355X (tools/bench_gemm.py): it pays only where the grid is one block per CU and the reduction long
+    // (enc.2 forward, dec.2 input gradient: 256 tiles x 18 chunks, 14.1 -> 11.6 us); with two blocks per CU already
+    // resident the second group only adds its hand-over (12.1 -> 14.1 us).  With every piece of the chunk loop removed
+    // these launches still take ~9 us (launch, first loads, epilogue, drain): the loop itself is 3-5 us of a 12-17 us launch.
+    const bool two = kg_env == 2 || (kg_env == 0 && blocks * p.splitk <= 256 && per_block >= 12);
+    if (two) return launch_kc<T, TR, false, 64, 64, 2, 2, 2>(p, classes, st);
     return launch_kc<T, TR, false, 64, 64, 2, 2>(p, classes, st);
 }
 

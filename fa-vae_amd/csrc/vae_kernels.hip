@@ -476,7 +476,7 @@ __device__ __forceinline__ void own_reduce(double (*val)[4], double* sm /* [NQ][
     __syncthreads();
 }
 
-template <class T>
+template <class T, int MAXP = OWN_MAXP>
 __global__ __launch_bounds__(OWN_THREADS) void bn_fwd_owner(const float* __restrict__ raw, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ act,
                                                             float* __restrict__ mean, float* __restrict__ invstd,
@@ -486,10 +486,10 @@ __global__ __launch_bounds__(OWN_THREADS) void bn_fwd_owner(const float* __restr
     __shared__ float ab[2 * OWN_CT];
     const int tid = threadIdx.x, tl = tid % OWN_TPR, rg = tid / OWN_TPR;
     const int c0 = blockIdx.x * OWN_CT + tl * 4;
-    float x[OWN_MAXP][4];
+    float x[MAXP][4];
     double val[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-    for (int p = 0; p < OWN_MAXP; ++p) {
+    for (int p = 0; p < MAXP; ++p) {
         const int r = rg + p * OWN_RG;
         if (r < R) {
             VecLoad<float, 4>::ld(raw + (size_t)r * C + c0, x[p]);
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(OWN_THREADS) void bn_fwd_owner(const float* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) { a[j] = ab[tl * 4 + j]; b[j] = ab[OWN_CT + tl * 4 + j]; }
 #pragma unroll
-    for (int p = 0; p < OWN_MAXP; ++p) {
+    for (int p = 0; p < MAXP; ++p) {
         const int r = rg + p * OWN_RG;
         if (r < R) {
             float y[4];
@@ -591,6 +591,9 @@ __global__ __launch_bounds__(OWN_THREADS) void bn_bwd_owner(const float* __restr
 }
 
 inline bool owner_applicable(long long R, int C) { return R <= (long long)OWN_RG * OWN_MAXP && C % OWN_CT == 0; }
+// forward only: up to 4096 rows (dec.1 at batch 64) with 16 row groups per thread: one launch instead of statistics + apply
+constexpr int OWN_MAXP_BIG = 4 * OWN_MAXP;
+inline bool owner_fwd_big_applicable(long long R, int C) { return R <= (long long)OWN_RG * OWN_MAXP_BIG && C % OWN_CT == 0; }
 
 template <class T>
 struct ColsumF {
@@ -1494,6 +1497,16 @@ extern "C" int favae_bn_train_fwd(const void* raw, const float* gamma, const flo
         else
             hipLaunchKernelGGL(bn_fwd_owner<bf16_t>, dim3(C / OWN_CT), dim3(OWN_THREADS), 0, ST, rawf, gamma, beta, (bf16_t*)act, mean,
                                invstd, run_mean, run_var, (int)R, C, eps, momentum);
+        FAVAE_LAUNCH_CHECK();
+        return FAVAE_OK;
+    }
+    if (owner_fwd_big_applicable(R, C)) {
+        if (DT_BASE(dtype) == FAVAE_F32)
+            hipLaunchKernelGGL((bn_fwd_owner<float, OWN_MAXP_BIG>), dim3(C / OWN_CT), dim3(OWN_THREADS), 0, ST, rawf, gamma, beta, (float*)act,
+                               mean, invstd, run_mean, run_var, (int)R, C, eps, momentum);
+        else
+            hipLaunchKernelGGL((bn_fwd_owner<bf16_t, OWN_MAXP_BIG>), dim3(C / OWN_CT), dim3(OWN_THREADS), 0, ST, rawf, gamma, beta, (bf16_t*)act,
+                               mean, invstd, run_mean, run_var, (int)R, C, eps, momentum);
         FAVAE_LAUNCH_CHECK();
         return FAVAE_OK;
     }
