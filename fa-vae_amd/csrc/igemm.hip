@@ -135,7 +135,38 @@ struct KcParams {
     const void* red_raw;   // fp32, or bf16 with red_raw_bf16
     const float *red_mean, *red_invstd;
     int red_raw_bf16;
+    // FI kernels: `in` is the fp32 output `raw` [pixels][Cin] of a convolution whose BatchNorm(train) + LeakyReLU has not been
+    // applied; the A operand is lrelu(raw * a[c] + b[c]) rounded to T, formed when a chunk goes to LDS.  a, b come from the
+    // epilogue sums of the producing GEMM (in_bins [in_nbin][2][Cin], red_mode 1); every block derives them in its
+    // prologue (while its first loads are in flight), block (0,0,0) publishes mean / invstd / a|b / running statistics.
+    const double* in_bins; int in_nbin; double in_R; float in_eps, in_mom;
+    const float *in_gamma, *in_beta;
+    float *in_mean, *in_invstd, *in_ab, *in_run_mean, *in_run_var;
 };
+
+// 8 (bf16) or 4 (fp32) channels c0.. of the fused-input operand: BN affine + LeakyReLU(0.01), same expressions and rounding as
+// bn_lrelu_fwd_ab (vae_kernels.hip), so the bytes equal those of the materialised activation
+template <class T> __device__ __forceinline__ uint4 bn_act_vec(const uint4* raw, const float* ab, int c0, int Cin);
+template <> __device__ __forceinline__ uint4 bn_act_vec<float>(const uint4* raw, const float* ab, int c0, int Cin) {
+    const float4 a = *(const float4*)(ab + c0), b = *(const float4*)(ab + Cin + c0);
+    float y0 = fmaf(__uint_as_float(raw[0].x), a.x, b.x), y1 = fmaf(__uint_as_float(raw[0].y), a.y, b.y);
+    float y2 = fmaf(__uint_as_float(raw[0].z), a.z, b.z), y3 = fmaf(__uint_as_float(raw[0].w), a.w, b.w);
+    y0 = y0 > 0.f ? y0 : 0.01f * y0; y1 = y1 > 0.f ? y1 : 0.01f * y1; y2 = y2 > 0.f ? y2 : 0.01f * y2; y3 = y3 > 0.f ? y3 : 0.01f * y3;
+    return make_uint4(__float_as_uint(y0), __float_as_uint(y1), __float_as_uint(y2), __float_as_uint(y3));
+}
+template <> __device__ __forceinline__ uint4 bn_act_vec<bf16_t>(const uint4* raw, const float* ab, int c0, int Cin) {
+    unsigned o[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float4 a = *(const float4*)(ab + c0 + 4 * h), b = *(const float4*)(ab + Cin + c0 + 4 * h);
+        float y0 = fmaf(__uint_as_float(raw[h].x), a.x, b.x), y1 = fmaf(__uint_as_float(raw[h].y), a.y, b.y);
+        float y2 = fmaf(__uint_as_float(raw[h].z), a.z, b.z), y3 = fmaf(__uint_as_float(raw[h].w), a.w, b.w);
+        y0 = y0 > 0.f ? y0 : 0.01f * y0; y1 = y1 > 0.f ? y1 : 0.01f * y1; y2 = y2 > 0.f ? y2 : 0.01f * y2; y3 = y3 > 0.f ? y3 : 0.01f * y3;
+        o[2 * h] = (unsigned)f32_to_bf16(y0) | ((unsigned)f32_to_bf16(y1) << 16);
+        o[2 * h + 1] = (unsigned)f32_to_bf16(y2) | ((unsigned)f32_to_bf16(y3) << 16);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // K-contiguous implicit GEMM (gather / scatter forms)
@@ -145,7 +176,8 @@ struct KcParams {
 // of 9-36 chunks on 256 CUs, i.e. one or two 4-wave blocks per CU, and with that few waves nothing of a chunk overlaps
 // (LDS write -> barrier -> LDS read -> MFMA runs serially, ~0.5 us per chunk measured); a second group of waves per tile
 // doubles the waves per SIMD without atomics or more tiles.
-template <class T, int BM, int BN, int WM, int WN, bool TR, bool SLOW, int KG = 1>
+// FI: fused input (see KcParams::in_bins): BatchNorm + LeakyReLU of the producing layer applied to the A operand on the fly.
+template <class T, int BM, int BN, int WM, int WN, bool TR, bool SLOW, int KG = 1, bool FI = false>
 __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
     constexpr int VE = 16 / sizeof(T);
     constexpr int VPR = BK / VE;
@@ -161,7 +193,10 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
     constexpr int STAGE = (BM + BN) * RS;
     constexpr int NBUF = 2 * STAGE <= 65536 ? 2 : 1;
     static_assert(KG == 1 || (BM == 64 && BN == 64 && !SLOW), "two reduction groups: 64x64 tiles only");
+    static_assert(!FI || (BM == 64 && BN == 64 && !SLOW), "fused input: 64x64 tiles, whole-chunk channel counts");
+    constexpr int VAL = (FI && sizeof(T) == 2) ? 2 : 1;   // 16-byte loads per A vector (fp32 source of a bf16 operand: two)
     __shared__ __attribute__((aligned(16))) char lds_all[KG * NBUF * STAGE];
+    __shared__ __attribute__((aligned(16))) float ab_s[FI ? 512 : 4];   // a[Cin] | b[Cin], Cin <= 256
 
     const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);          // reduction group of this wave
     const int tid = KG == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 255);   // thread index inside the group
@@ -222,7 +257,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
 
     // returns the validity bits of the A vectors (bit i); the zeroing select is applied when the registers are written
     // to LDS, D chunks later, so that nothing waits on a load at issue time
-    auto load_chunk = [&](int c, uint4 (&va)[VA], uint4 (&vb)[VB]) -> unsigned {
+    auto load_chunk = [&](int c, uint4 (&va)[VA * VAL], uint4 (&vb)[VB]) -> unsigned {
         unsigned mask = 0;
         if (!SLOW) {
             // branch-free: out-of-image taps and tail rows read a clamped (valid) address
@@ -236,7 +271,13 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
                 iy = min(max(iy, 0), p.Hi - 1);
                 ix = min(max(ix, 0), p.Wi - 1);
                 const size_t off = ((size_t)(a_n[i] * p.Hi + iy) * p.Wi + ix) * p.Cin + ci0 + vecA * VE;
-                va[i] = *(const uint4*)((const T*)p.in + off);
+                if constexpr (FI) {
+                    const float* src = (const float*)p.in + off;
+                    va[i * VAL] = *(const uint4*)src;
+                    if constexpr (VAL == 2) va[i * VAL + 1] = *(const uint4*)(src + 4);
+                } else {
+                    va[i] = *(const uint4*)((const T*)p.in + off);
+                }
                 mask |= ok ? (1u << i) : 0u;
             }
 #pragma unroll
@@ -289,13 +330,48 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     // group g reduces chunks c_begin + g, c_begin + g + KG, ...; every group runs the same number of iterations (barriers)
-    uint4 va[D][VA], vb[D][VB];
+    uint4 va[D][VA * VAL], vb[D][VB];
     unsigned am[D];
     const int n_it = (max(c_end - c_begin, 0) + KG - 1) / KG;
     auto chunk_of = [&](int j) { return c_begin + grp + KG * j; };
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (chunk_of(d) < c_end) am[d] = load_chunk(chunk_of(d), va[d], vb[d]);
+    if constexpr (FI) {
+        // scale / shift of the producing layer's BatchNorm from its epilogue sums, while the loads above are in flight
+        double* tot = (double*)lds_all;   // [2 * Cin] <= 4 KB of the (not yet written) operand stages
+        const int ftid = (int)threadIdx.x, C2 = 2 * p.Cin;
+        for (int qc = ftid; qc < C2; qc += 256 * KG) {
+            double t = 0.0;
+#pragma unroll 8
+            for (int b = 0; b < p.in_nbin; ++b) t += p.in_bins[(size_t)b * C2 + qc];
+            tot[qc] = t;
+        }
+        __syncthreads();
+        const bool publish = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+        for (int c = ftid; c < p.Cin; c += 256 * KG) {
+            const double m = tot[c] / p.in_R;
+            double var = tot[p.Cin + c] / p.in_R - m * m;
+            if (var < 0) var = 0;
+            const float is = (float)(1.0 / sqrt(var + (double)p.in_eps));
+            const float a = is * p.in_gamma[c];
+            const float b = p.in_beta[c] - (float)m * a;
+            ab_s[c] = a;
+            ab_s[p.Cin + c] = b;
+            if (publish) {
+                p.in_mean[c] = (float)m;
+                p.in_invstd[c] = is;
+                p.in_ab[c] = a;
+                p.in_ab[p.Cin + c] = b;
+                if (p.in_run_mean) {
+                    const double unb = p.in_R > 1 ? var * p.in_R / (p.in_R - 1) : var;
+                    p.in_run_mean[c] = (1.f - p.in_mom) * p.in_run_mean[c] + p.in_mom * (float)m;
+                    p.in_run_var[c] = (1.f - p.in_mom) * p.in_run_var[c] + p.in_mom * (float)unb;
+                }
+            }
+        }
+        __syncthreads();
+    }
     int buf = 0;
     for (int j0 = 0; j0 < n_it; j0 += D) {
 #pragma unroll
@@ -306,10 +382,16 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
                 char* ldsA = lds + buf * STAGE;
                 char* ldsB = ldsA + BM * RS;
                 if (mine) {
+                    int cfi = 0;   // first channel of this thread's A vectors in the chunk (fused input only)
+                    if constexpr (FI) { const int cc = chunk_of(j); cfi = (cc - (cc / cpt) * cpt) * BK + vecA * VE; }
 #pragma unroll
                     for (int i = 0; i < VA; ++i)
-                        if (NVA % 256 == 0 || (tid + i * 256) < NVA)
-                            *(uint4*)(ldsA + ((tid + i * 256) / VPR) * RS + vecA * 16) = keep_if((am[d] >> i) & 1u, va[d][i]);
+                        if (NVA % 256 == 0 || (tid + i * 256) < NVA) {
+                            uint4 v;
+                            if constexpr (FI) v = bn_act_vec<T>(&va[d][i * VAL], ab_s, cfi, p.Cin);
+                            else v = va[d][i];
+                            *(uint4*)(ldsA + ((tid + i * 256) / VPR) * RS + vecA * 16) = keep_if((am[d] >> i) & 1u, v);
+                        }
 #pragma unroll
                     for (int jj = 0; jj < VB; ++jj)
                         if (NVB % 256 == 0 || (tid + jj * 256) < NVB) *(uint4*)(ldsB + ((tid + jj * 256) / VPR) * RS + vecA * 16) = keep_if(b_ok[jj], vb[d][jj]);
@@ -643,14 +725,14 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
         }
 }
 
-template <class T, bool TR, bool SLOW, int BM, int BN, int WM, int WN, int KG = 1>
+template <class T, bool TR, bool SLOW, int BM, int BN, int WM, int WN, int KG = 1, bool FI = false>
 int launch_kc(const KcParams& p, int classes, hipStream_t st) {
     dim3 grid(cdiv(p.M, BM) * p.ntn, p.splitk, classes);
     const int cls = SLOW ? (TR ? 9 : 8) : (TR ? 4 : 0) + (BM == 64 ? 2 : 3);
     // algorithmic work, dense-tap convention: gather form ks*ks taps per output pixel, stride-2 scatter form 9/4
     const double taps = (TR && p.stride == 2) ? 2.25 : (double)(p.ks * p.ks);
     ProfScope prof(cls, 2.0 * p.Nb * p.Ho * p.Wo * (double)p.Cout * taps * p.Cin, st);
-    hipLaunchKernelGGL((igemm_kc<T, BM, BN, WM, WN, TR, SLOW, KG>), grid, dim3(256 * KG), 0, st, p);
+    hipLaunchKernelGGL((igemm_kc<T, BM, BN, WM, WN, TR, SLOW, KG, FI>), grid, dim3(256 * KG), 0, st, p);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }
@@ -662,7 +744,7 @@ int dispatch_kc(KcParams p, int classes, int target_blocks, int* fused, hipStrea
     // on every layer of the step (sweep on MI355X), because the fp32 atomic traffic of split-K grows with the tile
     // area while these grids already cover the 256 CUs.  128x32 serves the few-output-channel gather layers.
     bool narrow_n = !slow && p.Cout <= 32 && !TR;
-    if (!slow && !TR && g_force_kc_tile >= 0) narrow_n = g_force_kc_tile == 1;
+    if (!slow && !TR && g_force_kc_tile >= 0 && !p.in_bins) narrow_n = g_force_kc_tile == 1;
     const int BM = narrow_n ? 128 : 64, BN = narrow_n ? 32 : 64;
     p.ntn = cdiv(p.Cout, BN);
     // split the reduction when the tile grid alone cannot fill 256 CUs
@@ -693,6 +775,10 @@ int dispatch_kc(KcParams p, int classes, int target_blocks, int* fused, hipStrea
     // resident the second group only adds its hand-over (12.1 -> 14.1 us).  With every piece of the chunk loop removed
     // these launches still take ~9 us (launch, first loads, epilogue, drain): the loop itself is 3-5 us of a 12-17 us launch.
     const bool two = kg_env == 2 || (kg_env == 0 && blocks * p.splitk <= 256 && per_block >= 12);
+    if (p.in_bins) {   // fused input (checked by the caller: whole-chunk channel count <= 256, 64x64 tile)
+        if (two) return launch_kc<T, TR, false, 64, 64, 2, 2, 2, true>(p, classes, st);
+        return launch_kc<T, TR, false, 64, 64, 2, 2, 1, true>(p, classes, st);
+    }
     if (two) return launch_kc<T, TR, false, 64, 64, 2, 2, 2>(p, classes, st);
     return launch_kc<T, TR, false, 64, 64, 2, 2>(p, classes, st);
 }
@@ -725,10 +811,11 @@ int dispatch_pm(PmParams p, hipStream_t st) {
 
 namespace {
 struct RedArgs { double* bins; int nbin, mode; const void* act; const void* raw; const float *mean, *invstd; int* fused; int raw_bf16; };
+struct InBn { const double* bins; int nbin; double R; float eps, mom; const float *gamma, *beta; float *mean, *invstd, *ab, *run_mean, *run_var; };
 
 int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cin, int Ho,
                     int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk, int dtype, const RedArgs& red,
-                    void* stream) {
+                    void* stream, const InBn* ib = nullptr) {
     FAVAE_CHECK_ARG(in && w && out, "favae_conv_igemm: null pointer");
     FAVAE_CHECK_ARG(Nb > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Ho > 0 && Wo > 0 && Cout > 0, "favae_conv_igemm: bad shape");
     FAVAE_CHECK_ARG((ks == 1 && pad == 0) || (ks == 3 && pad == 1), "favae_conv_igemm: ks/pad must be 1/0 or 3/1");
@@ -748,7 +835,7 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
     hipStream_t st = (hipStream_t)stream;
     if (red.fused) *red.fused = 0;
     // one thread per output pixel pays off once the pixel count fills the chip several times over (the decoder side)
-    if (g_force_kc_tile < 0 && (long long)Nb * Ho * Wo >= 131072 && thin_in_applicable(Cin, Cout, ks, stride, scatter)) {
+    if (!ib && g_force_kc_tile < 0 && (long long)Nb * Ho * Wo >= 131072 && thin_in_applicable(Cin, Cout, ks, stride, scatter)) {
         ProfScope prof(14, 2.0 * Nb * Ho * Wo * (double)Cout * 9 * Cin, (hipStream_t)stream);
         ThinRed tr{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
         if (red.bins && red.mode == 2 && !out_bf16 && !red.raw_bf16) {   // the statistics form (mode 1) is not needed on this path
@@ -763,6 +850,15 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
     p.ks = ks; p.stride = stride; p.pad = pad; p.ldw = ks * ks * Cin; p.splitk = splitk; p.out_bf16 = out_bf16;
     p.red_bins = red.bins; p.red_nbin = red.nbin; p.red_mode = red.mode; p.red_act = red.act; p.red_raw = red.raw;
     p.red_mean = red.mean; p.red_invstd = red.invstd; p.red_raw_bf16 = red.raw_bf16;
+    p.in_bins = nullptr; p.in_nbin = 0; p.in_R = 1.0; p.in_eps = 0.f; p.in_mom = 0.f; p.in_gamma = p.in_beta = nullptr;
+    p.in_mean = p.in_invstd = p.in_ab = p.in_run_mean = p.in_run_var = nullptr;
+    if (ib) {
+        FAVAE_CHECK_ARG(Cin % BK == 0 && Cin <= 256 && Cout > 32, "favae_conv_igemm_bn_in: Cin must be 64, 128, 192 or 256 and Cout > 32");
+        FAVAE_CHECK_ARG(((uintptr_t)in % 16) == 0, "favae_conv_igemm_bn_in: 16-byte alignment");
+        p.in_bins = ib->bins; p.in_nbin = ib->nbin; p.in_R = ib->R; p.in_eps = ib->eps; p.in_mom = ib->mom; p.in_gamma = ib->gamma;
+        p.in_beta = ib->beta; p.in_mean = ib->mean; p.in_invstd = ib->invstd; p.in_ab = ib->ab; p.in_run_mean = ib->run_mean;
+        p.in_run_var = ib->run_var;
+    }
     int classes = 1;
     if (scatter && stride == 2) { classes = 4; p.HoC = Ho / 2; p.WoC = Wo / 2; }
     else { p.HoC = Ho; p.WoC = Wo; }
@@ -792,6 +888,20 @@ extern "C" int favae_conv_igemm_red(const void* in, const void* w, const float* 
     FAVAE_CHECK_ARG(!(raw_bf16 && (dtype & 0xF) != FAVAE_BF16), "favae_conv_igemm_red: FAVAE_RAW_BF16 needs FAVAE_BF16");
     const RedArgs red{bins, nbins, mode, act, raw, mean, invstd, fused, raw_bf16};
     return conv_igemm_impl(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype & ~FAVAE_RAW_BF16, red, stream);
+}
+
+extern "C" int favae_conv_igemm_bn_in(const void* in_raw, const double* in_bins, int in_nbins, const float* in_gamma,
+                                      const float* in_beta, float in_eps, float in_momentum, float* in_mean, float* in_invstd,
+                                      float* in_ab, float* in_run_mean, float* in_run_var, const void* w, const float* bias, float* out,
+                                      int Nb, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ks, int stride, int pad,
+                                      int scatter, int splitk, int dtype, double* bins, int nbins, int* fused, void* stream) {
+    FAVAE_CHECK_ARG(in_raw && in_bins && in_gamma && in_beta && in_mean && in_invstd && in_ab && in_nbins >= 1 && in_nbins <= 256,
+                    "favae_conv_igemm_bn_in: input BatchNorm arguments");
+    FAVAE_CHECK_ARG(!(bins && !(fused && nbins >= 1 && nbins <= 256)), "favae_conv_igemm_bn_in: bins / fused / nbins");
+    const InBn ib{in_bins, in_nbins, (double)Nb * Hi * Wi, in_eps, in_momentum, in_gamma, in_beta, in_mean, in_invstd, in_ab, in_run_mean,
+                  in_run_var};
+    const RedArgs red{bins, nbins, 1, nullptr, nullptr, nullptr, nullptr, bins ? fused : nullptr, 0};
+    return conv_igemm_impl(in_raw, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype, red, stream, &ib);
 }
 
 extern "C" int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const void* cols, int Cc, int cols_large,

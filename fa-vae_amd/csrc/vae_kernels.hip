@@ -282,6 +282,22 @@ __global__ __launch_bounds__(256) void bn_lrelu_fwd(const RT* __restrict__ raw, 
     }
 }
 
+// The same with the affine form given (ab = a[C] | b[C], published by the fused-input GEMM, igemm.hip): explicit fmaf so that
+// the stored activation equals what that GEMM formed on the fly, bit for bit.
+template <class T>
+__global__ __launch_bounds__(256) void bn_lrelu_fwd_ab(const float* __restrict__ raw, const float* __restrict__ ab, T* __restrict__ act,
+                                                       size_t nvec, int C) {
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    const int c = (int)((i0 * 4) % C);
+    const float4 a = *(const float4*)(ab + c), b = *(const float4*)(ab + C + c);
+#pragma unroll 4
+    for (size_t i = i0; i < nvec; i += stride) {
+        const float4 x = *(const float4*)(raw + i * 4);
+        const float y0 = fmaf(x.x, a.x, b.x), y1 = fmaf(x.y, a.y, b.y), y2 = fmaf(x.z, a.z, b.z), y3 = fmaf(x.w, a.w, b.w);
+        store4<T>(act + i * 4, lrelu(y0), lrelu(y1), lrelu(y2), lrelu(y3));
+    }
+}
+
 // Per-block prologue of the kernels that consume epilogue sums (igemm.hip, KcParams::red_bins): add the nbin bins of the
 // 2*C per-channel sums; tot[q*C + c] is valid after the call.  Needs 2*C <= 512 and 2*C | 256 or 256 | 2*C.
 __device__ __forceinline__ void bins_total(const double* __restrict__ bins, int nbin, int C, double* sm /*[256]*/, double* tot /*[512]*/) {
@@ -1473,6 +1489,21 @@ extern "C" int favae_bn_lrelu_fwd(const void* raw, const float* mean, const floa
         hipLaunchKernelGGL((bn_lrelu_fwd<bf16_t, bf16_t>), dim3((unsigned)grid), dim3(256), 0, ST, (const bf16_t*)raw, mean, invstd, gamma, beta, (bf16_t*)act, nvec, C, apply_act);
     else
         hipLaunchKernelGGL((bn_lrelu_fwd<bf16_t, float>), dim3((unsigned)grid), dim3(256), 0, ST, (const float*)raw, mean, invstd, gamma, beta, (bf16_t*)act, nvec, C, apply_act);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_bn_lrelu_fwd_ab(const float* raw, const float* ab, void* act, long long R, int C, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(raw && ab && act && R > 0 && C > 0 && C % 4 == 0, "favae_bn_lrelu_fwd_ab: bad argument");
+    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_bn_lrelu_fwd_ab: dtype");
+    const size_t nvec = (size_t)R * C / 4;
+    int c4 = C / 4, gg = c4, t = 256;
+    while (t) { const int r = gg % t; gg = t; t = r; }
+    const int mult = c4 / gg;   // the grid stride must be a multiple of C: a thread keeps its 4 channels
+    long long grid = (long long)std::min<size_t>(1024, (nvec + 255) / 256);
+    grid = std::max<long long>(mult, grid / mult * mult);
+    if (dtype == FAVAE_F32) hipLaunchKernelGGL(bn_lrelu_fwd_ab<float>, dim3((unsigned)grid), dim3(256), 0, ST, raw, ab, (float*)act, nvec, C);
+    else hipLaunchKernelGGL(bn_lrelu_fwd_ab<bf16_t>, dim3((unsigned)grid), dim3(256), 0, ST, raw, ab, (bf16_t*)act, nvec, C);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

@@ -128,3 +128,29 @@ def conv_wgrad_prefolded(rows, cols, dw, Rst, Cst, splitk=0):
     check(_lib.favae_conv_wgrad_prefolded(ptr(rows), _i(rows.shape[1]), _i(Rst), ptr(cols), _i(cols.shape[1]), _i(Cst), ptr(dw),
                                           ctypes.c_longlong(rows.shape[0]), _i(splitk), _i(dtype_code(rows)), stream_ptr()))
     return dw
+
+
+def conv_igemm_bn_in(raw_in, in_bins, gamma, beta, w, bias, out, ks, stride, pad, scatter, eps=1e-5, momentum=0.1, run_mean=None,
+                     run_var=None, bins=None, splitk=0):
+    """favae_conv_igemm_bn_in: conv whose input is the fp32 conv output raw_in BEFORE its BatchNorm(train) + LeakyReLU; returns
+    (mean, invstd, ab, fused) of the input layer (ab = a | b of the affine form; bn_lrelu_fwd_ab materialises the activation)."""
+    Nb, Hi, Wi, Cin = raw_in.shape
+    _, Ho, Wo, Cout = out.shape
+    assert raw_in.dtype == torch.float32 and in_bins.dtype == torch.float64 and in_bins.shape[1:] == (2, Cin)
+    mean = torch.empty(Cin, dtype=torch.float32, device=raw_in.device)
+    invstd = torch.empty_like(mean)
+    ab = torch.empty(2 * Cin, dtype=torch.float32, device=raw_in.device)
+    fused = ctypes.c_int(0)
+    _f = ctypes.c_float
+    check(_lib.favae_conv_igemm_bn_in(ptr(raw_in), ptr(in_bins), _i(in_bins.shape[0]), ptr(gamma), ptr(beta), _f(eps), _f(momentum),
+                                      ptr(mean), ptr(invstd), ptr(ab), ptr(run_mean), ptr(run_var), ptr(w), ptr(bias), ptr(out),
+                                      _i(Nb), _i(Hi), _i(Wi), _i(Cin), _i(Ho), _i(Wo), _i(Cout), _i(ks), _i(stride), _i(pad),
+                                      _i(scatter), _i(splitk), _i(dtype_code(w)), ptr(bins), _i(0 if bins is None else bins.shape[0]),
+                                      ctypes.byref(fused), stream_ptr()))
+    return mean, invstd, ab, bool(fused.value)
+
+
+def bn_lrelu_fwd_ab(raw, ab, act):
+    R, C = raw.numel() // raw.shape[-1], raw.shape[-1]
+    check(_lib.favae_bn_lrelu_fwd_ab(ptr(raw), ptr(ab), ptr(act), ctypes.c_longlong(R), _i(C), _i(dtype_code(act)), stream_ptr()))
+    return act

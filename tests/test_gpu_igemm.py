@@ -239,6 +239,68 @@ def test_epilogue_sums_feed_batchnorm_forward(dt, tol, kind, Nb, Cin, Cout, H):
     assert_close(rvd.cpu(), 0.9 + 0.1 * bv * R / (R - 1), 1e-6)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind,Nb,C0,C1,C2,H,splitk", [("conv", 16, 3, 64, 128, 32, 0),      # enc.0 -> enc.1
+                                                      ("conv", 64, 64, 128, 256, 16, 0),    # enc.1 -> enc.2: 256 tiles x 18 chunks, two reduction groups
+                                                      ("conv", 64, 128, 256, 512, 8, 0),    # enc.2 -> enc.3: split reduction
+                                                      ("convT", 16, 256, 128, 64, 8, 0),    # dec.2 -> dec.3
+                                                      ("convT", 5, 128, 64, 64, 16, 0),     # dec.3 -> final_layer.0, ragged tiles
+                                                      ("conv", 3, 64, 128, 64, 8, 1)])
+def test_batchnorm_and_leakyrelu_applied_in_the_consumer_load(dt, kind, Nb, C0, C1, C2, H, splitk):
+    """Conv -> BatchNorm(train) -> LeakyReLU -> Conv without a launch between the convolutions (favae_conv_igemm_bn_in): the
+    second convolution reads the first one's fp32 output and forms the activation in its operand load.  Against the three-launch
+    chain (favae_conv_igemm_red mode 1, favae_bn_train_fwd_bins, favae_conv_igemm): same statistics (1e-6: the bins are added in
+    another order), same running statistics, output within 1e-5 (fp32) / 2e-3 (bf16: an activation may round the other way
+    where a differs in its last bit) and favae_bn_lrelu_fwd_ab reproduces the materialised activation."""
+    import ctypes
+    lib = _lib()
+    g = torch.Generator().manual_seed(11 * C1 + Nb)
+    x = q(torch.randn(Nb, C0, H, H, generator=g), dt)
+    w1 = q(torch.randn(C1, C0, 3, 3, generator=g) * 0.2, dt)
+    b1 = torch.randn(C1, generator=g)
+    gam, bet = (torch.rand(C1, generator=g) + 0.5).cuda(), torch.randn(C1, generator=g).cuda()
+    H1 = H // 2
+    w1d = w1.permute(0, 2, 3, 1).reshape(C1, 9, C0).contiguous().to(dt).cuda()
+    raw1 = torch.empty(Nb, H1, H1, C1, device="cuda")
+    bins = torch.zeros(8, 2, C1, dtype=torch.float64, device="cuda")
+    assert lib.conv_igemm_red(nhwc(x).to(dt).cuda(), w1d, b1.cuda(), raw1, 3, 2, 1, 0, bins, 1, splitk=1)
+    scatter = int(kind == "convT")
+    H2 = H1 * 2 if scatter else H1 // 2
+    w2 = q(torch.randn(C2, C1, 3, 3, generator=g) * 0.1, dt)
+    w2d = w2.permute(0, 2, 3, 1).reshape(C2, 9, C1).contiguous().to(dt).cuda()      # [Cout][tap][Cin] in both forms
+    b2 = torch.randn(C2, generator=g).cuda()
+    # three launches
+    act = torch.empty(Nb, H1, H1, C1, dtype=dt, device="cuda")
+    mean0, inv0 = torch.empty(C1, device="cuda"), torch.empty(C1, device="cuda")
+    rm0, rv0 = torch.zeros(C1, device="cuda"), torch.ones(C1, device="cuda")
+    i_, f_, ll_ = ctypes.c_int, ctypes.c_float, ctypes.c_longlong
+    lib.check(lib.raw().favae_bn_train_fwd_bins(lib.ptr(raw1), lib.ptr(bins), i_(8), lib.ptr(gam), lib.ptr(bet), lib.ptr(act),
+                                                lib.ptr(mean0), lib.ptr(inv0), lib.ptr(rm0), lib.ptr(rv0), ll_(Nb * H1 * H1), i_(C1),
+                                                f_(1e-5), f_(0.1), i_(lib.dtype_code(act)), lib.stream_ptr()))
+    ref = torch.empty(Nb, H2, H2, C2, device="cuda")
+    lib.conv_igemm(act, w2d, b2, ref, 3, 2, 1, scatter, splitk)
+    # one launch
+    out = torch.empty_like(ref)
+    rm1, rv1 = torch.zeros(C1, device="cuda"), torch.ones(C1, device="cuda")
+    bins2 = torch.zeros(8, 2, C2, dtype=torch.float64, device="cuda")
+    mean1, inv1, ab, took2 = lib.conv_igemm_bn_in(raw1, bins, gam, bet, w2d, b2, out, 3, 2, 1, scatter, run_mean=rm1, run_var=rv1,
+                                                  bins=bins2, splitk=splitk)
+    torch.cuda.synchronize()
+    assert_close(mean1.cpu(), mean0.cpu(), 1e-6)
+    assert_close(inv1.cpu(), inv0.cpu(), 1e-6)
+    assert_close(rm1.cpu(), rm0.cpu(), 1e-6)
+    assert_close(rv1.cpu(), rv0.cpu(), 1e-6)
+    assert_close(out.cpu(), ref.cpu(), 1e-5 if dt == torch.float32 else 2e-3)
+    act2 = lib.bn_lrelu_fwd_ab(raw1, ab, torch.empty_like(act))
+    same = (act2 == act).float().mean().item()
+    assert same > 0.999, same                                     # (identical unless a / b differ in the last bit)
+    assert_close(act2.float().cpu(), act.float().cpu(), 1e-5 if dt == torch.float32 else 1e-2)
+    if took2:   # statistics of the second convolution from the same launch
+        r = out.reshape(-1, C2).double()
+        assert_close(bins2.sum(0)[0].cpu(), r.sum(0).cpu(), 1e-6)
+        assert_close(bins2.sum(0)[1].cpu(), (r * r).sum(0).cpu(), 1e-6)
+
+
 @pytest.mark.parametrize("dt,tol", DT)
 @pytest.mark.parametrize("kind,Nb,Cin,Cout,H", [("conv", 64, 64, 128, 32), ("convT", 32, 128, 64, 32)])
 def test_epilogue_sums_feed_batchnorm_backward(dt, tol, kind, Nb, Cin, Cout, H):
