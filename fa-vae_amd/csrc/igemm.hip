@@ -20,6 +20,7 @@
 #include "favae_hip.h"
 #include "smallconv.h"
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -136,12 +137,15 @@ struct KcParams {
     const float *red_mean, *red_invstd;
     int red_raw_bf16;
     // FI kernels: `in` is the fp32 output `raw` [pixels][Cin] of a convolution whose BatchNorm(train) + LeakyReLU has not been
-    // applied; the A operand is lrelu(raw * a[c] + b[c]) rounded to T, formed when a chunk goes to LDS.  a, b come from the
-    // epilogue sums of the producing GEMM (in_bins [in_nbin][2][Cin], red_mode 1); every block derives them in its
-    // prologue (while its first loads are in flight), block (0,0,0) publishes mean / invstd / a|b / running statistics.
-    const double* in_bins; int in_nbin; double in_R; float in_eps, in_mom;
-    const float *in_gamma, *in_beta;
-    float *in_mean, *in_invstd, *in_ab, *in_run_mean, *in_run_var;
+    // applied; the A operand is lrelu(raw * a[c] + b[c]) rounded to T, formed when a chunk goes to LDS.  in_ab = a[Cin] | b[Cin]
+    // as published by the producing GEMM (fin_* below).
+    const float* in_ab;
+    // red_mode 1 with fin_ab != NULL: the block that takes the last ticket of the launch adds the bins and publishes the
+    // BatchNorm(train) quantities of THIS layer: mean, invstd, a = invstd * gamma, b = beta - mean * a, running statistics.
+    const float *fin_gamma, *fin_beta;
+    float *fin_mean, *fin_invstd, *fin_ab, *fin_run_mean, *fin_run_var;
+    double fin_R; float fin_eps, fin_mom;
+    unsigned* fin_ticket;
 };
 
 // 8 (bf16) or 4 (fp32) channels c0.. of the fused-input operand: BN affine + LeakyReLU(0.01), same expressions and rounding as
@@ -338,38 +342,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
     for (int d = 0; d < D; ++d)
         if (chunk_of(d) < c_end) am[d] = load_chunk(chunk_of(d), va[d], vb[d]);
     if constexpr (FI) {
-        // scale / shift of the producing layer's BatchNorm from its epilogue sums, while the loads above are in flight
-        double* tot = (double*)lds_all;   // [2 * Cin] <= 4 KB of the (not yet written) operand stages
-        const int ftid = (int)threadIdx.x, C2 = 2 * p.Cin;
-        for (int qc = ftid; qc < C2; qc += 256 * KG) {
-            double t = 0.0;
-#pragma unroll 8
-            for (int b = 0; b < p.in_nbin; ++b) t += p.in_bins[(size_t)b * C2 + qc];
-            tot[qc] = t;
-        }
-        __syncthreads();
-        const bool publish = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
-        for (int c = ftid; c < p.Cin; c += 256 * KG) {
-            const double m = tot[c] / p.in_R;
-            double var = tot[p.Cin + c] / p.in_R - m * m;
-            if (var < 0) var = 0;
-            const float is = (float)(1.0 / sqrt(var + (double)p.in_eps));
-            const float a = is * p.in_gamma[c];
-            const float b = p.in_beta[c] - (float)m * a;
-            ab_s[c] = a;
-            ab_s[p.Cin + c] = b;
-            if (publish) {
-                p.in_mean[c] = (float)m;
-                p.in_invstd[c] = is;
-                p.in_ab[c] = a;
-                p.in_ab[p.Cin + c] = b;
-                if (p.in_run_mean) {
-                    const double unb = p.in_R > 1 ? var * p.in_R / (p.in_R - 1) : var;
-                    p.in_run_mean[c] = (1.f - p.in_mom) * p.in_run_mean[c] + p.in_mom * (float)m;
-                    p.in_run_var[c] = (1.f - p.in_mom) * p.in_run_var[c] + p.in_mom * (float)unb;
-                }
-            }
-        }
+        for (int i = (int)threadIdx.x; i < 2 * p.Cin; i += 256 * KG) ab_s[i] = p.in_ab[i];
         __syncthreads();
     }
     int buf = 0;
@@ -523,6 +496,70 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
                                  (redsm[(6 * 2 + qq) * 64 + col] + redsm[(7 * 2 + qq) * 64 + col]);
                         const int bin = (int)((blockIdx.x / p.ntn + blockIdx.z * 5u) % (unsigned)p.red_nbin);
                         unsafeAtomicAdd(p.red_bins + ((size_t)bin * 2 + qq) * p.Cout + n0 + col, t);
+                    }
+                }
+                if (red == 1 && p.fin_ab) {   // block-uniform
+                    // the last block of the launch turns the sums into the layer's BatchNorm quantities, so that the consumer
+                    // (favae_conv_igemm_bn_in) needs 2 * Cout floats instead of the bins
+                    __shared__ int is_last;
+                    wait_vm_writes();          // this thread's atomics have been performed
+                    __syncthreads();
+                    if (ftid == 0)
+                        is_last = __hip_atomic_fetch_add(p.fin_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.z - 1;
+                    __syncthreads();
+                    if (is_last) {
+                        // 2 * Cout sums x nbin bins, read with agent-scope loads (other blocks' atomics), 8 in flight per thread:
+                        // thread = (sum index qc, part of the bins); the parts meet in LDS (the staging area of the sums above)
+                        constexpr int NT = 256 * KG;
+                        const int C2 = 2 * p.Cout, parts = C2 >= NT ? 1 : NT / C2;
+                        double* part_sm = redsm;   // [parts][C2] <= NT doubles (C2 < NT) -- all reads of redsm are behind the barrier above
+                        double* tot = part_sm + NT;   // [C2] for C2 <= 512: behind the parts (LDS: BM*TS*4 + (NT + 512) * 8 <= NBUF * STAGE)
+                        static_assert(BM * TS * 4 + (256 * KG + 512) * 8 <= NBUF * STAGE, "finalisation scratch behind the output tile");
+                        for (int q0 = 0; q0 < C2; q0 += NT) {
+                            const int qc = C2 >= NT ? q0 + ftid : ftid % C2, part = C2 >= NT ? 0 : ftid / C2;
+                            double t = 0.0;
+                            if (qc < C2 && part < parts) {
+                                for (int b0 = part; b0 < p.red_nbin; b0 += 8 * parts) {
+                                    double x[8];
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) {
+                                        const int b = b0 + u * parts;
+                                        x[u] = b < p.red_nbin ? __hip_atomic_load(p.red_bins + (size_t)b * C2 + qc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                                    }
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) t += x[u];
+                                }
+                            }
+                            if (C2 >= NT) { if (qc < C2) tot[qc] = t; }
+                            else {
+                                part_sm[ftid] = t;
+                                __syncthreads();
+                                if (ftid < C2) {
+                                    double u = 0.0;
+                                    for (int k = 0; k < parts; ++k) u += part_sm[k * C2 + ftid];
+                                    tot[ftid] = u;
+                                }
+                            }
+                        }
+                        __syncthreads();
+                        for (int c = ftid; c < p.Cout; c += NT) {
+                            const double s0 = tot[c], s1 = tot[p.Cout + c];
+                            const double m = s0 / p.fin_R;
+                            double var = s1 / p.fin_R - m * m;
+                            if (var < 0) var = 0;
+                            const float is = (float)(1.0 / sqrt(var + (double)p.fin_eps));
+                            const float a = is * p.fin_gamma[c];
+                            p.fin_mean[c] = (float)m;
+                            p.fin_invstd[c] = is;
+                            p.fin_ab[c] = a;
+                            p.fin_ab[p.Cout + c] = p.fin_beta[c] - (float)m * a;
+                            if (p.fin_run_mean) {
+                                const double unb = p.fin_R > 1 ? var * p.fin_R / (p.fin_R - 1) : var;
+                                p.fin_run_mean[c] = (1.f - p.fin_mom) * p.fin_run_mean[c] + p.fin_mom * (float)m;
+                                p.fin_run_var[c] = (1.f - p.fin_mom) * p.fin_run_var[c] + p.fin_mom * (float)unb;
+                            }
+                        }
+                        if (ftid == 0) __hip_atomic_store(p.fin_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
@@ -744,7 +781,7 @@ int dispatch_kc(KcParams p, int classes, int target_blocks, int* fused, hipStrea
     // on every layer of the step (sweep on MI355X), because the fp32 atomic traffic of split-K grows with the tile
     // area while these grids already cover the 256 CUs.  128x32 serves the few-output-channel gather layers.
     bool narrow_n = !slow && p.Cout <= 32 && !TR;
-    if (!slow && !TR && g_force_kc_tile >= 0 && !p.in_bins) narrow_n = g_force_kc_tile == 1;
+    if (!slow && !TR && g_force_kc_tile >= 0 && !p.in_ab) narrow_n = g_force_kc_tile == 1;
     const int BM = narrow_n ? 128 : 64, BN = narrow_n ? 32 : 64;
     p.ntn = cdiv(p.Cout, BN);
     // split the reduction when the tile grid alone cannot fill 256 CUs
@@ -775,7 +812,7 @@ int dispatch_kc(KcParams p, int classes, int target_blocks, int* fused, hipStrea
     // resident the second group only adds its hand-over (12.1 -> 14.1 us).  With every piece of the chunk loop removed
     // these launches still take ~9 us (launch, first loads, epilogue, drain): the loop itself is 3-5 us of a 12-17 us launch.
     const bool two = kg_env == 2 || (kg_env == 0 && blocks * p.splitk <= 256 && per_block >= 12);
-    if (p.in_bins) {   // fused input (checked by the caller: whole-chunk channel count <= 256, 64x64 tile)
+    if (p.in_ab) {   // fused input (checked by the caller: whole-chunk channel count <= 256, 64x64 tile)
         if (two) return launch_kc<T, TR, false, 64, 64, 2, 2, 2, true>(p, classes, st);
         return launch_kc<T, TR, false, 64, 64, 2, 2, 1, true>(p, classes, st);
     }
@@ -809,13 +846,28 @@ int dispatch_pm(PmParams p, hipStream_t st) {
 
 }  // namespace
 
+#define RC_(x) do { int rc_ = (x); if (rc_ != FAVAE_OK) return rc_; } while (0)
 namespace {
 struct RedArgs { double* bins; int nbin, mode; const void* act; const void* raw; const float *mean, *invstd; int* fused; int raw_bf16; };
-struct InBn { const double* bins; int nbin; double R; float eps, mom; const float *gamma, *beta; float *mean, *invstd, *ab, *run_mean, *run_var; };
+struct Fin { const float *gamma, *beta; float *mean, *invstd, *ab, *run_mean, *run_var; float eps, mom; };
+
+// a ticket per launch that finalises BatchNorm statistics: slots of a zero-initialised device array handed out in rotation
+// (a launch leaves its slot at zero); launches that overlap in time must not share a slot, 256 in flight is far beyond a step
+__device__ unsigned g_fin_tickets[256];
+int fin_ticket(unsigned** out) {
+    static unsigned* per_device[64] = {nullptr};
+    static std::atomic<unsigned> next{0};
+    int dev = 0;
+    FAVAE_HIP(hipGetDevice(&dev));
+    FAVAE_CHECK_ARG(dev >= 0 && dev < 64, "favae_conv_igemm: device index %d", dev);
+    if (!per_device[dev]) FAVAE_HIP(hipGetSymbolAddress((void**)&per_device[dev], HIP_SYMBOL(g_fin_tickets)));
+    *out = per_device[dev] + (next.fetch_add(1u) & 255u);
+    return FAVAE_OK;
+}
 
 int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cin, int Ho,
                     int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk, int dtype, const RedArgs& red,
-                    void* stream, const InBn* ib = nullptr) {
+                    void* stream, const float* in_ab = nullptr, const Fin* fin = nullptr) {
     FAVAE_CHECK_ARG(in && w && out, "favae_conv_igemm: null pointer");
     FAVAE_CHECK_ARG(Nb > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Ho > 0 && Wo > 0 && Cout > 0, "favae_conv_igemm: bad shape");
     FAVAE_CHECK_ARG((ks == 1 && pad == 0) || (ks == 3 && pad == 1), "favae_conv_igemm: ks/pad must be 1/0 or 3/1");
@@ -835,7 +887,7 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
     hipStream_t st = (hipStream_t)stream;
     if (red.fused) *red.fused = 0;
     // one thread per output pixel pays off once the pixel count fills the chip several times over (the decoder side)
-    if (!ib && g_force_kc_tile < 0 && (long long)Nb * Ho * Wo >= 131072 && thin_in_applicable(Cin, Cout, ks, stride, scatter)) {
+    if (!in_ab && g_force_kc_tile < 0 && (long long)Nb * Ho * Wo >= 131072 && thin_in_applicable(Cin, Cout, ks, stride, scatter)) {
         ProfScope prof(14, 2.0 * Nb * Ho * Wo * (double)Cout * 9 * Cin, (hipStream_t)stream);
         ThinRed tr{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
         if (red.bins && red.mode == 2 && !out_bf16 && !red.raw_bf16) {   // the statistics form (mode 1) is not needed on this path
@@ -850,14 +902,17 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
     p.ks = ks; p.stride = stride; p.pad = pad; p.ldw = ks * ks * Cin; p.splitk = splitk; p.out_bf16 = out_bf16;
     p.red_bins = red.bins; p.red_nbin = red.nbin; p.red_mode = red.mode; p.red_act = red.act; p.red_raw = red.raw;
     p.red_mean = red.mean; p.red_invstd = red.invstd; p.red_raw_bf16 = red.raw_bf16;
-    p.in_bins = nullptr; p.in_nbin = 0; p.in_R = 1.0; p.in_eps = 0.f; p.in_mom = 0.f; p.in_gamma = p.in_beta = nullptr;
-    p.in_mean = p.in_invstd = p.in_ab = p.in_run_mean = p.in_run_var = nullptr;
-    if (ib) {
+    p.in_ab = in_ab;
+    if (in_ab) {
         FAVAE_CHECK_ARG(Cin % BK == 0 && Cin <= 256 && Cout > 32, "favae_conv_igemm_bn_in: Cin must be 64, 128, 192 or 256 and Cout > 32");
-        FAVAE_CHECK_ARG(((uintptr_t)in % 16) == 0, "favae_conv_igemm_bn_in: 16-byte alignment");
-        p.in_bins = ib->bins; p.in_nbin = ib->nbin; p.in_R = ib->R; p.in_eps = ib->eps; p.in_mom = ib->mom; p.in_gamma = ib->gamma;
-        p.in_beta = ib->beta; p.in_mean = ib->mean; p.in_invstd = ib->invstd; p.in_ab = ib->ab; p.in_run_mean = ib->run_mean;
-        p.in_run_var = ib->run_var;
+        FAVAE_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)in_ab % 16) == 0, "favae_conv_igemm_bn_in: 16-byte alignment");
+    }
+    p.fin_gamma = p.fin_beta = nullptr; p.fin_mean = p.fin_invstd = p.fin_ab = p.fin_run_mean = p.fin_run_var = nullptr;
+    p.fin_R = 1.0; p.fin_eps = p.fin_mom = 0.f; p.fin_ticket = nullptr;
+    if (fin && red.bins && red.mode == 1) {
+        p.fin_gamma = fin->gamma; p.fin_beta = fin->beta; p.fin_mean = fin->mean; p.fin_invstd = fin->invstd; p.fin_ab = fin->ab;
+        p.fin_run_mean = fin->run_mean; p.fin_run_var = fin->run_var; p.fin_R = (double)Nb * Ho * Wo; p.fin_eps = fin->eps; p.fin_mom = fin->mom;
+        RC_(fin_ticket(&p.fin_ticket));
     }
     int classes = 1;
     if (scatter && stride == 2) { classes = 4; p.HoC = Ho / 2; p.WoC = Wo / 2; }
@@ -890,18 +945,18 @@ extern "C" int favae_conv_igemm_red(const void* in, const void* w, const float* 
     return conv_igemm_impl(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype & ~FAVAE_RAW_BF16, red, stream);
 }
 
-extern "C" int favae_conv_igemm_bn_in(const void* in_raw, const double* in_bins, int in_nbins, const float* in_gamma,
-                                      const float* in_beta, float in_eps, float in_momentum, float* in_mean, float* in_invstd,
-                                      float* in_ab, float* in_run_mean, float* in_run_var, const void* w, const float* bias, float* out,
-                                      int Nb, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ks, int stride, int pad,
-                                      int scatter, int splitk, int dtype, double* bins, int nbins, int* fused, void* stream) {
-    FAVAE_CHECK_ARG(in_raw && in_bins && in_gamma && in_beta && in_mean && in_invstd && in_ab && in_nbins >= 1 && in_nbins <= 256,
-                    "favae_conv_igemm_bn_in: input BatchNorm arguments");
-    FAVAE_CHECK_ARG(!(bins && !(fused && nbins >= 1 && nbins <= 256)), "favae_conv_igemm_bn_in: bins / fused / nbins");
-    const InBn ib{in_bins, in_nbins, (double)Nb * Hi * Wi, in_eps, in_momentum, in_gamma, in_beta, in_mean, in_invstd, in_ab, in_run_mean,
-                  in_run_var};
+extern "C" int favae_conv_igemm_bn(const void* in, const float* in_ab, const void* w, const float* bias, float* out, int Nb, int Hi,
+                                   int Wi, int Cin, int Ho, int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk,
+                                   int dtype, double* bins, int nbins, const float* gamma, const float* beta, float eps,
+                                   float momentum, float* mean, float* invstd, float* ab, float* run_mean, float* run_var, int* fused,
+                                   void* stream) {
+    FAVAE_CHECK_ARG(!(bins && !(fused && nbins >= 1 && nbins <= 256)), "favae_conv_igemm_bn: bins / fused / nbins");
+    FAVAE_CHECK_ARG(!(ab && !(bins && gamma && beta && mean && invstd)), "favae_conv_igemm_bn: ab needs bins, gamma, beta, mean, invstd");
+    const Fin fin{gamma, beta, mean, invstd, ab, run_mean, run_var, eps, momentum};
     const RedArgs red{bins, nbins, 1, nullptr, nullptr, nullptr, nullptr, bins ? fused : nullptr, 0};
-    return conv_igemm_impl(in_raw, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype, red, stream, &ib);
+    if (fused) *fused = 0;
+    return conv_igemm_impl(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype, red, stream, in_ab,
+                           ab ? &fin : nullptr);
 }
 
 extern "C" int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const void* cols, int Cc, int cols_large,

@@ -182,6 +182,10 @@ struct Vae {
     // its weight gradient on the same stream and writes the re-laid weights into the half the running step does not read
     // (the input-gradient GEMM of that layer may still be queued on the main stream): no event between the two streams for it.
     size_t sh_half; int sh_sel; bool merged; int upd_half;
+    // BatchNorm + LeakyReLU of a layer applied in the operand load of the next convolution (favae_conv_igemm_bn_in): the main
+    // chain has no launch between the two GEMMs; the activation the backward pass reads (weight gradient of the next layer,
+    // LeakyReLU slopes) is materialised on the weight-gradient stream, which is idle during the forward pass
+    float* ab[NL]; bool act_deferred[NL]; bool bn_published[NL]; bool fi_on; int fi_pend[NL], fi_npend, fi_flushes; hipEvent_t ev_fi[2], ev_acts; bool acts_wait;
     char* shp(int half) const { return SH + (size_t)half * sh_half; }
     const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(shp(sh_sel) + L[l].wc_off * esz); }
     const void* Wt(int l) const { return (const void*)(shp(sh_sel) + L[l].wt_off * esz); }
@@ -249,6 +253,7 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
         v.draw[l] = (char*)c.take(n * v.esz);
         v.mean[l] = (float*)c.take((size_t)v.L[l].Cout * 4);
         v.invstd[l] = (float*)c.take((size_t)v.L[l].Cout * 4);
+        v.ab[l] = (float*)c.take((size_t)v.L[l].Cout * 8);
     }
     const size_t img = (size_t)B * 64 * 64 * v.ch;
     v.xf = (float*)c.take(img * 4);
@@ -347,12 +352,32 @@ int ensure_streams(Vae& v, hipStream_t main) {
     return FAVAE_OK;
 }
 
-int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false) {
+template <class F> int side_do(Vae& v, F&& f);   // (defined with the enqueue worker's users below)
+
+// fi >= 0: the input is raw[fi], the output of layer fi before its BatchNorm + LeakyReLU, applied in the operand load
+int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false, int fi = -1) {
     const Layer& L = v.L[l];
     const float* bias = v.P + L.b_off;
     const int sk = (pooled && v.raw_pooled[l]) ? -1 : 0;
     const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_OUT_BF16 : 0);
     v.stats_fused[l] = false;
+    v.bn_published[l] = false;
+    const bool publish = pooled && v.fi_on && (v.fuse & 1u) && v.sbins[l] && L.kind != LINEAR && L.bn && !v.raw_bf[l];
+    if (fi >= 0 || publish) {
+        // fused chain: the launch publishes this layer's BatchNorm quantities from its epilogue sums (where the shape runs
+        // unsplit) and / or reads its input through the BatchNorm + LeakyReLU of layer fi
+        const bool own = (v.fuse & 1u) && v.sbins[l] != nullptr && L.bn;
+        const int scatter = L.kind == CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
+        int fused = 0;
+        RC(favae_conv_igemm_bn(fi >= 0 ? (const void*)v.raw[fi] : in, fi >= 0 ? v.ab[fi] : nullptr, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin,
+                               L.Cin, L.Hout, L.Hout, L.Cout, 3, stride, 1, scatter, sk, dt, own ? v.sbins[l] : nullptr,
+                               own ? bins_for(v.rows(l, B)) : 0, own ? v.P + L.g_off : nullptr, own ? v.P + L.be_off : nullptr, 1e-5f, 0.1f,
+                               v.mean[l], v.invstd[l], publish ? v.ab[l] : nullptr, own ? v.BUF + L.rm_off : nullptr,
+                               own ? v.BUF + L.rv_off : nullptr, &fused, st));
+        v.stats_fused[l] = fused != 0;
+        v.bn_published[l] = fused != 0 && publish;
+        return FAVAE_OK;
+    }
     if (pooled && (v.fuse & 1u) && v.sbins[l] && L.kind != LINEAR) {
         // training step: the zero pool (and with it sbins) was cleared at the start of the step; take the BN statistics
         // in the GEMM epilogue where this shape runs unsplit
@@ -379,6 +404,10 @@ int bn_fwd(Vae& v, int l, int B, bool train, void* st) {
     const Layer& L = v.L[l];
     const long long R = v.rows(l, B);
     const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0);
+    if (train && v.bn_published[l]) {   // the producing GEMM finished the statistics (mean, invstd, running stats, a | b)
+        v.bn_published[l] = v.stats_fused[l] = false;
+        return favae_bn_lrelu_fwd_ab(v.raw[l], v.ab[l], v.act[l], R, L.Cout, v.dtype, st);
+    }
     if (train && v.stats_fused[l]) {
         v.stats_fused[l] = false;
         return favae_bn_train_fwd_bins(v.raw[l], v.sbins[l], bins_for(R), v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l],
@@ -391,14 +420,56 @@ int bn_fwd(Vae& v, int l, int B, bool train, void* st) {
     return favae_bn_lrelu_fwd(v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.P + L.be_off, v.act[l], R, L.Cout, 1, dt, st);
 }
 
-int encoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false) {
-    const void* in = v.xt;
-    for (int l = 0; l < 5; ++l) {
-        RC(conv_fwd(v, l, in, B, st, pooled));
-        RC(bn_fwd(v, l, B, train, st));
+// may layer l's BatchNorm + LeakyReLU be left to the operand load of the next convolution?
+bool fi_ok(const Vae& v, int l, bool train, bool pooled) {
+    if (!(train && pooled && v.fi_on && v.bn_published[l]) || v.raw_bf[l] || (v.fuse & 0x80000u)) return false;   // (0x80000: publish only)
+    const int nl = l + 1;
+    if (nl >= NL || nl == L_FC || nl == L_OUT || v.L[nl].kind == LINEAR) return false;
+    return v.L[l].Cout % 64 == 0 && v.L[l].Cout <= 256 && v.L[nl].Cout > 32;
+}
+
+// the consumers of the pending layers have been queued on `st` (they publish a | b): materialise the activations on the
+// weight-gradient stream
+int fi_flush(Vae& v, int B, void* st) {
+    if (!v.fi_npend) return FAVAE_OK;
+    const int k = v.fi_flushes++ & 1;
+    FAVAE_HIP(hipEventRecord(v.ev_fi[k], (hipStream_t)st));
+    int ls[NL]; const int n = v.fi_npend;
+    for (int i = 0; i < n; ++i) ls[i] = v.fi_pend[i];
+    v.fi_npend = 0;
+    v.acts_wait = true;
+    int l0 = ls[0], l1 = n > 1 ? ls[1] : -1, l2 = n > 2 ? ls[2] : -1, l3 = n > 3 ? ls[3] : -1;
+    return side_do(v, [&v, k, B, l0, l1, l2, l3]() -> int {
+        FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_fi[k], 0));
+        for (int l : {l0, l1, l2, l3})
+            if (l >= 0) RC(favae_bn_lrelu_fwd_ab(v.raw[l], v.ab[l], v.act[l], v.rows(l, B), v.L[l].Cout, v.dtype, (void*)v.side));
+        FAVAE_HIP(hipEventRecord(v.ev_acts, v.side));
+        return FAVAE_OK;
+    });
+}
+
+int conv_bn_chain(Vae& v, int lo, int hi, const void* in, int B, bool train, void* st, bool pooled) {
+    int fi = -1;
+    for (int l = lo; l <= hi; ++l) {
+        RC(conv_fwd(v, l, in, B, st, pooled, fi));
+        if (fi >= 0) v.fi_pend[v.fi_npend++] = fi;       // its consumer is queued
+        fi = -1;
+        if (l < hi && fi_ok(v, l, train, pooled) && v.fi_npend < 3) {
+            fi = l;
+            v.stats_fused[l] = v.bn_published[l] = false;
+            v.act_deferred[l] = true;
+        } else {
+            RC(fi_flush(v, B, st));
+            RC(bn_fwd(v, l, B, train, st));
+        }
         in = v.act[l];
     }
-    return conv_fwd(v, L_FC, in, B, st, pooled);
+    return FAVAE_OK;
+}
+
+int encoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false) {
+    RC(conv_bn_chain(v, 0, 4, v.xt, B, train, st, pooled));
+    return conv_fwd(v, L_FC, v.act[4], B, st, pooled);
 }
 
 int decoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false, bool skip_out = false, bool skip_in = false) {
@@ -407,13 +478,8 @@ int decoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false, bool s
         RC(favae_conv_igemm(v.zlat, v.Wf(L_DI), v.P + L.b_off, (float*)v.act[L_DI], B, 1, 1, L.Cin, 1, 1, L.Cout, 1, 1, 0, 0, 0,
                             v.dtype | (v.dtype == FAVAE_BF16 ? FAVAE_OUT_BF16 : 0), st));
     }
-    const void* in = v.act[L_DI];
-    for (int l = 7; l <= 11; ++l) {
-        RC(conv_fwd(v, l, in, B, st, pooled));
-        RC(bn_fwd(v, l, B, train, st));
-        in = v.act[l];
-    }
-    return skip_out ? FAVAE_OK : conv_fwd(v, L_OUT, in, B, st, pooled);
+    RC(conv_bn_chain(v, 7, 11, v.act[L_DI], B, train, st, pooled));
+    return skip_out ? FAVAE_OK : conv_fwd(v, L_OUT, v.act[11], B, st, pooled);
 }
 
 int bn_bwd(Vae& v, int l, int B, void* st) {
@@ -626,6 +692,8 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.ada = {false, 0.f, 0.f, 0.f, 0.f, 0, false};
     v.pending = -1;
     v.wk = nullptr;
+    v.fi_on = false; v.fi_npend = 0; v.fi_flushes = 0; v.acts_wait = false;
+    for (int l = 0; l < NL; ++l) v.act_deferred[l] = v.bn_published[l] = false;
     v.join_pending = false;
     v.dp_epoch = false;
     v.ev_join_ext = nullptr;
@@ -645,6 +713,9 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
         // the side streams themselves are created at the first training step (ensure_streams), next to the caller's stream
         bool ok = hipEventCreateWithFlags(&v.ev_comm, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&v.ev_x, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&v.ev_fi[0], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&v.ev_fi[1], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&v.ev_acts, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&v.ev_batch, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&v.ev_fold, hipEventDisableTiming) == hipSuccess;
         for (int l = 0; l < NL && ok; ++l) ok = hipEventCreateWithFlags(&v.ev_wg[l], hipEventDisableTiming) == hipSuccess;
@@ -669,7 +740,7 @@ extern "C" int favae_vae_destroy(favae_vae* h) {
     if (v.ev_fence_ok) { kill(v.ev_fence[0]); kill(v.ev_fence[1]); }
     for (hipStream_t q : {v.side, v.side2, v.side3})
         if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
-    kill(v.ev_comm); kill(v.ev_x); kill(v.ev_batch); kill(v.ev_fold);
+    kill(v.ev_comm); kill(v.ev_x); kill(v.ev_batch); kill(v.ev_fold); kill(v.ev_fi[0]); kill(v.ev_fi[1]); kill(v.ev_acts);
     for (int l = 0; l < NL; ++l) { kill(v.ev_fork[l]); kill(v.ev_dg[l]); kill(v.ev_wg[l]); }
     kill(v.ev_join); kill(v.ev_join2);
     delete h;
@@ -725,6 +796,13 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
         // single-device epochs: a layer's update follows its weight gradient at once (optimiser stream, one event wait) and
         // writes the other shadow half (FAVAE_FUSE_MASK bit 0x10000: in place, behind the layer's input-gradient GEMM, i.e.
         // two more waits per layer; bit 0x20000: on the weight-gradient stream itself, no wait)
+        // Opt-in (FAVAE_FUSE_MASK bit 0x40000; 0x80000: publish only): measured on MI355X the fused chain is SLOWER than the
+        // launches it removes -- in a 3x3 convolution every activation is an operand of up to nine taps, so the load-side
+        // BatchNorm + LeakyReLU is redone per tap and the fp32 source doubles the operand bytes: +6.6 us per consumer GEMM
+        // (final_layer.0: +25 us) against 7.5-8 us per apply launch, and the last-block finalisation adds ~8 us per producer
+        // (tools/bench_fi.py; step 1.06 -> 1.15 ms).  Kept as a tested option.
+        v.fi_on = epoch && !v.dp_epoch && v.overlap && (v.fuse & 0x40000u);
+        v.fi_npend = 0; v.acts_wait = false;
         v.merged = epoch && !v.dp_epoch && v.ada.on && !(v.fuse & 0x10000u);
         v.upd_half = v.merged ? (v.sh_sel ^ 1) : v.sh_sel;
         if (v.inline_tail) {
@@ -793,6 +871,11 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
         }
     }
     for (int sg = stage_lo; sg < stage_hi; ++sg) {
+        if (sg == 0 && v.acts_wait) {   // the backward pass reads activations that were materialised on the weight-gradient stream
+            if (v.wk) RC(v.wk->drain());
+            FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_acts, 0));
+            v.acts_wait = false;
+        }
         if (sg == 0) {
             RC(wgrad(v, L_OUT, v.act[11], B, st));
             RC(dgrad(v, L_OUT, v.dact[11], B, st, v.dact_pooled[11], v.dact_bf[11], 11));

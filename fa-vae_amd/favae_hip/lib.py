@@ -130,24 +130,25 @@ def conv_wgrad_prefolded(rows, cols, dw, Rst, Cst, splitk=0):
     return dw
 
 
-def conv_igemm_bn_in(raw_in, in_bins, gamma, beta, w, bias, out, ks, stride, pad, scatter, eps=1e-5, momentum=0.1, run_mean=None,
-                     run_var=None, bins=None, splitk=0):
-    """favae_conv_igemm_bn_in: conv whose input is the fp32 conv output raw_in BEFORE its BatchNorm(train) + LeakyReLU; returns
-    (mean, invstd, ab, fused) of the input layer (ab = a | b of the affine form; bn_lrelu_fwd_ab materialises the activation)."""
-    Nb, Hi, Wi, Cin = raw_in.shape
+def conv_igemm_bn(x, in_ab, w, bias, out, ks, stride, pad, scatter, bins=None, gamma=None, beta=None, publish=False, eps=1e-5,
+                  momentum=0.1, run_mean=None, run_var=None, splitk=0):
+    """favae_conv_igemm_bn.  in_ab given: x is the fp32 output of the preceding conv before its BatchNorm + LeakyReLU.
+    publish: the launch turns its epilogue sums (bins) into (mean, invstd, ab) of the BatchNorm that follows this conv.
+    Returns (fused, mean, invstd, ab)."""
+    Nb, Hi, Wi, Cin = x.shape
     _, Ho, Wo, Cout = out.shape
-    assert raw_in.dtype == torch.float32 and in_bins.dtype == torch.float64 and in_bins.shape[1:] == (2, Cin)
-    mean = torch.empty(Cin, dtype=torch.float32, device=raw_in.device)
-    invstd = torch.empty_like(mean)
-    ab = torch.empty(2 * Cin, dtype=torch.float32, device=raw_in.device)
+    mean = invstd = ab = None
+    if publish:
+        mean = torch.empty(Cout, dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        ab = torch.empty(2 * Cout, dtype=torch.float32, device=x.device)
     fused = ctypes.c_int(0)
     _f = ctypes.c_float
-    check(_lib.favae_conv_igemm_bn_in(ptr(raw_in), ptr(in_bins), _i(in_bins.shape[0]), ptr(gamma), ptr(beta), _f(eps), _f(momentum),
-                                      ptr(mean), ptr(invstd), ptr(ab), ptr(run_mean), ptr(run_var), ptr(w), ptr(bias), ptr(out),
-                                      _i(Nb), _i(Hi), _i(Wi), _i(Cin), _i(Ho), _i(Wo), _i(Cout), _i(ks), _i(stride), _i(pad),
-                                      _i(scatter), _i(splitk), _i(dtype_code(w)), ptr(bins), _i(0 if bins is None else bins.shape[0]),
-                                      ctypes.byref(fused), stream_ptr()))
-    return mean, invstd, ab, bool(fused.value)
+    check(_lib.favae_conv_igemm_bn(ptr(x), ptr(in_ab), ptr(w), ptr(bias), ptr(out), _i(Nb), _i(Hi), _i(Wi), _i(Cin), _i(Ho), _i(Wo),
+                                   _i(Cout), _i(ks), _i(stride), _i(pad), _i(scatter), _i(splitk), _i(dtype_code(w)), ptr(bins),
+                                   _i(0 if bins is None else bins.shape[0]), ptr(gamma), ptr(beta), _f(eps), _f(momentum), ptr(mean),
+                                   ptr(invstd), ptr(ab), ptr(run_mean), ptr(run_var), ctypes.byref(fused), stream_ptr()))
+    return bool(fused.value), mean, invstd, ab
 
 
 def bn_lrelu_fwd_ab(raw, ab, act):

@@ -64,20 +64,22 @@ int favae_conv_igemm_red(const void* in, const void* w, const float* bias, float
                          double* bins, int nbins, int mode, const void* act, const void* raw, const float* mean,
                          const float* invstd, int* fused, void* stream);
 
-/* favae_conv_igemm whose input is the fp32 output in_raw [Nb,Hi,Wi,Cin] of the preceding convolution BEFORE its
- * BatchNorm(train) + LeakyReLU (:34-35, 58-59): the activation lrelu(raw * a[c] + b[c]), rounded to dtype, is formed when a
- * chunk of the A operand goes to LDS, so the Conv -> BN -> LeakyReLU -> Conv chain of encode() / decode() (:80-87, 94-99)
- * needs no launch between the two convolutions.  in_bins [in_nbins][2][Cin]: the sum / sum of squares per channel that
- * favae_conv_igemm_red (mode 1) took in the producer's epilogue.  Every block derives a = invstd * gamma,
- * b = beta - mean * a itself; one block also writes in_mean, in_invstd [Cin], in_ab [2*Cin] = (a | b) and updates the running
- * statistics (in_run_mean / in_run_var, may be NULL) with in_momentum.  The materialised activation, where the backward pass
- * wants it, is favae_bn_lrelu_fwd_ab(in_raw, in_ab, ...): same bytes.  Cin in {64, 128, 192, 256}, Cout > 32;
- * bins / nbins / fused (bins may be NULL): epilogue statistics of THIS convolution as in favae_conv_igemm_red mode 1. */
-int favae_conv_igemm_bn_in(const void* in_raw, const double* in_bins, int in_nbins, const float* in_gamma, const float* in_beta,
-                           float in_eps, float in_momentum, float* in_mean, float* in_invstd, float* in_ab, float* in_run_mean,
-                           float* in_run_var, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cin, int Ho,
-                           int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk, int dtype, double* bins,
-                           int nbins, int* fused, void* stream);
+/* Conv -> BatchNorm(train) -> LeakyReLU -> Conv chains of encode() / decode() (:80-87, 94-99; blocks :25-42, 45-78) without a
+ * launch between the convolutions.  favae_conv_igemm with two optional fusions:
+ *   output side (ab != NULL; needs bins): as favae_conv_igemm_red mode 1 the epilogue adds sum / sum of squares per channel
+ *     into bins [nbins][2][Cout] (zeroed by the caller); the block that finishes last turns them into the BatchNorm(train)
+ *     quantities of the layer that follows this convolution: mean, invstd [Cout], ab [2*Cout] = (a | b) with
+ *     a = invstd * gamma, b = beta - mean * a, and the running statistics (run_mean / run_var, may be NULL; unbiased variance,
+ *     `momentum`).  *fused = 1 if the launch did so; 0 if this shape runs with a split reduction (nothing was written: the
+ *     caller applies favae_bn_train_fwd to out instead).
+ *   input side (in_ab != NULL): `in` is the fp32 output [Nb,Hi,Wi,Cin] of the preceding convolution BEFORE its BatchNorm +
+ *     LeakyReLU and in_ab the (a | b) its launch published; the activation lrelu(in * a[c] + b[c]), rounded to dtype, is formed
+ *     when a chunk of the A operand goes to LDS.  Cin in {64, 128, 192, 256}, Cout > 32.  The materialised activation, where the
+ *     backward pass wants it, is favae_bn_lrelu_fwd_ab(in, in_ab, ...): same bytes. */
+int favae_conv_igemm_bn(const void* in, const float* in_ab, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi,
+                        int Cin, int Ho, int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk, int dtype,
+                        double* bins, int nbins, const float* gamma, const float* beta, float eps, float momentum, float* mean,
+                        float* invstd, float* ab, float* run_mean, float* run_var, int* fused, void* stream);
 
 /* Weight gradient  dw[r][tap][c] += sum_pixels rows[pix][r] * cols[pix'][c]  (fp32 atomics; caller zeroes dw).
  * splitk: 0 = choose, > 0 = that many slices of the pixel range, < 0 = choose and dw is known to be all zero (an unsplit
@@ -136,8 +138,8 @@ int favae_bn_eval_prep(const float* run_mean, const float* run_var, int C, float
 /* act = LeakyReLU_0.01((raw-mean)*invstd*gamma+beta) stored as dtype (:34-35); apply_act=0 skips the LeakyReLU. */
 int favae_bn_lrelu_fwd(const void* raw, const float* mean, const float* invstd, const float* gamma, const float* beta,
                        void* act, long long R, int C, int apply_act, int dtype, void* stream);
-/* act = LeakyReLU_0.01(raw * a[c] + b[c]) with ab [2*C] = (a | b) as published by favae_conv_igemm_bn_in: the activation that
- * kernel formed on the fly, materialised (bit-identical) for the backward pass (:34-35 under loss.backward(), :249). */
+/* act = LeakyReLU_0.01(raw * a[c] + b[c]) with ab [2*C] = (a | b) as published by favae_conv_igemm_bn: the activation that a consuming
+ * favae_conv_igemm_bn forms on the fly, materialised (bit-identical) for the backward pass (:34-35 under loss.backward(), :249). */
 int favae_bn_lrelu_fwd_ab(const float* raw, const float* ab, void* act, long long R, int C, int dtype, void* stream);
 /* Training-mode BN + LeakyReLU in one call (statistics, running-stat update, apply; :34-35 under self.train()): same
  * results as favae_bn_stats followed by favae_bn_lrelu_fwd; small layers (R <= 1024) run as one launch. */

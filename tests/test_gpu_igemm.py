@@ -247,10 +247,11 @@ def test_epilogue_sums_feed_batchnorm_forward(dt, tol, kind, Nb, Cin, Cout, H):
                                                       ("convT", 5, 128, 64, 64, 16, 0),     # dec.3 -> final_layer.0, ragged tiles
                                                       ("conv", 3, 64, 128, 64, 8, 1)])
 def test_batchnorm_and_leakyrelu_applied_in_the_consumer_load(dt, kind, Nb, C0, C1, C2, H, splitk):
-    """Conv -> BatchNorm(train) -> LeakyReLU -> Conv without a launch between the convolutions (favae_conv_igemm_bn_in): the
-    second convolution reads the first one's fp32 output and forms the activation in its operand load.  Against the three-launch
-    chain (favae_conv_igemm_red mode 1, favae_bn_train_fwd_bins, favae_conv_igemm): same statistics (1e-6: the bins are added in
-    another order), same running statistics, output within 1e-5 (fp32) / 2e-3 (bf16: an activation may round the other way
+    """Conv -> BatchNorm(train) -> LeakyReLU -> Conv without a launch between the convolutions (favae_conv_igemm_bn): the first
+    launch publishes the BatchNorm quantities from its epilogue sums (last block), the second reads the first one's fp32 output
+    and forms the activation in its operand load.  Against the three-launch chain (favae_conv_igemm_red mode 1,
+    favae_bn_train_fwd_bins, favae_conv_igemm): same statistics (1e-6: the bins are added in another order), same running
+    statistics, output within 1e-5 (fp32) / 2e-3 (bf16: an activation may round the other way
     where a differs in its last bit) and favae_bn_lrelu_fwd_ab reproduces the materialised activation."""
     import ctypes
     lib = _lib()
@@ -263,7 +264,10 @@ def test_batchnorm_and_leakyrelu_applied_in_the_consumer_load(dt, kind, Nb, C0, 
     w1d = w1.permute(0, 2, 3, 1).reshape(C1, 9, C0).contiguous().to(dt).cuda()
     raw1 = torch.empty(Nb, H1, H1, C1, device="cuda")
     bins = torch.zeros(8, 2, C1, dtype=torch.float64, device="cuda")
-    assert lib.conv_igemm_red(nhwc(x).to(dt).cuda(), w1d, b1.cuda(), raw1, 3, 2, 1, 0, bins, 1, splitk=1)
+    rm1, rv1 = torch.zeros(C1, device="cuda"), torch.ones(C1, device="cuda")
+    took, mean1, inv1, ab = lib.conv_igemm_bn(nhwc(x).to(dt).cuda(), None, w1d, b1.cuda(), raw1, 3, 2, 1, 0, bins=bins, gamma=gam, beta=bet,
+                                              publish=True, run_mean=rm1, run_var=rv1, splitk=1)
+    assert took
     scatter = int(kind == "convT")
     H2 = H1 * 2 if scatter else H1 // 2
     w2 = q(torch.randn(C2, C1, 3, 3, generator=g) * 0.1, dt)
@@ -281,10 +285,8 @@ def test_batchnorm_and_leakyrelu_applied_in_the_consumer_load(dt, kind, Nb, C0, 
     lib.conv_igemm(act, w2d, b2, ref, 3, 2, 1, scatter, splitk)
     # one launch
     out = torch.empty_like(ref)
-    rm1, rv1 = torch.zeros(C1, device="cuda"), torch.ones(C1, device="cuda")
     bins2 = torch.zeros(8, 2, C2, dtype=torch.float64, device="cuda")
-    mean1, inv1, ab, took2 = lib.conv_igemm_bn_in(raw1, bins, gam, bet, w2d, b2, out, 3, 2, 1, scatter, run_mean=rm1, run_var=rv1,
-                                                  bins=bins2, splitk=splitk)
+    took2, *_ = lib.conv_igemm_bn(raw1, ab, w2d, b2, out, 3, 2, 1, scatter, bins=bins2, splitk=splitk)
     torch.cuda.synchronize()
     assert_close(mean1.cpu(), mean0.cpu(), 1e-6)
     assert_close(inv1.cpu(), inv0.cpu(), 1e-6)

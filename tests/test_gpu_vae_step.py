@@ -247,6 +247,46 @@ def test_epoch_with_the_enqueue_worker_equals_the_single_threaded_epoch(dtype, t
         assert _rel(out["1"][1][k].numpy(), out["0"][1][k].numpy()) <= 5e-2, k
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_epoch_with_batchnorm_applied_in_the_consumer_loads(dtype):
+    """FAVAE_FUSE_MASK bit 0x40000: the forward pass runs Conv -> BN -> LeakyReLU -> Conv chains through favae_conv_igemm_bn (the
+    producer's last block publishes the BatchNorm quantities, the consumer applies them in its operand load, the activation
+    for the backward pass is materialised on the weight-gradient stream).  Off by default (slower on MI355X); the
+    first step of an epoch must agree with the default path, later steps within the run-to-run spread."""
+    import os
+    z, Bn, N = 20, 64, 5 * 64
+    torch.manual_seed(0)
+    P, Bf = vt.init_state(z, 3)
+    sd = {k: v.detach().clone() for k, v in P.items()}
+    sd.update({k: v.clone() for k, v in Bf.items()})
+    img, _ = img_inputs(N)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(5)).to(torch.int32).cuda()
+    eps = torch.randn(N, z, generator=torch.Generator().manual_seed(3)).cuda()
+    prior = torch.from_numpy(np.random.RandomState(7).randn(N, z) * 0.5).cuda()
+    out = {}
+    old = os.environ.get("FAVAE_FUSE_MASK")
+    try:
+        for mask in ("0x17b", "0x4017b"):
+            os.environ["FAVAE_FUSE_MASK"] = mask
+            eng = _engine(z, dtype)
+            eng.load_state_dict(sd)
+            data = eng.upload_images(img)
+            ms = torch.zeros(5, 2, dtype=torch.float64, device="cuda")
+            eng.train_epoch(data, perm, eps, prior, 1.7, 1.0, 0.01, 1e-3, Bn, ms)
+            torch.cuda.synchronize()
+            out[mask] = (ms.cpu().numpy(), eng.state_dict())
+    finally:
+        if old is None:
+            os.environ.pop("FAVAE_FUSE_MASK", None)
+        else:
+            os.environ["FAVAE_FUSE_MASK"] = old
+    m0, m1 = out["0x17b"][0], out["0x4017b"][0]
+    assert np.allclose(m1[0], m0[0], rtol=1e-5 if dtype == "f32" else 2e-3), (m1[0], m0[0])
+    assert np.allclose(m1[:, 0], m0[:, 0], rtol=1e-2 if dtype == "f32" else 5e-2)
+    for k in ("enc.0.1.running_mean", "enc.1.1.running_var", "dec.3.1.running_mean", "final_layer.1.running_var"):
+        assert _rel(out["0x4017b"][1][k].numpy(), out["0x17b"][1][k].numpy()) <= 5e-2, k
+
+
 def test_data_parallel_epoch_over_rccl_one_rank():
     """The multi-rank trainloop in a one-rank RCCL group (own process: it owns a process group): favae_vae_train_epoch_dp
     through the library's communicator and the torch.distributed fallback both reproduce the single-device epochs
