@@ -146,6 +146,9 @@ struct KcParams {
     float *fin_mean, *fin_invstd, *fin_ab, *fin_run_mean, *fin_run_var;
     double fin_R; float fin_eps, fin_mom;
     unsigned* fin_ticket;
+    // eval-mode BatchNorm + LeakyReLU in the epilogue (staged 64x64 epilogue of unsplit reductions): the stored value is
+    // lrelu(y * a[c] + b[c]) with ep_ab = a[Cout] | b[Cout] from the running statistics
+    const float* ep_ab;
 };
 
 // 8 (bf16) or 4 (fp32) channels c0.. of the fused-input operand: BN affine + LeakyReLU(0.01), same expressions and rounding as
@@ -413,6 +416,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
             const int c4 = (tid & 15) * 4, n = n0 + c4;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (add_bias && n < p.Cout) bv = *(const float4*)(p.bias + n);
+            float4 ea = make_float4(1.f, 1.f, 1.f, 1.f), eb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.ep_ab && n < p.Cout) { ea = *(const float4*)(p.ep_ab + n); eb = *(const float4*)(p.ep_ab + p.Cout + n); }
             const int red = p.red_bins ? p.red_mode : 0;   // block-uniform
             double rs[4] = {0.0, 0.0, 0.0, 0.0}, rq[4] = {0.0, 0.0, 0.0, 0.0};
             float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
@@ -433,6 +438,11 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
                     v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
                 }
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (p.ep_ab) {   // block-uniform
+                    v.x = fmaf(v.x, ea.x, eb.x); v.y = fmaf(v.y, ea.y, eb.y); v.z = fmaf(v.z, ea.z, eb.z); v.w = fmaf(v.w, ea.w, eb.w);
+                    v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;
+                    v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;
+                }
                 if (p.out_bf16) {
                     uint2 u;
                     u.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
@@ -781,7 +791,7 @@ int dispatch_kc(KcParams p, int classes, int target_blocks, int* fused, hipStrea
     // on every layer of the step (sweep on MI355X), because the fp32 atomic traffic of split-K grows with the tile
     // area while these grids already cover the 256 CUs.  128x32 serves the few-output-channel gather layers.
     bool narrow_n = !slow && p.Cout <= 32 && !TR;
-    if (!slow && !TR && g_force_kc_tile >= 0 && !p.in_ab) narrow_n = g_force_kc_tile == 1;
+    if (!slow && !TR && g_force_kc_tile >= 0 && !p.in_ab && !p.ep_ab) narrow_n = g_force_kc_tile == 1;
     const int BM = narrow_n ? 128 : 64, BN = narrow_n ? 32 : 64;
     p.ntn = cdiv(p.Cout, BN);
     // split the reduction when the tile grid alone cannot fill 256 CUs
@@ -867,7 +877,7 @@ int fin_ticket(unsigned** out) {
 
 int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cin, int Ho,
                     int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk, int dtype, const RedArgs& red,
-                    void* stream, const float* in_ab = nullptr, const Fin* fin = nullptr) {
+                    void* stream, const float* in_ab = nullptr, const Fin* fin = nullptr, const float* ep_ab = nullptr) {
     FAVAE_CHECK_ARG(in && w && out, "favae_conv_igemm: null pointer");
     FAVAE_CHECK_ARG(Nb > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Ho > 0 && Wo > 0 && Cout > 0, "favae_conv_igemm: bad shape");
     FAVAE_CHECK_ARG((ks == 1 && pad == 0) || (ks == 3 && pad == 1), "favae_conv_igemm: ks/pad must be 1/0 or 3/1");
@@ -887,7 +897,7 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
     hipStream_t st = (hipStream_t)stream;
     if (red.fused) *red.fused = 0;
     // one thread per output pixel pays off once the pixel count fills the chip several times over (the decoder side)
-    if (!in_ab && g_force_kc_tile < 0 && (long long)Nb * Ho * Wo >= 131072 && thin_in_applicable(Cin, Cout, ks, stride, scatter)) {
+    if (!in_ab && !ep_ab && g_force_kc_tile < 0 && (long long)Nb * Ho * Wo >= 131072 && thin_in_applicable(Cin, Cout, ks, stride, scatter)) {
         ProfScope prof(14, 2.0 * Nb * Ho * Wo * (double)Cout * 9 * Cin, (hipStream_t)stream);
         ThinRed tr{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
         if (red.bins && red.mode == 2 && !out_bf16 && !red.raw_bf16) {   // the statistics form (mode 1) is not needed on this path
@@ -902,6 +912,9 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
     p.ks = ks; p.stride = stride; p.pad = pad; p.ldw = ks * ks * Cin; p.splitk = splitk; p.out_bf16 = out_bf16;
     p.red_bins = red.bins; p.red_nbin = red.nbin; p.red_mode = red.mode; p.red_act = red.act; p.red_raw = red.raw;
     p.red_mean = red.mean; p.red_invstd = red.invstd; p.red_raw_bf16 = red.raw_bf16;
+    p.ep_ab = ep_ab;
+    if (ep_ab) FAVAE_CHECK_ARG(splitk == 1 && Cout % 4 == 0 && Cout > 32 && ((uintptr_t)ep_ab % 16) == 0,
+                               "favae_conv_igemm_affine: needs splitk = 1 and Cout > 32, a multiple of 4");
     p.in_ab = in_ab;
     if (in_ab) {
         FAVAE_CHECK_ARG(Cin % BK == 0 && Cin <= 256 && Cout > 32, "favae_conv_igemm_bn_in: Cin must be 64, 128, 192 or 256 and Cout > 32");
@@ -957,6 +970,15 @@ extern "C" int favae_conv_igemm_bn(const void* in, const float* in_ab, const voi
     if (fused) *fused = 0;
     return conv_igemm_impl(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype, red, stream, in_ab,
                            ab ? &fin : nullptr);
+}
+
+extern "C" int favae_conv_igemm_affine(const void* in, const void* w, const float* bias, void* out, int Nb, int Hi, int Wi, int Cin,
+                                       int Ho, int Wo, int Cout, int ks, int stride, int pad, int scatter, int dtype,
+                                       const float* ab, void* stream) {
+    FAVAE_CHECK_ARG(ab, "favae_conv_igemm_affine: null ab");
+    const RedArgs none{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    return conv_igemm_impl(in, w, bias, (float*)out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, 1, dtype, none, stream, nullptr,
+                           nullptr, ab);
 }
 
 extern "C" int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const void* cols, int Cc, int cols_large,

@@ -233,6 +233,16 @@ __global__ void bn_eval_prep(const float* run_mean, const float* run_var, int C,
     invstd[c] = 1.f / sqrtf(run_var[c] + eps);
 }
 
+// the affine form of eval-mode BN with the same operations as bn_eval_prep + bn_lrelu_fwd (invstd = 1 / sqrt(var + eps), a = invstd * gamma)
+__global__ void bn_eval_ab(const float* run_mean, const float* run_var, const float* gamma, const float* beta, int C, float eps, float* ab) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.f / sqrtf(run_var[c] + eps);
+    const float a = is * gamma[c];
+    ab[c] = a;
+    ab[C + c] = beta[c] - run_mean[c] * a;
+}
+
 // ---- BN apply + LeakyReLU(0.01) forward, 4 channels per thread -----------------------------------------------
 template <class T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
@@ -1489,6 +1499,14 @@ extern "C" int favae_bn_lrelu_fwd(const void* raw, const float* mean, const floa
         hipLaunchKernelGGL((bn_lrelu_fwd<bf16_t, bf16_t>), dim3((unsigned)grid), dim3(256), 0, ST, (const bf16_t*)raw, mean, invstd, gamma, beta, (bf16_t*)act, nvec, C, apply_act);
     else
         hipLaunchKernelGGL((bn_lrelu_fwd<bf16_t, float>), dim3((unsigned)grid), dim3(256), 0, ST, (const float*)raw, mean, invstd, gamma, beta, (bf16_t*)act, nvec, C, apply_act);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_bn_eval_ab(const float* run_mean, const float* run_var, const float* gamma, const float* beta, int C, float eps,
+                                float* ab, void* stream) {
+    FAVAE_CHECK_ARG(run_mean && run_var && gamma && beta && ab && C > 0, "favae_bn_eval_ab: bad argument");
+    hipLaunchKernelGGL(bn_eval_ab, dim3(cdiv(C, 64)), dim3(64), 0, ST, run_mean, run_var, gamma, beta, C, eps, ab);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

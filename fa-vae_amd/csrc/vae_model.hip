@@ -185,6 +185,7 @@ struct Vae {
     // BatchNorm + LeakyReLU of a layer applied in the operand load of the next convolution (favae_conv_igemm_bn_in): the main
     // chain has no launch between the two GEMMs; the activation the backward pass reads (weight gradient of the next layer,
     // LeakyReLU slopes) is materialised on the weight-gradient stream, which is idle during the forward pass
+    bool eval_fused, eval_ab_ready;   // eval-mode BatchNorm in the GEMM epilogues (large-batch eval executor); ab[] holds the running-stat form
     float* ab[NL]; bool act_deferred[NL]; bool bn_published[NL]; bool fi_on; int fi_pend[NL], fi_npend, fi_flushes; hipEvent_t ev_fi[2], ev_acts; bool acts_wait;
     char* shp(int half) const { return SH + (size_t)half * sh_half; }
     const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(shp(sh_sel) + L[l].wc_off * esz); }
@@ -449,6 +450,24 @@ int fi_flush(Vae& v, int B, void* st) {
 }
 
 int conv_bn_chain(Vae& v, int lo, int hi, const void* in, int B, bool train, void* st, bool pooled) {
+    if (!train && v.eval_fused) {
+        // eval passes over a data set (batch >= 256): BatchNorm with the running statistics is an affine map known before the
+        // launch, so it rides with the LeakyReLU in the GEMM epilogue: one launch per layer, no fp32 conv output in memory
+        for (int l = lo; l <= hi; ++l) {
+            const Layer& L = v.L[l];
+            if (L.Cin % 64 != 0) {   // encoder.0 keeps the thin-input convolution + apply
+                RC(conv_fwd(v, l, in, B, st, pooled));
+                RC(bn_fwd(v, l, B, false, st));
+                in = v.act[l];
+                continue;
+            }
+            if (!v.eval_ab_ready) RC(favae_bn_eval_ab(v.BUF + L.rm_off, v.BUF + L.rv_off, v.P + L.g_off, v.P + L.be_off, L.Cout, 1e-5f, v.ab[l], st));
+            RC(favae_conv_igemm_affine(in, v.Wf(l), v.P + L.b_off, v.act[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, 2, 1,
+                                       L.kind == CONVT_S2, v.dtype | (v.dtype == FAVAE_BF16 ? FAVAE_OUT_BF16 : 0), v.ab[l], st));
+            in = v.act[l];
+        }
+        return FAVAE_OK;
+    }
     int fi = -1;
     for (int l = lo; l <= hi; ++l) {
         RC(conv_fwd(v, l, in, B, st, pooled, fi));
@@ -692,6 +711,8 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.ada = {false, 0.f, 0.f, 0.f, 0.f, 0, false};
     v.pending = -1;
     v.wk = nullptr;
+    v.eval_fused = batch_max >= 256 && !(getenv("FAVAE_EVAL_FUSED") && getenv("FAVAE_EVAL_FUSED")[0] == '0');
+    v.eval_ab_ready = false;
     v.fi_on = false; v.fi_npend = 0; v.fi_flushes = 0; v.acts_wait = false;
     for (int l = 0; l < NL; ++l) v.act_deferred[l] = v.bn_published[l] = false;
     v.join_pending = false;
@@ -1176,11 +1197,15 @@ extern "C" int favae_vae_encode_all(favae_vae* h, const float* data_nhwc, long l
     FAVAE_CHECK_ARG(h && n > 0 && batch > 0, "favae_vae_encode_all: bad argument");
     Vae& v = h->v;
     const long long row = (long long)64 * 64 * v.ch;
-    for (long long o = 0; o < n; o += batch) {
+    v.eval_ab_ready = false;   // the first batch derives the affine forms from the current running statistics, the rest reuse them
+    int rc = FAVAE_OK;
+    for (long long o = 0; o < n && rc == FAVAE_OK; o += batch) {
         const int B = (int)std::min<long long>(batch, n - o);
-        RC(favae_vae_encode(h, data_nhwc + o * row, nullptr, B, xmean + o * v.z, xcov + o * v.z, 0, st));
+        rc = favae_vae_encode(h, data_nhwc + o * row, nullptr, B, xmean + o * v.z, xcov + o * v.z, 0, st);
+        v.eval_ab_ready = v.eval_fused;
     }
-    return FAVAE_OK;
+    v.eval_ab_ready = false;
+    return rc;
 }
 
 /* Decoder (reconstruction / decoder(), :94-99, 360-385): zin [B][z] fp32 -> out [B][64][64][ch] fp32 NHWC. */
@@ -1201,13 +1226,17 @@ extern "C" int favae_vae_reconstruct_stats(favae_vae* h, const float* zin, const
     Vae& v = h->v;
     const long long row = (long long)64 * 64 * v.ch;
     FAVAE_HIP(hipMemsetAsync(acc3, 0, 3 * sizeof(double), (hipStream_t)st));
-    for (long long o = 0; o < n; o += batch) {
+    v.eval_ab_ready = false;
+    int rc = FAVAE_OK;
+    for (long long o = 0; o < n && rc == FAVAE_OK; o += batch) {
         const int B = (int)std::min<long long>(batch, n - o);
-        RC(favae_cast(zin + o * v.z, v.zlat, (long long)B * v.z, v.dtype, st));
-        RC(decoder_fwd(v, B, false, st));
-        RC(favae_sigmoid_sse(v.raw[L_OUT], data_nhwc + o * row, (long long)B * row, acc3, v.scratch, v.scratch_doubles, st));
+        rc = favae_cast(zin + o * v.z, v.zlat, (long long)B * v.z, v.dtype, st);
+        if (rc == FAVAE_OK) rc = decoder_fwd(v, B, false, st);
+        v.eval_ab_ready = v.eval_fused;
+        if (rc == FAVAE_OK) rc = favae_sigmoid_sse(v.raw[L_OUT], data_nhwc + o * row, (long long)B * row, acc3, v.scratch, v.scratch_doubles, st);
     }
-    return FAVAE_OK;
+    v.eval_ab_ready = false;
+    return rc;
 }
 
 /* Debug/parity access to the executor's internal buffers: which = 0 raw, 1 act, 2 dact, 3 draw. */

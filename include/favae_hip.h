@@ -81,6 +81,16 @@ int favae_conv_igemm_bn(const void* in, const float* in_ab, const void* w, const
                         double* bins, int nbins, const float* gamma, const float* beta, float eps, float momentum, float* mean,
                         float* invstd, float* ab, float* run_mean, float* run_var, int* fused, void* stream);
 
+/* favae_conv_igemm followed by eval-mode BatchNorm + LeakyReLU in the epilogue (self.eval() passes: update_x :343-355,
+ * reconstruction :368-381): out (dtype with FAVAE_OUT_BF16, else fp32) = lrelu((conv + bias) * a[c] + b[c]),
+ * ab [2*Cout] = (a | b) from favae_bn_eval_ab.  Same values as favae_conv_igemm + favae_bn_lrelu_fwd.  Unsplit reduction,
+ * Cout > 32 and a multiple of 4. */
+int favae_conv_igemm_affine(const void* in, const void* w, const float* bias, void* out, int Nb, int Hi, int Wi, int Cin, int Ho,
+                            int Wo, int Cout, int ks, int stride, int pad, int scatter, int dtype, const float* ab, void* stream);
+/* a = gamma / sqrt(running_var + eps), b = beta - running_mean * a -> ab [2*C]. */
+int favae_bn_eval_ab(const float* run_mean, const float* run_var, const float* gamma, const float* beta, int C, float eps, float* ab,
+                     void* stream);
+
 /* Weight gradient  dw[r][tap][c] += sum_pixels rows[pix][r] * cols[pix'][c]  (fp32 atomics; caller zeroes dw).
  * splitk: 0 = choose, > 0 = that many slices of the pixel range, < 0 = choose and dw is known to be all zero (an unsplit
  * reduction then stores its result instead of reading the zeros back).
