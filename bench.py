@@ -26,6 +26,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 E_EPOCHS = 5
+HBM_CLASSES = {7: "BatchNorm + LeakyReLU backward apply (colreduce<BnBwdApplyF>)", 13: "Adam step + gradient clear (adam_kernel<true>)"}
 CLASS_NAMES = {14: "conv thin-input (VALU, one thread per pixel)", 2: "igemm_kc gather 64x64", 3: "igemm_kc gather 128x32", 6: "igemm_kc scatter 64x64",
                8: "igemm_kc gather elementwise-load", 9: "igemm_kc scatter elementwise-load", 10: "igemm_pm wgrad 32x128",
                11: "igemm_pm wgrad 128x32", 12: "igemm_pm wgrad 64x64", 15: "wgrad narrow-channel (VALU)"}
@@ -40,13 +41,24 @@ CLASS_KERNEL = {2: "void igemm_kc<unsigned short, 64, 64, 2, 2, false, false>(Kc
                 12: "void igemm_pm<unsigned short, 64, 64, 2, 2>(PmParams)"}
 
 
-def pmc_traffic(cls, dtype):
+CLASS_KERNEL.update({7: "void colreduce<1, 4, BnBwdApplyF<unsigned short, float, float> >(int, int, int, int, int, double*, unsigned int*, BnBwdApplyF<unsigned short, float, float>)",
+                     13: "void adam_kernel<true, false>(float*, float*, float*, float*, unsigned long, float, float, float, float, float, unsigned short*, unsigned long)"})
+PMC_JSON = os.path.join(ROOT, "profiles", "r2_pmc_traffic_per_launch.json")
+
+
+def pmc_traffic(cls, dtype, key=None):
     """HBM-side bytes per launch of a kernel class from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE runs of tools/prof_step.py, gfx950 corrections applied); None when there is no such record."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic_per_launch.json")
-    if dtype != "bf16" or cls not in CLASS_KERNEL or not os.path.exists(path):
+    if dtype != "bf16" or not os.path.exists(PMC_JSON):
         return None
-    rec = json.load(open(path)).get(CLASS_KERNEL[cls])
+    d = json.load(open(PMC_JSON))
+    if key is not None:
+        return d.get(key, {}).get("hbm_bytes")
+    name = CLASS_KERNEL.get(cls)
+    rec = d.get(name) if name else None
+    if rec is None and name:      # kernel signatures carry template / argument lists: match on the prefix before the arguments
+        stem = name.split("(")[0]
+        rec = next((v for k, v in d.items() if k.startswith(stem)), None)
     return None if rec is None else rec["hbm_bytes"]
 
 
@@ -116,6 +128,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--samples", dest="n", type=int, default=202599, help="samples per GPU")
+    ap.add_argument("--global-samples", dest="n_global", type=int, default=0,
+                    help="strong scaling: this many samples in total, sharded over the ranks (dist.shard_bounds); overrides --samples")
     ap.add_argument("--kc", type=int, default=50)
     ap.add_argument("--latent", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -153,6 +167,12 @@ def main():
     import favae
     from favae_hip import lib
 
+    scaling = "weak"
+    n_total = a.n * ws
+    if a.n_global > 0:                                    # strong scaling: fixed global N, np.array_split-style shards
+        from favae_hip import dist as _fd
+        lo, hi = _fd.shard_bounds(a.n_global, ws, rank)
+        a.n, n_total, scaling = hi - lo, a.n_global, "strong"
     img, lab = synth(a.n, 1 + rank)
     np.random.seed(0)
     torch.manual_seed(0)
@@ -179,7 +199,7 @@ def main():
     raw = lib.raw()
     for _ in range(a.warmup):
         one_iteration()
-    raw.favae_prof_enable(1, 16)
+    raw.favae_prof_enable(1, 17)     # coprime to the launches per step of every timed class (10 / 13 / 9 / 5 ...)
     fence()
     t0 = time.time()
     for _ in range(a.steps):
@@ -199,61 +219,100 @@ def main():
     secondary = None
     if not a.no_secondary:
         from favae_hip import imgvae as _iv
-        acc = {"trainloop": 0.0}
-        orig = _iv.ImgVAE.trainloop
+        acc = {"trainloop": 0.0, "update_x": 0.0, "reconstruction_r2": 0.0}
+        origs = {k: getattr(_iv.ImgVAE, k) for k in acc}
 
-        def timed_trainloop(self, *args, **kw):
-            torch.cuda.synchronize()
-            ts = time.time()
-            r = orig(self, *args, **kw)
-            torch.cuda.synchronize()
-            acc["trainloop"] += time.time() - ts
-            return r
-        _iv.ImgVAE.trainloop = timed_trainloop
+        def timed(name):
+            f = origs[name]
+
+            def g(self, *args, **kw):
+                torch.cuda.synchronize()
+                ts = time.time()
+                r = f(self, *args, **kw)
+                torch.cuda.synchronize()
+                acc[name] += time.time() - ts
+                return r
+            return g
+        for k in acc:
+            setattr(_iv.ImgVAE, k, timed(k))
         fence()
         ts = time.time()
         one_iteration()
         fence()
         tot = time.time() - ts
-        _iv.ImgVAE.trainloop = orig
-        rest = max(tot - acc["trainloop"], 1e-9)
-        secondary = {"vae_trainloop_samples_per_s": E_EPOCHS * a.n * ws / acc["trainloop"],
-                     "vae_ms_per_64_image_step": 1e3 * acc["trainloop"] / (E_EPOCHS * ((a.n + 63) // 64)),
-                     "fa_and_eval_passes_samples_per_s": a.n * ws / rest,
-                     "seconds": {"iteration": tot, "trainloop": acc["trainloop"], "fa_updates_update_x_reconstruction": rest}}
+        for k, f in origs.items():
+            setattr(_iv.ImgVAE, k, f)
+        evalp = acc["update_x"] + acc["reconstruction_r2"]
+        fa_only = max(tot - acc["trainloop"] - evalp, 1e-9)
+        nsteps = E_EPOCHS * ((a.n + 63) // 64)
+        secondary = {"vae_trainloop_samples_per_s": E_EPOCHS * n_total / acc["trainloop"],
+                     "vae_ms_per_64_image_step": 1e3 * acc["trainloop"] / nsteps,
+                     "fa_only_samples_per_s": n_total / fa_only,
+                     "eval_passes_samples_per_s": 2 * n_total / max(evalp, 1e-9),
+                     "seconds": {"iteration": tot, "trainloop": acc["trainloop"], "update_x": acc["update_x"],
+                                 "reconstruction_r2": acc["reconstruction_r2"],
+                                 "fa_updates_bound_pruning": fa_only},
+                     "note": "one extra, untimed iteration with a device synchronisation around trainloop / update_x / reconstruction; "
+                             "fa_only = update_w, update_Z, update_tau/b/alpha, the multilabel update, update_bound, (de)pruning"}
 
     if rank == 0:
-        n_global = a.n * ws
-        kern = []
+        n_global = n_total
+        kern, hbm = [], []
         for c in range(16):
-            cnt, sec, fl = prof[3 * c], prof[3 * c + 1], prof[3 * c + 2]
-            if cnt > 0:
+            cnt, sec, work = prof[3 * c], prof[3 * c + 1], prof[3 * c + 2]
+            if cnt <= 0:
+                continue
+            if c in HBM_CLASSES:
+                hbm.append({"cls": c, "kernel": HBM_CLASSES[c], "sampled_launches": int(cnt), "avg_us": 1e6 * sec / cnt,
+                            "gb_per_s": work / sec / 1e9, "algorithmic_bytes_per_launch": work / cnt, "seconds": sec})
+            else:
                 kern.append({"cls": c, "kernel": CLASS_NAMES.get(c, str(c)), "sampled_launches": int(cnt), "avg_us": 1e6 * sec / cnt,
-                             "tflops": fl / sec / 1e12, "share_of_gemm_time": sec})
+                             "tflops": work / sec / 1e12, "algorithmic_flops_per_launch": work / cnt, "share_of_gemm_time": sec})
         tot = sum(k["share_of_gemm_time"] for k in kern) or 1.0
         for k in kern:
             k["share_of_gemm_time"] /= tot
         dom = max(kern, key=lambda k: k["share_of_gemm_time"]) if kern else None
+        domh = max(hbm, key=lambda k: k["seconds"]) if hbm else None
         peak = 2500.0 if a.dtype == "bf16" else 157.3
+        # algorithmic work of one 64-image step: forward + backward of the conv VAE, dense-tap convention
+        macs_fwd = 197_591_040 + 12_288 * a.latent
+        step_gflop = 64 * 2.0 * (3 * macs_fwd - 1_769_472) / 1e9
+        nparam = 12_587_203 + 12_290 * a.latent
+        step_gb_min = (10 * 4 * nparam + 64 * 4 * 2.1e6) / 1e9      # parameters / Adam 10 x 4 B, activations + their gradients ~2 x 2.1 MB per sample
+        step_gb_meas = pmc_traffic(None, a.dtype, "__per_step__")
+        step_ms = secondary["vae_ms_per_64_image_step"] if secondary else None
         out = {
             "metric": "samples/sec per FA-VAE train iteration (VAE fwd-bwd + FA update)",
             "value": E_EPOCHS * n_global * a.steps / dt, "unit": "samples/s", "n_gpus": ws, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "bf16 conv MFMA (fp32 accumulate) + f64 FA" if a.dtype == "bf16" else "f32 conv MFMA + f64 FA",
             "data": "synthetic",
-            "config": {"workload": "condition_a_VAE full CelebA scale: N=%d synthetic 64x64x3 images per GPU + 40-label view, "
-                                   "latent %d, Kc=%d, E=%d epochs of batch 64 per iteration" % (a.n, a.latent, a.kc, E_EPOCHS),
+            "config": {"workload": "condition_a_VAE full CelebA scale: N=%d synthetic 64x64x3 images %s + 40-label view, "
+                                   "latent %d, Kc=%d, E=%d epochs of batch 64 per iteration"
+                                   % (n_global if scaling == "strong" else a.n, "in total, sharded over the GPUs" if scaling == "strong" else "per GPU",
+                                      a.latent, a.kc, E_EPOCHS),
                        "samples_per_gpu": a.n, "global_samples": n_global, "epochs_per_iteration": E_EPOCHS, "batch": 64,
                        "parallelism": "dp%d (N-sharded, RCCL all-reduce of VAE gradients and FA statistics)" % ws,
                        "bound_last": float(model.L[-1])},
             "roofline": None if dom is None else {
                 "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
                 "frac": dom["tflops"] / peak, "traffic": pmc_traffic(dom["cls"], a.dtype),
-                "note": "HIP events on the launch stream around every 16th launch inside the timed region (weight gradients "
-                        "run on a side stream next to the main chain, so their durations include that overlap); algorithmic "
-                        "flops, dense-tap convention; traffic = mean HBM-side bytes per launch of this kernel from the "
-                        "committed rocprofv3 --pmc passes (profiles/r1_pmc_traffic_per_launch.json)"},
-            "kernels": kern,
+                "note": "dominant GEMM class by time. HIP events on the launch stream around every 17th launch inside the timed "
+                        "region (weight gradients run on a side stream next to the main chain, so their durations include that "
+                        "overlap); achieved = algorithmic flops per launch (dense-tap convention) / mean launch duration; traffic = "
+                        "mean HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes "
+                        "(profiles/r2_pmc_traffic_per_launch.json)"},
+            "roofline_hbm": None if domh is None else {
+                "bound": "hbm", "kernel": domh["kernel"], "achieved": domh["gb_per_s"], "peak": 8000.0, "unit": "GB/s",
+                "frac": domh["gb_per_s"] / 8000.0, "traffic": pmc_traffic(domh["cls"], a.dtype),
+                "note": "top HBM-bound kernel class by time, timed the same way; achieved = algorithmic bytes per launch / mean launch "
+                        "duration (these launches run on side streams or between GEMMs of the main chain and share the chip)"},
+            "step": {"gflop": step_gflop, "gbytes_algorithmic_min": step_gb_min, "gbytes_measured_pmc": None if step_gb_meas is None else step_gb_meas / 1e9,
+                     "ms": step_ms,
+                     "tflops": None if not step_ms else step_gflop / step_ms, "mfma_frac": None if not step_ms else step_gflop / step_ms / peak,
+                     "hbm_gb_per_s": None if (not step_ms or step_gb_meas is None) else step_gb_meas / 1e6 / step_ms,
+                     "note": "one 64-image training step: algorithmic flops (SURVEY 8d), minimum and PMC-measured HBM bytes, wall time per step"},
+            "kernels": kern, "kernels_hbm": hbm,
         }
         if secondary is not None:
             out["secondary"] = secondary

@@ -74,5 +74,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 // waits for outstanding vector memory operations on gfx950.
 __device__ __forceinline__ void wait_vm_writes() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Optional live timing of selected launches (bench.py roofline): every `stride`-th launch of a kernel class is bracketed by
+// HIP events on its launch stream (api.hip); `work` is the algorithmic flops (GEMM classes) or bytes (HBM-bound classes).
+extern "C" int favae_prof_begin(int cls, double work, void* stream);
+extern "C" void favae_prof_end(int idx, void* stream);
+struct ProfScope {
+    void* st; int idx;
+    ProfScope(int cls, double work, hipStream_t s) : st((void*)s), idx(favae_prof_begin(cls, work, (void*)s)) {}
+    ~ProfScope() { if (idx >= 0) favae_prof_end(idx, st); }
+};
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }

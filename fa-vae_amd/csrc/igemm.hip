@@ -28,35 +28,6 @@ namespace {
 
 constexpr int BK = 64;  // reduction elements per LDS stage
 
-// ---- optional live timing of the GEMM launches (bench.py roofline): every `stride`-th launch of each kernel class is
-// bracketed by HIP events on the launch stream; favae_prof_collect() resolves them after a synchronise. -----------
-struct ProfRec { hipEvent_t a, b; int cls; double flops; };
-struct Prof {
-    int enabled = 0, stride = 1;
-    long long counter[16] = {0};
-    std::vector<ProfRec> recs;
-    std::mutex mu;
-} g_prof;
-
-struct ProfScope {
-    hipStream_t st; int idx = -1;
-    ProfScope(int cls, double flops, hipStream_t s) : st(s) {
-        if (!g_prof.enabled) return;
-        std::lock_guard<std::mutex> lk(g_prof.mu);
-        if ((g_prof.counter[cls]++ % g_prof.stride) != 0) return;
-        ProfRec r; r.cls = cls; r.flops = flops;
-        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-        (void)hipEventRecord(r.a, st);
-        g_prof.recs.push_back(r);
-        idx = (int)g_prof.recs.size() - 1;
-    }
-    ~ProfScope() {
-        if (idx < 0) return;
-        std::lock_guard<std::mutex> lk(g_prof.mu);
-        (void)hipEventRecord(g_prof.recs[idx].b, st);
-    }
-};
-
 int g_force_kc_tile = -1, g_force_pm_tile = -1;  // developer override (favae_debug_force_tile), -1 = heuristic
 
 template <class T> struct Frag;
@@ -1070,31 +1041,3 @@ extern "C" int favae_debug_force_tile(int kc_tile, int pm_tile) {
     return FAVAE_OK;
 }
 
-/* Live kernel timing for bench.py: enable with a sampling stride, run, then collect per-class (launches, seconds, flops).
- * Classes: 2/3 gather form tiles 64x64/128x32, 6 scatter form 64x64, 8/9 element-wise loaders (gather/scatter),
- * 10-12 weight gradient tiles 32x128/128x32/64x64, 15 narrow-channel weight gradient (smallconv.hip). */
-extern "C" int favae_prof_enable(int enabled, int stride) {
-    std::lock_guard<std::mutex> lk(g_prof.mu);
-    g_prof.enabled = enabled;
-    g_prof.stride = stride > 0 ? stride : 1;
-    for (auto& c : g_prof.counter) c = 0;
-    return FAVAE_OK;
-}
-extern "C" int favae_prof_collect(double* out /* [16][3] */) {
-    FAVAE_CHECK_ARG(out, "favae_prof_collect: null");
-    FAVAE_HIP(hipDeviceSynchronize());
-    std::lock_guard<std::mutex> lk(g_prof.mu);
-    for (int i = 0; i < 48; ++i) out[i] = 0.0;
-    for (auto& r : g_prof.recs) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
-            out[r.cls * 3 + 0] += 1.0;
-            out[r.cls * 3 + 1] += ms * 1e-3;
-            out[r.cls * 3 + 2] += r.flops;
-        }
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
-    }
-    g_prof.recs.clear();
-    return FAVAE_OK;
-}

@@ -1617,6 +1617,8 @@ template <class T, class RT, class DT>
 static int bn_bwd_bins_impl(const void* dact, const void* act, const void* raw, const float* mean, const float* invstd,
                             const float* gamma, const double* bins, int nbins, void* draw, float* dgamma, float* dbeta,
                             float* dbias, long long R, int C, double* scratch, size_t cap, hipStream_t st) {
+    // algorithmic bytes: dact + raw + act read, draw written
+    ProfScope prof(7, (double)R * C * (sizeof(DT) + sizeof(RT) + 2 * sizeof(T)), st);
     return run_colreduce<1>(R, C, scratch, cap,
                             BnBwdApplyF<T, RT, DT>{(const DT*)dact, (const T*)act, (const RT*)raw, mean, invstd, gamma, nullptr, (T*)draw, C,
                                                    (float)(1.0 / (double)R), dbias, bins, nbins, dgamma, dbeta}, st);
@@ -1872,6 +1874,7 @@ extern "C" int favae_adam_step_clear(float* p, float* g, float* m, float* v, lon
     FAVAE_CHECK_ARG(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "favae_adam_step_clear: bad argument (n must be a multiple of 4)");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    ProfScope prof(13, 32.0 * (double)n, ST);   // p, g, m, v read; p, m, v written; g cleared
     hipLaunchKernelGGL(adam_kernel<true>, dim3(ew_grid((size_t)n / 4)), dim3(256), 0, ST, p, g, m, v, (size_t)n / 4, beta1, beta2, eps, step_size, bc2_sqrt);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;

@@ -127,6 +127,19 @@ def sum_scalar(x, device=None):
     return t.item()
 
 
+def min_scalar(x, device=None):
+    """Minimum of a Python int/float over ranks."""
+    if not active():
+        return x
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device if td.get_backend() == "nccl" else "cpu")
+    td.all_reduce(t, op=td.ReduceOp.MIN)
+    return t.item()
+
+
+def max_scalar(x, device=None):
+    return -min_scalar(-x, device)
+
+
 def all_equal(x, device=None):
     if not active():
         return True

@@ -263,10 +263,17 @@ class ImgVAE(VAE):
             tau_f = float(torch.Tensor(np.asarray(tau)).reshape(-1)[0])       # the fp32 cast of :210
         else:
             prior, tau_f = None, 1.0
-        n = data.shape[0]
+        n_loc = data.shape[0]
+        # Data-parallel epochs step in lockstep (one gradient all-reduce per optimiser step), so every rank visits the same
+        # number of samples per epoch: the smallest shard's.  With np.array_split-style shards (dist.shard_bounds) that leaves
+        # at most ONE sample per rank and epoch unvisited -- a different one each epoch, the permutation is drawn over the whole
+        # shard -- and makes every mini-batch the same size on every rank, so the averaged gradient is exactly the gradient of the
+        # global batch of BATCH * world_size samples.  (The FA statistics always run over all rows.)
+        n = int(dist.min_scalar(n_loc, self.device))
+        if dist.active() and dist.max_scalar(n_loc, self.device) - n >= self.BATCH and not getattr(self, "_warned_shards", False):
+            self._warned_shards = True
+            print("favae_hip: unbalanced shards: ranks with more than %d rows skip the surplus in each VAE epoch" % n)
         nb = (n + self.BATCH - 1) // self.BATCH
-        if not dist.all_equal(nb, self.device):
-            raise ValueError("data-parallel trainloop needs the same number of mini-batches on every rank (got %d here)" % nb)
         metrics = torch.zeros(nb, 2, dtype=torch.float64, device=self.device)
         elbo_checker = -1e20
         for ep in range(int(epochs)):
@@ -274,7 +281,7 @@ class ImgVAE(VAE):
             seed = int(torch.empty((), dtype=torch.int64).random_().item())   # RandomSampler seed
             g = torch.Generator()
             g.manual_seed(seed)
-            perm = torch.randperm(n, generator=g)
+            perm = torch.randperm(n_loc, generator=g)[:n]
             eps = torch.cat([torch.randn(min(self.BATCH, n - s), self.dimx) for s in range(0, n, self.BATCH)], 0)
             perm_d, eps_d = perm.to(torch.int32).to(self.device), eps.to(self.device)
             if not dist.active():

@@ -125,9 +125,10 @@ int favae_conv_fold_taps(const void* src, void* dst, size_t dst_bytes, int Nb, i
 int favae_conv_wgrad_prefolded(const void* rows, int Rc, int Rst, const void* cols, int Cc, int Cst, float* dw, long long K,
                                int splitk, int dtype, void* stream);
 
-/* Live HIP-event timing of the GEMM launches (measurement only; no reference counterpart). Every stride-th launch of
- * each kernel class is timed on its launch stream; collect() synchronises and returns [16][3] = launches, seconds,
- * algorithmic flops per class (classes: see csrc/igemm.hip). */
+/* Live HIP-event timing of selected launches (measurement only; no reference counterpart). Every stride-th launch of each
+ * kernel class is timed on its launch stream; collect() synchronises and returns [16][3] = launches, seconds, algorithmic
+ * work per class: flops for the GEMM classes, bytes for the HBM-bound ones (7 BatchNorm-backward apply, 13 Adam); classes
+ * are listed in csrc/api.hip.  Choose a stride coprime to the launches per step of the classes of interest. */
 int favae_prof_enable(int enabled, int stride);
 int favae_prof_collect(double* out48);
 /* Developer hook for tile tuning (tools/tune_gemm.py; no reference counterpart): force the tile of the gather-form

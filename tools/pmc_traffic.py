@@ -26,5 +26,11 @@ for k in sorted(fe, key=lambda k: -fe[k][0] * fe[k][1]):
     w = wr.get(k, (0, 0.0))[1]
     out[k] = {"launches": n, "fetch_bytes_corrected": 2 * f * 1024, "write_bytes": w * 1024, "hbm_bytes": (2 * f + w) * 1024}
     print('%-90s n %5d  fetch %9.3f MB  write %9.3f MB' % (k[:90], n, 2 * f * 1024 / 1e6, w * 1024 / 1e6))
+# whole training step: everything but the one-off kernels (uploads, torch fills, the stream probe), per gather_batch launch
+steps = max([v["launches"] for k, v in out.items() if "gather_batch" in k] or [1])
+skip = ("nchw_to_nhwc", "at::native", "probe_", "__amd_rocclr_copyBuffer")
+tot = sum(v["launches"] * v["hbm_bytes"] for k, v in out.items() if not any(x in k for x in skip))
+out["__per_step__"] = {"steps": steps, "hbm_bytes": tot / steps}
+print('per training step (%d steps): %.1f MB' % (steps, tot / steps / 1e6))
 if len(sys.argv) > 3:
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
