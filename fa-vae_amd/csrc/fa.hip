@@ -507,15 +507,22 @@ extern "C" int favae_fa_rows_gemm(const double* X, int ldx, int d, const double*
                                   const double* base, int ldbase, double beta, double* out, int ldo, long long N, int accumulate,
                                   void* stream) {
     FAVAE_CHECK_ARG(X && P && out && N > 0 && d > 0 && K > 0, "favae_fa_rows_gemm: bad argument");
-    FAVAE_CHECK_ARG(K <= 16 * MAXTJ, "favae_fa_rows_gemm: K = %d exceeds %d", K, 16 * MAXTJ);
-    const int nt = cdiv(K, 16);
     dim3 grid((unsigned)cdivll(N, 64)), block(256);
-#define RG_CASE(n) case n: hipLaunchKernelGGL(rows_gemm_kernel<n>, grid, block, 0, ST, X, ldx, d, P, ldp, K, c, alpha, base, ldbase, beta, out, ldo, N, accumulate); break;
-    switch (nt) {
-        RG_CASE(1) RG_CASE(2) RG_CASE(3) RG_CASE(4) RG_CASE(5) RG_CASE(6) RG_CASE(7) RG_CASE(8) RG_CASE(9) RG_CASE(10) RG_CASE(11) RG_CASE(12) RG_CASE(13)
-    }
+    // a wave holds 16 rows x up to 13 column tiles in registers; wider outputs (the FA prior of a 512-dimensional latent)
+    // run as column panels of 208
+    for (int k0 = 0; k0 < K; k0 += 16 * MAXTJ) {
+        const int Kp = std::min(K - k0, 16 * MAXTJ), nt = cdiv(Kp, 16);
+        const double* Pp = P + k0;
+        const double* cp = c ? c + k0 : nullptr;
+        const double* bp = base ? base + k0 : nullptr;
+        double* op = out + k0;
+#define RG_CASE(n) case n: hipLaunchKernelGGL(rows_gemm_kernel<n>, grid, block, 0, ST, X, ldx, d, Pp, ldp, Kp, cp, alpha, bp, ldbase, beta, op, ldo, N, accumulate); break;
+        switch (nt) {
+            RG_CASE(1) RG_CASE(2) RG_CASE(3) RG_CASE(4) RG_CASE(5) RG_CASE(6) RG_CASE(7) RG_CASE(8) RG_CASE(9) RG_CASE(10) RG_CASE(11) RG_CASE(12) RG_CASE(13)
+        }
 #undef RG_CASE
-    FAVAE_LAUNCH_CHECK();
+        FAVAE_LAUNCH_CHECK();
+    }
     return FAVAE_OK;
 }
 

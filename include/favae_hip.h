@@ -350,7 +350,7 @@ int favae_fa_atb(const double* A, int lda, int da, const double* B, int ldb, int
  * one GPU (two streams) race; calls on one stream, or on different GPUs, do not. */
 int favae_fa_atb_static(const double* A, int lda, int da, const double* B, int ldb, int db, int ones, long long N, double* C,
                         void* stream);
-/* out[N][K] = alpha (X[N][d] P[d][K] + c[K]) + beta base[N][K]; accumulate=1: out += alpha X P.  K <= 208.
+/* out[N][K] = alpha (X[N][d] P[d][K] + c[K]) + beta base[N][K]; accumulate=1: out += alpha X P (any K: column panels of 208).
  * q.Z['mean'] (cA/favae.py:986-987), the predictive means (:996-997), the FA prior Z W^T + b
  * (cA/celeba_deepvanilla_vae.py:209) and Z W^T + b of the multilabel update (cA/favae.py:1212). */
 int favae_fa_rows_gemm(const double* X, int ldx, int d, const double* P, int ldp, int K, const double* c, double alpha,

@@ -40,7 +40,7 @@ def test_atb_statistics(N, da, db, ones):
     assert np.array_equal(C, C2)
 
 
-@pytest.mark.parametrize("N,d,K", [(512, 20, 10), (2048, 40, 100), (20001, 50, 20), (100, 200, 40), (65, 3, 200)])
+@pytest.mark.parametrize("N,d,K", [(512, 20, 10), (2048, 40, 100), (20001, 50, 20), (100, 200, 40), (65, 3, 200), (300, 200, 512)])
 def test_rows_gemm(N, d, K):
     fa = _fa()
     rs = np.random.RandomState(d)
