@@ -1230,13 +1230,16 @@ __global__ void conv_out_wprep(const T* __restrict__ w, T* __restrict__ wk, int 
 }
 
 // sigmoid(raw) vs y: per-block partial (sum (y-s)^2, sum y, sum y^2), then one block adds them onto acc3
-__global__ __launch_bounds__(256) void sigmoid_sse(const float* __restrict__ raw, const float* __restrict__ y, size_t n,
+template <class YT>
+__global__ __launch_bounds__(256) void sigmoid_sse(const float* __restrict__ raw, const YT* __restrict__ y, size_t n,
                                                    double* __restrict__ partial) {
     __shared__ double sm[12];
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float s = 1.f / (1.f + expf(-raw[i]));
-        const double t = y[i], d = t - (double)s;
+        double t;
+        if constexpr (sizeof(YT) == 1) t = (double)((float)y[i] / 255.f); else t = (double)y[i];
+        const double d = t - (double)s;
         a0 += d * d; a1 += t; a2 += t * t;
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
@@ -1434,6 +1437,39 @@ __global__ __launch_bounds__(256) void gather_batch(const float* __restrict__ da
         if (xf) ((float4*)xf)[i] = v;
         if (xt) store4<T>(xt + i * 4, v.x, v.y, v.z, v.w);
     }
+}
+
+// the same from a uint8 resident data set (pixel value k stands for k / 255, exactly what torchvision's ToTensor makes of an
+// 8-bit image: a correctly rounded fp32 division)
+template <class T>
+__global__ __launch_bounds__(256) void gather_batch_u8(const unsigned char* __restrict__ data, const int* __restrict__ idx, int B,
+                                                       size_t row4, float* __restrict__ xf, T* __restrict__ xt) {
+    const size_t total = (size_t)B * row4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / row4, j = i - b * row4;
+        const size_t src = (size_t)(idx ? idx[b] : (int)b) * row4 + j;
+        const uchar4 u = ((const uchar4*)data)[src];
+        const float4 v = make_float4((float)u.x / 255.f, (float)u.y / 255.f, (float)u.z / 255.f, (float)u.w / 255.f);
+        if (xf) ((float4*)xf)[i] = v;
+        if (xt) store4<T>(xt + i * 4, v.x, v.y, v.z, v.w);
+    }
+}
+
+// fp32 NCHW -> uint8 NHWC, counting the values that are not exactly k / 255 (a data set with any such value stays fp32)
+__global__ void nchw_to_nhwc_u8(const float* __restrict__ in, unsigned char* __restrict__ out, size_t N, int C, int HW,
+                                unsigned long long* __restrict__ mismatches) {
+    const size_t total = N * HW * C;
+    unsigned bad = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const size_t p = i / C, n = p / HW, hw = p - n * HW;
+        const float x = in[(n * C + c) * HW + hw];
+        const float k = rintf(x * 255.f);
+        const bool ok = k >= 0.f && k <= 255.f && k / 255.f == x;
+        out[i] = ok ? (unsigned char)k : 0;
+        bad += ok ? 0u : 1u;
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 
 template <class T>
@@ -1840,16 +1876,25 @@ extern "C" int favae_conv_out_ll(const void* act, const void* wk, const float* b
     return FAVAE_OK;
 }
 
-extern "C" int favae_sigmoid_sse(const float* raw, const float* y, long long n, double* acc3, double* scratch,
-                                 size_t scratch_doubles, void* stream) {
+static int sigmoid_sse_impl(const float* raw, const void* y, int y_u8, long long n, double* acc3, double* scratch, size_t scratch_doubles,
+                            void* stream) {
     FAVAE_CHECK_ARG(raw && y && acc3 && scratch && n > 0, "favae_sigmoid_sse: bad argument");
     const int grid = (int)std::min<size_t>(1024, ((size_t)n + 255) / 256);
     FAVAE_CHECK_ARG((size_t)3 * grid <= scratch_doubles, "favae_sigmoid_sse: scratch too small");
-    hipLaunchKernelGGL(sigmoid_sse, dim3(grid), dim3(256), 0, ST, raw, y, (size_t)n, scratch);
+    if (y_u8) hipLaunchKernelGGL(sigmoid_sse<unsigned char>, dim3(grid), dim3(256), 0, ST, raw, (const unsigned char*)y, (size_t)n, scratch);
+    else hipLaunchKernelGGL(sigmoid_sse<float>, dim3(grid), dim3(256), 0, ST, raw, (const float*)y, (size_t)n, scratch);
     FAVAE_LAUNCH_CHECK();
     hipLaunchKernelGGL(sse_finish, dim3(1), dim3(64), 0, ST, scratch, grid, acc3);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
+}
+extern "C" int favae_sigmoid_sse(const float* raw, const float* y, long long n, double* acc3, double* scratch,
+                                 size_t scratch_doubles, void* stream) {
+    return sigmoid_sse_impl(raw, y, 0, n, acc3, scratch, scratch_doubles, stream);
+}
+extern "C" int favae_sigmoid_sse_u8(const float* raw, const unsigned char* y, long long n, double* acc3, double* scratch,
+                                    size_t scratch_doubles, void* stream) {
+    return sigmoid_sse_impl(raw, y, 1, n, acc3, scratch, scratch_doubles, stream);
 }
 
 extern "C" int favae_sigmoid(const float* raw, float* out, long long n, void* stream) {
@@ -1963,6 +2008,27 @@ extern "C" int favae_gather_batch(const float* data, const int* idx, int B, long
         hipLaunchKernelGGL(gather_batch<float>, dim3(grid), dim3(256), 0, ST, data, idx, B, row4, x_f32, (float*)x_t);
     else
         hipLaunchKernelGGL(gather_batch<bf16_t>, dim3(grid), dim3(256), 0, ST, data, idx, B, row4, x_f32, (bf16_t*)x_t);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_gather_batch_u8(const unsigned char* data, const int* idx, int B, long long row_elems, float* x_f32, void* x_t,
+                                     int dtype, void* stream) {
+    FAVAE_CHECK_ARG(data && B > 0 && row_elems > 0 && row_elems % 4 == 0 && (x_f32 || x_t), "favae_gather_batch_u8: bad argument");
+    const size_t row4 = (size_t)row_elems / 4;
+    const int grid = ew_grid((size_t)B * row4);
+    if (dtype == FAVAE_F32)
+        hipLaunchKernelGGL(gather_batch_u8<float>, dim3(grid), dim3(256), 0, ST, data, idx, B, row4, x_f32, (float*)x_t);
+    else
+        hipLaunchKernelGGL(gather_batch_u8<bf16_t>, dim3(grid), dim3(256), 0, ST, data, idx, B, row4, x_f32, (bf16_t*)x_t);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_nchw_to_nhwc_u8(const float* in, unsigned char* out, long long N, int C, int HW, unsigned long long* mismatches,
+                                     void* stream) {
+    FAVAE_CHECK_ARG(in && out && mismatches && N > 0 && C > 0 && HW > 0, "favae_nchw_to_nhwc_u8: bad argument");
+    hipLaunchKernelGGL(nchw_to_nhwc_u8, dim3(ew_grid((size_t)N * HW * C)), dim3(256), 0, ST, in, out, (size_t)N, C, HW, mismatches);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

@@ -185,6 +185,7 @@ struct Vae {
     // BatchNorm + LeakyReLU of a layer applied in the operand load of the next convolution (favae_conv_igemm_bn_in): the main
     // chain has no launch between the two GEMMs; the activation the backward pass reads (weight gradient of the next layer,
     // LeakyReLU slopes) is materialised on the weight-gradient stream, which is idle during the forward pass
+    bool data_u8;   // the resident data set handed to the step / encode / reconstruction calls is uint8 (favae_vae_set_data_u8)
     bool eval_fused, eval_ab_ready;   // eval-mode BatchNorm in the GEMM epilogues (large-batch eval executor); ab[] holds the running-stat form
     float* ab[NL]; bool act_deferred[NL]; bool bn_published[NL]; bool fi_on; int fi_pend[NL], fi_npend, fi_flushes; hipEvent_t ev_fi[2], ev_acts; bool acts_wait;
     char* shp(int half) const { return SH + (size_t)half * sh_half; }
@@ -356,6 +357,13 @@ int ensure_streams(Vae& v, hipStream_t main) {
 template <class F> int side_do(Vae& v, F&& f);   // (defined with the enqueue worker's users below)
 
 // fi >= 0: the input is raw[fi], the output of layer fi before its BatchNorm + LeakyReLU, applied in the operand load
+// rows idx[b] of the resident data set (fp32 or uint8 NHWC) -> fp32 batch and / or dtype batch
+int gather(const Vae& v, const float* data, const int* idx, int B, float* xf, void* xt, void* st) {
+    const long long row = (long long)64 * 64 * v.ch;
+    if (v.data_u8) return favae_gather_batch_u8((const unsigned char*)data, idx, B, row, xf, xt, v.dtype, st);
+    return favae_gather_batch(data, idx, B, row, xf, xt, v.dtype, st);
+}
+
 int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false, int fi = -1) {
     const Layer& L = v.L[l];
     const float* bias = v.P + L.b_off;
@@ -713,6 +721,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.wk = nullptr;
     v.eval_fused = batch_max >= 256 && !(getenv("FAVAE_EVAL_FUSED") && getenv("FAVAE_EVAL_FUSED")[0] == '0');
     v.eval_ab_ready = false;
+    v.data_u8 = false;
     v.fi_on = false; v.fi_npend = 0; v.fi_flushes = 0; v.acts_wait = false;
     for (int l = 0; l < NL; ++l) v.act_deferred[l] = v.bn_published[l] = false;
     v.join_pending = false;
@@ -751,6 +760,12 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
         }
     }
     *out = h;
+    return FAVAE_OK;
+}
+
+extern "C" int favae_vae_set_data_u8(favae_vae* h, int on) {
+    FAVAE_CHECK_ARG(h, "favae_vae_set_data_u8: null handle");
+    h->v.data_u8 = on != 0;
     return FAVAE_OK;
 }
 
@@ -837,7 +852,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
                 // behind the previous step's last reader of the zero pool (BN backward of encoder.0), not behind its tail
                 FAVAE_HIP(hipStreamWaitEvent(v.side, jp ? v.ev_fork[0] : v.ev_x, 0));
                 FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, v.side));
-                RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, xf, xt, v.dtype, (void*)v.side));
+                RC(gather(v, data_nhwc, idx, B, xf, xt, (void*)v.side));
                 FAVAE_HIP(hipEventRecord(v.ev_batch, v.side));
                 RC(favae_conv_fold_taps(xt, fold0, v.fold0_bytes, B, 32, 32, 64, 64, v.ch, 2, 0, v.dtype, (void*)v.side));
                 FAVAE_HIP(hipEventRecord(v.ev_fold, v.side));
@@ -852,7 +867,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             if (!epoch) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));
             FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, (hipStream_t)st));
             if (epoch) { std::swap(v.xf, v.xf_alt); std::swap(v.xt, v.xt_alt); }
-            RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, v.xf, v.xt, v.dtype, st));
+            RC(gather(v, data_nhwc, idx, B, v.xf, v.xt, st));
             if (can_fold) {
                 // encoder.0's weight gradient ends the step: its tap gather needs the batch only, so it runs now, on the
                 // weight-gradient stream (idle during the forward pass; in order behind the previous step's last reader of fold0)
@@ -1186,7 +1201,7 @@ extern "C" int favae_vae_encode(favae_vae* h, const float* data_nhwc, const int*
     FAVAE_CHECK_ARG(h && data_nhwc && xmean && xcov, "favae_vae_encode: null pointer");
     Vae& v = h->v;
     FAVAE_CHECK_ARG(B > 0 && B <= v.Bmax, "favae_vae_encode: batch");
-    RC(favae_gather_batch(data_nhwc, idx, B, (long long)64 * 64 * v.ch, nullptr, v.xt, v.dtype, st));
+    RC(gather(v, data_nhwc, idx, B, nullptr, v.xt, st));
     RC(encoder_fwd(v, B, train != 0, st));
     return favae_encode_head(v.raw[L_FC], B, v.z, xmean, xcov, st);
 }
@@ -1201,7 +1216,8 @@ extern "C" int favae_vae_encode_all(favae_vae* h, const float* data_nhwc, long l
     int rc = FAVAE_OK;
     for (long long o = 0; o < n && rc == FAVAE_OK; o += batch) {
         const int B = (int)std::min<long long>(batch, n - o);
-        rc = favae_vae_encode(h, data_nhwc + o * row, nullptr, B, xmean + o * v.z, xcov + o * v.z, 0, st);
+        const float* rows = v.data_u8 ? (const float*)((const unsigned char*)data_nhwc + o * row) : data_nhwc + o * row;
+        rc = favae_vae_encode(h, rows, nullptr, B, xmean + o * v.z, xcov + o * v.z, 0, st);
         v.eval_ab_ready = v.eval_fused;
     }
     v.eval_ab_ready = false;
@@ -1233,7 +1249,10 @@ extern "C" int favae_vae_reconstruct_stats(favae_vae* h, const float* zin, const
         rc = favae_cast(zin + o * v.z, v.zlat, (long long)B * v.z, v.dtype, st);
         if (rc == FAVAE_OK) rc = decoder_fwd(v, B, false, st);
         v.eval_ab_ready = v.eval_fused;
-        if (rc == FAVAE_OK) rc = favae_sigmoid_sse(v.raw[L_OUT], data_nhwc + o * row, (long long)B * row, acc3, v.scratch, v.scratch_doubles, st);
+        if (rc == FAVAE_OK)
+            rc = v.data_u8 ? favae_sigmoid_sse_u8(v.raw[L_OUT], (const unsigned char*)data_nhwc + o * row, (long long)B * row, acc3, v.scratch,
+                                                  v.scratch_doubles, st)
+                           : favae_sigmoid_sse(v.raw[L_OUT], data_nhwc + o * row, (long long)B * row, acc3, v.scratch, v.scratch_doubles, st);
     }
     v.eval_ab_ready = false;
     return rc;

@@ -19,6 +19,7 @@ np.random.seed(0)
 
 class ImgVAE(_ImgVAE):
     PRIOR, FORCE_BETA_ONE, ALWAYS_FA_PRIOR, UPDATE_X_USES_SELF_IMG = "sampled", False, True, True   # :140-155, :244
+    CHECKPOINT_INFIX = "8"                                                                         # :226
 
     def trainloop(self, img=None, Z=None, W=None, b=None, tau=None, epochs=20, beta=1, wandb=None):
         return super().trainloop(img=img, Z=Z, W=W, b=b, tau=tau, epochs=epochs, wandb=wandb, favae=True, beta=beta)

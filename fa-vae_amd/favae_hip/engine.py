@@ -195,13 +195,30 @@ class VaeEngine:
     def refresh_weights(self):
         L.check(_raw.favae_vae_refresh_weights(self.h, L.stream_ptr()))
 
-    def upload_images(self, img_nchw):
-        """float32 NCHW numpy / CPU tensor -> resident fp32 NHWC device tensor (chunked so host memory stays flat)."""
+    def upload_images(self, img_nchw, allow_u8=None):
+        """float32 NCHW numpy / CPU tensor -> resident NHWC device tensor (chunked so host memory stays flat).  8-bit images
+        (every value exactly k / 255, what torchvision's ToTensor produces) stay resident as uint8 -- a quarter of the HBM,
+        bit-identical batches (favae_gather_batch_u8); anything else as fp32.  FAVAE_DATA_U8=0 forces fp32."""
+        import os
         t = torch.from_numpy(img_nchw) if isinstance(img_nchw, np.ndarray) else img_nchw
         N, C, H, W = t.shape
         assert (H, W) == (64, 64) and C == self.ch, "the executor is built for %dx64x64 images" % self.ch
-        out = torch.empty(N, H, W, C, dtype=torch.float32, device=self.dev)
+        if allow_u8 is None:
+            allow_u8 = os.environ.get("FAVAE_DATA_U8", "1") != "0"
         chunk = 8192
+        if allow_u8:
+            out = torch.empty(N, H, W, C, dtype=torch.uint8, device=self.dev)
+            bad = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            for s in range(0, N, chunk):
+                src = t[s:s + chunk].to(torch.float32).contiguous().to(self.dev)
+                L.check(_raw.favae_nchw_to_nhwc_u8(L.ptr(src), ctypes.c_void_p(out[s:].data_ptr()), _ll(src.shape[0]), _i(C), _i(H * W),
+                                                   L.ptr(bad), L.stream_ptr()))
+                if s == 0 and int(bad.item()):        # the first chunk decides for data that is not 8-bit at all
+                    break
+            if int(bad.item()) == 0:
+                return out
+            del out
+        out = torch.empty(N, H, W, C, dtype=torch.float32, device=self.dev)
         for s in range(0, N, chunk):
             src = t[s:s + chunk].to(torch.float32).contiguous().to(self.dev)
             L.check(_raw.favae_nchw_to_nhwc(L.ptr(src), ctypes.c_void_p(out[s:].data_ptr()), _ll(src.shape[0]), _i(C),
@@ -209,8 +226,13 @@ class VaeEngine:
         torch.cuda.current_stream().synchronize()
         return out
 
+    def _fmt(self, data, h=None):
+        """Tell the executor whether the data set it is about to read is uint8 or fp32."""
+        L.check(_raw.favae_vae_set_data_u8(self.h if h is None else h, _i(1 if data.dtype == torch.uint8 else 0)))
+
     def train_fwdbwd(self, data, idx, B, eps, prior, tau, beta, var_x, metrics=None):
         m = self.metrics if metrics is None else metrics
+        self._fmt(data)
         L.check(_raw.favae_vae_train_fwdbwd(self.h, L.ptr(data), L.ptr(idx), _i(B), L.ptr(eps), L.ptr(prior), _f(tau),
                                             _f(beta), _f(var_x), L.ptr(m), L.stream_ptr()))
         return m
@@ -219,6 +241,7 @@ class VaeEngine:
 
     def train_stages(self, data, idx, B, eps, prior, tau, beta, var_x, metrics, lo, hi):
         """The step of train_fwdbwd in pieces (favae_vae_train_stages): forward with lo == 0, backward stages [lo, hi)."""
+        self._fmt(data)
         L.check(_raw.favae_vae_train_stages(self.h, L.ptr(data), L.ptr(idx), _i(B), L.ptr(eps), L.ptr(prior), _f(tau),
                                             _f(beta), _f(var_x), L.ptr(metrics), _i(lo), _i(hi), L.stream_ptr()))
 
@@ -239,6 +262,7 @@ class VaeEngine:
 
     def train_epoch(self, data, perm, eps, prior, tau, beta, var_x, lr, batch, metrics):
         n = perm.numel()
+        self._fmt(data)
         L.check(_raw.favae_vae_train_epoch(self.h, L.ptr(data), L.ptr(perm), _ll(n), _i(batch), L.ptr(eps), L.ptr(prior),
                                            _f(tau), _f(beta), _f(var_x), _f(lr), _ll(self.step), L.ptr(metrics),
                                            L.stream_ptr()))
@@ -247,17 +271,20 @@ class VaeEngine:
     def train_epoch_dp(self, comm, data, perm, eps, prior, tau, beta, var_x, lr, batch, metrics):
         """One data-parallel epoch in one call: bucketed gradient all-reduce + bucket-wise Adam on the communicator's stream."""
         n = perm.numel()
+        self._fmt(data)
         L.check(_raw.favae_vae_train_epoch_dp(self.h, comm, L.ptr(data), L.ptr(perm), _ll(n), _i(batch), L.ptr(eps), L.ptr(prior),
                                               _f(tau), _f(beta), _f(var_x), _f(lr), _ll(self.step), L.ptr(metrics),
                                               L.stream_ptr()))
         self.step += (n + batch - 1) // batch
 
     def encode(self, data, idx, B, xmean, xcov, train=False):
+        self._fmt(data)
         L.check(_raw.favae_vae_encode(self.h, L.ptr(data), L.ptr(idx), _i(B), ctypes.c_void_p(xmean.data_ptr()),
                                       ctypes.c_void_p(xcov.data_ptr()), _i(int(train)), L.stream_ptr()))
 
     def encode_all(self, data, xmean, xcov, batch=64):
         """update_x over a resident data set; `batch` is the reference's loader batch, the eval executor uses its own."""
+        self._fmt(data, self._eval_handle())
         L.check(_raw.favae_vae_encode_all(self._eval_handle(), L.ptr(data), _ll(data.shape[0]), _i(max(batch, self.eval_batch)),
                                           L.ptr(xmean), L.ptr(xcov), L.stream_ptr()))
 
@@ -266,6 +293,7 @@ class VaeEngine:
                                       _i(int(train)), L.stream_ptr()))
 
     def reconstruct_stats(self, zin, data, acc3, batch=64):
+        self._fmt(data, self._eval_handle())
         L.check(_raw.favae_vae_reconstruct_stats(self._eval_handle(), L.ptr(zin), L.ptr(data), _ll(zin.shape[0]),
                                                  _i(max(batch, self.eval_batch)), L.ptr(acc3), L.stream_ptr()))
 

@@ -61,6 +61,11 @@ class ImgVAE(VAE):
     ALWAYS_FA_PRIOR = False     # celeba2cartoon: trainloop has no `favae` flag, the FA prior is always used
     UPDATE_X_USES_SELF_IMG = False   # celeba2cartoon/betaVAE iterate self.img whatever `img` is (:244)
     BATCH = 64                  # DataLoader(batch_size=64), :218
+    CHECKPOINT_INFIX = "_celeba_vanilla_"   # file name of restore_weights' checkpoint (:308-314); celeba2cartoon uses "8"
+    # restore_weights keeps its best-ELBO checkpoint on the device; with write_checkpoints the file the reference writes
+    # (./checkpoints/<dataset><infix><latentspace_lr>.pt, {epoch, elbo, state_dict, optimizer}) is also written, once per
+    # trainloop (150 MB device -> host + serialisation, hence opt-in; FAVAE_WRITE_CHECKPOINTS=1 turns it on globally)
+    write_checkpoints = os.environ.get("FAVAE_WRITE_CHECKPOINTS") == "1"
 
     def __init__(self, dimx=2, channels=1, var_x=0.01, lr=1e-5, h=None, w=None, dataset=None, latentspace_lr=1,
                  precision=None):
@@ -330,10 +335,12 @@ class ImgVAE(VAE):
                            str(self.dataset) + " Gaussian LogLikelihood": float(-self.reconstruc_during_training[-1]),
                            str(self.dataset) + " KL(Q||P)": float(self.KL_QandP[-1])})
         self.training = True
-        if self.defer_pull:
+        if self.defer_pull and not self.write_checkpoints:
             self._stale = True
         else:
             self._pull()
+        if self.write_checkpoints and self.elbo_training and dist.rank() == 0:
+            self.save_checkpoint()
         if not self.elbo_training:
             return True
         return abs(1 - np.mean(self.elbo_training[-10:]) / self.elbo_training[-1]) > 1e-4
@@ -349,6 +356,39 @@ class ImgVAE(VAE):
             eng.restore(self._ckp["snap"])
             elbo_checker = self._ckp["elbo"]
         return elbo_checker
+
+    # ---- the reference's checkpoint file (:300-314, 319-328) ----------------------------------------------------
+    def checkpoint_path(self):
+        return "./checkpoints/" + str(self.dataset) + self.CHECKPOINT_INFIX + str(self.latentspace_lr) + ".pt"
+
+    def save_checkpoint(self, path=None, epoch=None, elbo=None):
+        """Write the current model + optimiser state in the layout of the reference's restore_weights file
+        ({"epoch", "elbo", "state_dict", "optimizer"}); `elbo` is stored as a Python float so that the file loads with
+        torch.load(weights_only=True).  After a trainloop the current state IS the best-ELBO state (every worse epoch was
+        rolled back), i.e. what the reference's file holds."""
+        path = self.checkpoint_path() if path is None else path
+        self.sync()
+        d = os.path.dirname(path)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        ck = getattr(self, "_ckp", None) or {}
+        elbo = float(elbo if elbo is not None else ck.get("elbo", self.elbo_training[-1] if self.elbo_training else float("nan")))
+        epoch = int(epoch if epoch is not None else ck.get("epoch", len(self.elbo_training)))
+        torch.save({"epoch": epoch, "elbo": elbo, "state_dict": {k: v.detach().cpu() for k, v in self.state_dict().items()},
+                    "optimizer": self.optim.state_dict()}, path)
+        return path
+
+    def load_checkpoint(self, path=None):
+        """Load a restore_weights file (written by this build or by the reference's ImgVAE: same keys) into the module, the
+        torch optimiser and -- at the next use -- the executor.  Tensors only: a file whose `elbo` is a pickled NumPy scalar
+        (the reference stores np.float64) is refused by weights_only=True; re-save it with elbo=float(elbo) first."""
+        path = self.checkpoint_path() if path is None else path
+        ckp = torch.load(path, map_location="cpu", weights_only=True)
+        self.load_state_dict(ckp["state_dict"])
+        self.optim.load_state_dict(ckp["optimizer"])
+        self._synced_version = None
+        self._stale = False
+        return ckp["epoch"], ckp["elbo"]
 
     # ---- update_x (:331-358) ----------------------------------------------------------------------------------
     def update_x(self, img=None):

@@ -228,6 +228,8 @@ int favae_conv_out_ll(const void* act, const void* wk, const float* bias, const 
                       float var_x, float* raw, void* draw, double* rec_err, float* dbias, double* scratch,
                       size_t scratch_doubles, int dtype, void* stream);
 int favae_sigmoid(const float* raw, float* out, long long n, void* stream);
+int favae_sigmoid_sse_u8(const float* raw, const unsigned char* y, long long n, double* acc3, double* scratch,
+                         size_t scratch_doubles, void* stream);
 /* acc3 += (sum (y - sigmoid(raw))^2, sum y, sum y^2). scratch >= 3*1024 doubles. */
 int favae_sigmoid_sse(const float* raw, const float* y, long long n, double* acc3, double* scratch, size_t scratch_doubles,
                       void* stream);
@@ -258,6 +260,13 @@ int favae_weight_prep(const float* w, void* w_copy, void* w_transposed, int Co, 
 /* rows idx[b] of the resident fp32 NHWC dataset -> fp32 batch and/or dtype batch (DataLoader batch, :227-229). */
 int favae_gather_batch(const float* data, const int* idx, int B, long long row_floats, float* x_f32, void* x_t, int dtype,
                        void* stream);
+/* The same from a uint8 resident data set [N][row_elems] (NHWC): value k stands for k / 255 as a correctly rounded fp32
+ * division, i.e. what torchvision's ToTensor makes of an 8-bit image (the trainers' loader, cA/favae_trainer.py:21-28). */
+int favae_gather_batch_u8(const unsigned char* data, const int* idx, int B, long long row_elems, float* x_f32, void* x_t, int dtype,
+                          void* stream);
+/* fp32 NCHW -> uint8 NHWC; *mismatches += the number of values that are not exactly k / 255 (then the data set stays fp32). */
+int favae_nchw_to_nhwc_u8(const float* in, unsigned char* out, long long N, int C, int HW, unsigned long long* mismatches,
+                          void* stream);
 int favae_cast(const float* in, void* out, long long n, int dtype, void* stream);
 int favae_nchw_to_nhwc(const float* in, float* out, long long N, int C, int HW, int Cpad, void* stream);
 int favae_nhwc_to_nchw_f64(const float* in, double* out, long long N, int C, int HW, int Cpad, void* stream);
@@ -281,6 +290,9 @@ int favae_vae_create(favae_vae** out, int z, int channels, int batch_max, int dt
                      float* adam_m, float* adam_v, float* bn_buffers, void* shadow, size_t shadow_bytes, void* workspace,
                      size_t workspace_bytes);
 int favae_vae_destroy(favae_vae* h);
+/* on != 0: the data_nhwc arguments of the calls below are uint8 NHWC arrays (value k = k / 255, see favae_gather_batch_u8)
+ * instead of fp32: a quarter of the HBM residency (2.5 instead of 10 GB at N = 202 599), identical arithmetic for 8-bit images. */
+int favae_vae_set_data_u8(favae_vae* h, int on);
 int favae_vae_refresh_weights(favae_vae* h, void* stream);
 /* forward + loss + backward of one mini-batch (:229-249); metrics2_out (device) = (reconstruction_error, kl_div). */
 int favae_vae_train_fwdbwd(favae_vae* h, const float* data_nhwc, const int* idx, int B, const float* eps,

@@ -200,3 +200,53 @@ def test_two_rank_sharded_statistics_match_unsharded():
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+def test_checkpoint_file_round_trips_with_the_oracle(tmp_path):
+    """The restore_weights file of the reference (cA/celeba_deepvanilla_vae.py:300-314: {epoch, elbo, state_dict, optimizer} at
+    ./checkpoints/<dataset>_celeba_vanilla_<latentspace_lr>.pt): a file written by ImgVAE.save_checkpoint loads into the
+    oracle's module + torch optimiser, a file written from the oracle's state loads into ImgVAE; tensors only
+    (torch.load(weights_only=True)).  No GPU: the nn.Module / torch.optim side of ImgVAE is what the file is made from."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from favae_hip.imgvae import ImgVAE
+    from oracle import vae_torch as vt
+    torch.manual_seed(3)
+    vae = ImgVAE(dimx=8, channels=3, lr=1e-3, h=64, w=64, dataset="ck", latentspace_lr=0.5)
+    assert vae.checkpoint_path() == "./checkpoints/ck_celeba_vanilla_0.5.pt"
+    g = torch.Generator().manual_seed(1)
+    for i, p in enumerate(vae.parameters()):                      # an optimiser state as after 7 steps
+        vae.optim.state[p] = {"step": torch.tensor(7.0), "exp_avg": torch.randn(p.shape, generator=g) * 1e-3,
+                              "exp_avg_sq": torch.rand(p.shape, generator=g) * 1e-6}
+    vae.elbo_training = [-123.5]
+    path = vae.save_checkpoint(str(tmp_path / "a.pt"), epoch=4)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(ck) == {"epoch", "elbo", "state_dict", "optimizer"} and ck["epoch"] == 4 and ck["elbo"] == -123.5
+    ref = vt.OracleImgVAE(dimx=8, channels=3, lr=1e-3, dataset="ck")
+    assert set(ref.state_dict()) <= set(ck["state_dict"])          # same parameter / buffer names as the reference module
+    ref.load_state_dict(ck["state_dict"])
+    ref.optim.load_state_dict(ck["optimizer"])
+    mine = vae.state_dict()
+    for k, v in ref.state_dict().items():
+        assert torch.equal(v, mine[k]), k
+    for p_ref, p_mine in zip([ref.P[k] for k in ref.names], vae.parameters()):
+        assert torch.equal(ref.optim.state[p_ref]["exp_avg"], vae.optim.state[p_mine]["exp_avg"])
+        assert float(ref.optim.state[p_ref]["step"]) == 7.0
+    # the other way: the oracle's state written in the reference layout
+    torch.manual_seed(5)
+    ref2 = vt.OracleImgVAE(dimx=8, channels=3, lr=1e-3, dataset="ck")
+    for k in ref2.names:
+        ref2.optim.state[ref2.P[k]] = {"step": torch.tensor(2.0), "exp_avg": torch.full_like(ref2.P[k], 0.25),
+                                       "exp_avg_sq": torch.full_like(ref2.P[k], 0.5)}
+    sd = ref2.state_dict()
+    torch.save({"epoch": 2, "elbo": -1.0, "state_dict": sd, "optimizer": ref2.optim.state_dict()}, str(tmp_path / "b.pt"))
+    ep, elbo = vae.load_checkpoint(str(tmp_path / "b.pt"))
+    assert (ep, elbo) == (2, -1.0)
+    now = vae.state_dict()
+    for k, v in ref2.state_dict().items():
+        assert torch.equal(v, now[k]), k
+    p0 = next(iter(vae.parameters()))
+    assert float(vae.optim.state[p0]["step"]) == 2.0 and float(vae.optim.state[p0]["exp_avg"].flatten()[0]) == 0.25
+    sys.path.insert(0, os.path.join(PKG, "domain_adaptation"))
+    import celeba2cartoon_vae
+    assert celeba2cartoon_vae.ImgVAE(dimx=8, channels=3, dataset="d", latentspace_lr=1).checkpoint_path() == "./checkpoints/d81.pt"

@@ -287,6 +287,55 @@ def test_epoch_with_batchnorm_applied_in_the_consumer_loads(dtype):
         assert _rel(out["0x4017b"][1][k].numpy(), out["0x17b"][1][k].numpy()) <= 5e-2, k
 
 
+def test_uint8_resident_data_set_equals_fp32_resident():
+    """8-bit images (values k / 255, what the trainers' ToTensor loader yields) stay resident as uint8: a quarter of the HBM.
+    The gathered batches are bit-identical to those of the fp32 copy (correctly rounded k / 255 on the device), so a training
+    step, update_x and the reconstruction statistics agree to the last bits that split-K atomics leave open; data that is
+    not 8-bit stays fp32."""
+    import ctypes
+    from favae_hip import lib as L
+    z, Bn, N = 20, 64, 192
+    torch.manual_seed(0)
+    P, Bf = vt.init_state(z, 3)
+    sd = {k: v.detach().clone() for k, v in P.items()}
+    sd.update({k: v.clone() for k, v in Bf.items()})
+    img, _ = img_inputs(N)
+    img8 = (np.round(img * 255).astype(np.float32) / np.float32(255)).astype(np.float32)
+    eng = _engine(z, "f32")
+    eng.load_state_dict(sd)
+    assert eng.upload_images(img).dtype == torch.float32            # not 8-bit: stays fp32
+    d8, d32 = eng.upload_images(img8), eng.upload_images(img8, allow_u8=False)
+    assert d8.dtype == torch.uint8 and d32.dtype == torch.float32 and d8.shape == d32.shape
+    idx = torch.randperm(N, generator=torch.Generator().manual_seed(2))[:Bn].to(torch.int32).cuda()
+    row = 64 * 64 * 3
+    xa, xb = torch.empty(Bn, row, device="cuda"), torch.empty(Bn, row, device="cuda")
+    ta, tb = torch.empty(Bn, row, dtype=torch.bfloat16, device="cuda"), torch.empty(Bn, row, dtype=torch.bfloat16, device="cuda")
+    raw = L.raw()
+    L.check(raw.favae_gather_batch(L.ptr(d32), L.ptr(idx), ctypes.c_int(Bn), ctypes.c_longlong(row), L.ptr(xa), L.ptr(ta), ctypes.c_int(L.BF16), L.stream_ptr()))
+    L.check(raw.favae_gather_batch_u8(L.ptr(d8), L.ptr(idx), ctypes.c_int(Bn), ctypes.c_longlong(row), L.ptr(xb), L.ptr(tb), ctypes.c_int(L.BF16), L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(xa, xb) and torch.equal(ta, tb)
+    assert torch.equal(xa.cpu().reshape(Bn, 64, 64, 3), torch.from_numpy(img8).permute(0, 2, 3, 1)[idx.cpu().long()])
+    eps = torch.randn(Bn, z, generator=torch.Generator().manual_seed(3)).cuda()
+    prior = torch.from_numpy(np.random.RandomState(7).randn(N, z) * 0.5).cuda()
+    m32 = eng.train_fwdbwd(d32, idx, Bn, eps, prior, 1.7, 1.0, 0.01).cpu().numpy().copy()
+    g32 = eng.G.clone()
+    m8 = eng.train_fwdbwd(d8, idx, Bn, eps, prior, 1.7, 1.0, 0.01).cpu().numpy().copy()
+    assert np.allclose(m8, m32, rtol=1e-6)
+    assert _rel(eng.G.cpu().numpy(), g32.cpu().numpy()) <= 1e-3      # (two runs of the same step differ this much: atomics order, LeakyReLU kink)
+    eng.load_state_dict(sd)
+    mu8, var8 = torch.empty(N, z, dtype=torch.float64, device="cuda"), torch.empty(N, z, dtype=torch.float64, device="cuda")
+    mu32, var32 = torch.empty_like(mu8), torch.empty_like(var8)
+    eng.encode_all(d8, mu8, var8)
+    eng.encode_all(d32, mu32, var32)
+    assert _rel(mu8.cpu().numpy(), mu32.cpu().numpy()) <= 1e-5 and _rel(var8.cpu().numpy(), var32.cpu().numpy()) <= 1e-5
+    zin = torch.randn(N, z, generator=torch.Generator().manual_seed(4)).cuda()
+    a8, a32 = torch.zeros(3, dtype=torch.float64, device="cuda"), torch.zeros(3, dtype=torch.float64, device="cuda")
+    eng.reconstruct_stats(zin, d8, a8)
+    eng.reconstruct_stats(zin, d32, a32)
+    assert np.allclose(a8.cpu().numpy(), a32.cpu().numpy(), rtol=1e-6)
+
+
 def test_data_parallel_epoch_over_rccl_one_rank():
     """The multi-rank trainloop in a one-rank RCCL group (own process: it owns a process group): favae_vae_train_epoch_dp
     through the library's communicator and the torch.distributed fallback both reproduce the single-device epochs
