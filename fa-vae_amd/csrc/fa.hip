@@ -44,24 +44,31 @@ __global__ __launch_bounds__(64 * ATB_WAVES) void atb_kernel(const double* __res
     for (int a = 0; a < TI; ++a)
 #pragma unroll
         for (int b = 0; b < TJ; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-    for (long long n = n0 + 4 * wave; n < n1; n += 4 * ATB_WAVES) {
-        const long long r = n + lr;
-        const bool ok = r < n1;
-        double av[TI], bv[TJ];
+    // two 4-row steps per iteration: 16 independent 8-byte loads per lane in flight before the first MFMA (the kernel is a
+    // stream over A and B; what it needs is bytes in flight, not MFMA issue)
+    for (long long n = n0 + 8 * wave; n < n1; n += 8 * ATB_WAVES) {
+        double av[2][TI], bv[2][TJ];
 #pragma unroll
-        for (int a = 0; a < TI; ++a) {
-            const int i = i0 + a * 16 + lc;
-            av[a] = (ok && i < da) ? A[r * lda + i] : 0.0;
+        for (int u = 0; u < 2; ++u) {
+            const long long r = n + 4 * u + lr;
+            const bool ok = r < n1;
+#pragma unroll
+            for (int a = 0; a < TI; ++a) {
+                const int i = i0 + a * 16 + lc;
+                av[u][a] = (ok && i < da) ? A[r * lda + i] : 0.0;
+            }
+#pragma unroll
+            for (int b = 0; b < TJ; ++b) {
+                const int j = j0 + b * 16 + lc;
+                bv[u][b] = !ok ? 0.0 : (j < db ? B[r * ldb + j] : (j == db && ones ? 1.0 : 0.0));
+            }
         }
 #pragma unroll
-        for (int b = 0; b < TJ; ++b) {
-            const int j = j0 + b * 16 + lc;
-            bv[b] = !ok ? 0.0 : (j < db ? B[r * ldb + j] : (j == db && ones ? 1.0 : 0.0));
-        }
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int a = 0; a < TI; ++a)
+            for (int a = 0; a < TI; ++a)
 #pragma unroll
-            for (int b = 0; b < TJ; ++b) acc[a][b] = mfma_f64(av[a], bv[b], acc[a][b]);
+                for (int b = 0; b < TJ; ++b) acc[a][b] = mfma_f64(av[u][a], bv[u][b], acc[a][b]);
     }
     // C/D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
     double* out = partial + (size_t)blockIdx.x * da * dbp;
