@@ -199,7 +199,7 @@ def main():
     raw = lib.raw()
     for _ in range(a.warmup):
         one_iteration()
-    raw.favae_prof_enable(1, 17)     # coprime to the launches per step of every timed class (10 / 13 / 9 / 5 ...)
+    raw.favae_prof_enable(1, 257)    # prime: coprime to the launches per step of every timed class; ~0.4 % of the launches carry events
     fence()
     t0 = time.time()
     for _ in range(a.steps):
@@ -297,7 +297,7 @@ def main():
             "roofline": None if dom is None else {
                 "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
                 "frac": dom["tflops"] / peak, "traffic": pmc_traffic(dom["cls"], a.dtype),
-                "note": "dominant GEMM class by time. HIP events on the launch stream around every 17th launch inside the timed "
+                "note": "dominant GEMM class by time. HIP events on the launch stream around every 257th launch inside the timed "
                         "region (weight gradients run on a side stream next to the main chain, so their durations include that "
                         "overlap); achieved = algorithmic flops per launch (dense-tap convention) / mean launch duration; traffic = "
                         "mean HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes "

@@ -70,7 +70,8 @@ class VaeEngine:
         # eval-mode passes over a whole data set (update_x, reconstruction diagnostic) are independent per sample (BN uses
         # the running statistics), so they run through a second executor over the SAME parameters with a larger batch:
         # 512-image GEMMs fill the chip, 64-image ones do not
-        self.eval_batch = 512
+        import os
+        self.eval_batch = int(os.environ.get("FAVAE_EVAL_BATCH", "512"))
         self.h_eval = None
         self.workspace_eval = None
 

@@ -23,7 +23,7 @@ prior = torch.randn(N, z, dtype=torch.float64).cuda()
 nsteps = (N + 63) // 64
 metrics = torch.zeros(nsteps, 2, dtype=torch.float64, device='cuda')
 import os
-stream = torch.cuda.Stream() if os.environ.get('FAVAE_OWN_STREAM', '1') == '1' else torch.cuda.current_stream()
+stream = torch.cuda.Stream(priority=int(os.environ.get('FAVAE_MAIN_PRIO', '0'))) if os.environ.get('FAVAE_OWN_STREAM', '1') == '1' else torch.cuda.current_stream()
 torch.cuda.synchronize()
 torch.cuda.set_stream(stream)
 eng.train_epoch(data, perm, eps, prior, 1.5, 1.0, 0.01, 1e-3, 64, metrics)
