@@ -695,27 +695,29 @@ __global__ __launch_bounds__(RKF_THREADS) void reparam_kl_fwd(const float* __res
 // the GEMM dtype as the stand-alone path stores it) into LDS and produces 64 of the N output columns for all B rows with
 // K = z FMAs per output; block 0 also writes zlat / stdq and the KL term.  One launch instead of two on the main chain of
 // the training step, both of which are chains of dependent loads rather than work (K = 20).
-constexpr int RKD_ZMAX = 32;
-template <class T>
-__global__ __launch_bounds__(RKF_THREADS) void reparam_kl_decin(const float* __restrict__ fc, const float* __restrict__ eps,
+// Two instances: z <= 32 with RKF_THREADS threads (the headline latent sizes) and z <= 128 with 256 threads and the weight row
+// of the thread's column still in registers (the 100-dimensional latent of the DA / TL trainers).
+constexpr int RKD_ZMAX = 32, RKD_ZMAX_BIG = 128;
+template <class T, int ZMAX, int THREADS>
+__global__ __launch_bounds__(THREADS) void reparam_kl_decin(const float* __restrict__ fc, const float* __restrict__ eps,
                                                                  const double* __restrict__ prior, const int* __restrict__ idx,
                                                                  float tau, int B, int z, T* __restrict__ zlat,
                                                                  float* __restrict__ stdq, double* __restrict__ kl_out,
                                                                  const T* __restrict__ w, const float* __restrict__ bias,
                                                                  T* __restrict__ out, int N) {
     extern __shared__ float zs[];   // [B][z]
-    __shared__ double sm[RKF_THREADS / 64];
+    __shared__ double sm[THREADS / 64];
     const bool first = blockIdx.x == 0;
     const int n = blockIdx.x * 64 + (threadIdx.x & 63), bg = threadIdx.x >> 6;
     // the weight row and the bias of this thread's column travel while z is computed
-    float wr[RKD_ZMAX];
+    float wr[ZMAX];
 #pragma unroll
-    for (int k = 0; k < RKD_ZMAX; ++k) wr[k] = (k < z && n < N) ? to_f32<T>(w[(size_t)n * z + k]) : 0.f;
+    for (int k = 0; k < ZMAX; ++k) wr[k] = (k < z && n < N) ? to_f32<T>(w[(size_t)n * z + k]) : 0.f;
     const float bn = n < N ? bias[n] : 0.f;
     const double std_p = sqrt((double)(1.0f / tau));
     const double sp = fmin(fmax(std_p, 1e-6), 1e20);
     double acc = 0.0;
-    for (int i = threadIdx.x; i < B * z; i += RKF_THREADS) {
+    for (int i = threadIdx.x; i < B * z; i += THREADS) {
         const int b = i / z, k = i - b * z;
         const float mu = fc[b * 2 * z + k];
         const float lv = fc[b * 2 * z + z + k] + 1e-6f;
@@ -740,14 +742,14 @@ __global__ __launch_bounds__(RKF_THREADS) void reparam_kl_decin(const float* __r
     if (first && threadIdx.x == 0) {
         double t = 0.0;
 #pragma unroll
-        for (int q = 0; q < RKF_THREADS / 64; ++q) t += sm[q];
+        for (int q = 0; q < THREADS / 64; ++q) t += sm[q];
         *kl_out = t / B;
     }
     if (n >= N) return;
-    for (int b = bg; b < B; b += RKF_THREADS / 64) {
+    for (int b = bg; b < B; b += THREADS / 64) {
         float a = 0.f;
 #pragma unroll
-        for (int k = 0; k < RKD_ZMAX; ++k)
+        for (int k = 0; k < ZMAX; ++k)
             if (k < z) a = fmaf(zs[b * z + k], wr[k], a);
         out[(size_t)b * N + n] = from_f32<T>(a + bn);
     }
@@ -831,12 +833,21 @@ __global__ __launch_bounds__(RKB_THREADS) void reparam_kl_bwd_bias(const float* 
     reparam_bwd_bias_body<T, false>(fc, eps, prior, idx, stdq, dz, tau, beta, B, z, dfc, dbias, vals, part);
 }
 
+// LDS plan of decin_bwd_reparam<T, ZMAX>: phase 1 = ds [64][65] + ws [64][ZMAX+1] floats + colpart [16][64] doubles;
+// phase 2 (last block) = vals [B*2z <= VALS] floats + part [4][256] doubles
+template <int ZMAX> struct DecinBwdSmem {
+    static constexpr int VALS = ZMAX <= 32 ? RKB_MAX : 2 * RKB_MAX;
+    static constexpr int COLPART = ((64 * 65 + 64 * (ZMAX + 1)) * 4 + 15) / 16 * 16;
+    static constexpr int P1 = COLPART + 16 * 64 * 8, P2 = VALS * 4 + 4 * 256 * 8;
+    static constexpr int BYTES = P1 > P2 ? P1 : P2;
+};
+
 // Backward of decoder_input (:41-45) and of the reparameterisation in one launch (the middle of the backward pass is a chain
 // of latency-bound launches).  Block j owns 64 of the N columns for all B rows: it stores the dtype copy of the incoming
 // gradient (operand of the weight gradient), sums its columns (bias gradient, fixed order), and adds its share of
 // dz = d @ W (fp32 atomics into the zeroed dz, as the split-K GEMM did); the block that takes the last ticket then has the
 // complete dz and runs the reparameterisation / KL backward + the bias gradient of the encoder head.
-template <class T>
+template <class T, int ZMAX>
 __global__ __launch_bounds__(RKB_THREADS) void decin_bwd_reparam(const float* __restrict__ dact, const T* __restrict__ w,
                                                                  T* __restrict__ draw, float* __restrict__ dbias_di, float* dz,
                                                                  unsigned* ticket, const float* __restrict__ fc,
@@ -844,12 +855,12 @@ __global__ __launch_bounds__(RKB_THREADS) void decin_bwd_reparam(const float* __
                                                                  const int* __restrict__ idx, const float* __restrict__ stdq,
                                                                  float tau, float beta, int B, int z, int N, T* __restrict__ dfc,
                                                                  float* __restrict__ dbias_fc) {
-    constexpr int ZP = RKD_ZMAX + 1;
-    __shared__ __attribute__((aligned(16))) char smem[RKB_MAX * 4 + 4 * 256 * 8];   // 40 KB: two phases share it
+    constexpr int ZP = ZMAX + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // DecinBwdSmem<ZMAX>::BYTES (40 KB / 72 KB): two phases share it
     __shared__ int is_last;
     float* ds = (float*)smem;                              // [64][65]
     float* ws = ds + 64 * 65;                              // [64][ZP]
-    double* colpart = (double*)(smem + 26 * 1024);         // [16][64]
+    double* colpart = (double*)(smem + DecinBwdSmem<ZMAX>::COLPART);   // [16][64]
     const int tid = threadIdx.x, c = tid & 63, r = tid >> 6, n0 = blockIdx.x * 64;
     for (int i = tid; i < 64 * z; i += RKB_THREADS) {
         const int cc = i / z, k = i - cc * z;
@@ -895,7 +906,7 @@ __global__ __launch_bounds__(RKB_THREADS) void decin_bwd_reparam(const float* __
     __syncthreads();
     if (!is_last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // dz is read with plain loads below: drop any cached copy
-    reparam_bwd_bias_body<T, true>(fc, eps, prior, idx, stdq, dz, tau, beta, B, z, dfc, dbias_fc, (float*)smem, (double*)(smem + RKB_MAX * 4));
+    reparam_bwd_bias_body<T, true>(fc, eps, prior, idx, stdq, dz, tau, beta, B, z, dfc, dbias_fc, (float*)smem, (double*)(smem + DecinBwdSmem<ZMAX>::VALS * 4));
     if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -1727,15 +1738,15 @@ extern "C" int favae_reparam_kl_decoder_input(const float* fc, const float* eps,
                                               const float* bias, void* out, int N, int dtype, void* stream) {
     FAVAE_CHECK_ARG(fc && eps && zlat && stdq && kl_out && w && bias && out && B > 0 && z > 0 && N > 0 && tau > 0,
                     "favae_reparam_kl_decoder_input: bad argument");
-    FAVAE_CHECK_ARG(z <= RKD_ZMAX && (size_t)B * z * sizeof(float) <= 48 * 1024, "favae_reparam_kl_decoder_input: z <= %d, B*z <= 12288", RKD_ZMAX);
+    FAVAE_CHECK_ARG(z <= RKD_ZMAX_BIG && (size_t)B * z * sizeof(float) <= 48 * 1024, "favae_reparam_kl_decoder_input: z <= %d, B*z <= 12288", RKD_ZMAX_BIG);
     FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_reparam_kl_decoder_input: dtype");
     const size_t lds = (size_t)B * z * sizeof(float);
-    if (dtype == FAVAE_F32)
-        hipLaunchKernelGGL(reparam_kl_decin<float>, dim3((N + 63) / 64), dim3(RKF_THREADS), lds, ST, fc, eps, prior, idx, tau, B, z, (float*)zlat,
-                           stdq, kl_out, (const float*)w, bias, (float*)out, N);
-    else
-        hipLaunchKernelGGL(reparam_kl_decin<bf16_t>, dim3((N + 63) / 64), dim3(RKF_THREADS), lds, ST, fc, eps, prior, idx, tau, B, z, (bf16_t*)zlat,
-                           stdq, kl_out, (const bf16_t*)w, bias, (bf16_t*)out, N);
+    const dim3 grid((N + 63) / 64);
+#define RKD_LAUNCH(TT, ZM, TH) hipLaunchKernelGGL((reparam_kl_decin<TT, ZM, TH>), grid, dim3(TH), lds, ST, fc, eps, prior, idx, tau, B, z, (TT*)zlat, \
+                                                  stdq, kl_out, (const TT*)w, bias, (TT*)out, N)
+    if (z <= RKD_ZMAX) { if (dtype == FAVAE_F32) RKD_LAUNCH(float, RKD_ZMAX, RKF_THREADS); else RKD_LAUNCH(bf16_t, RKD_ZMAX, RKF_THREADS); }
+    else { if (dtype == FAVAE_F32) RKD_LAUNCH(float, RKD_ZMAX_BIG, 256); else RKD_LAUNCH(bf16_t, RKD_ZMAX_BIG, 256); }
+#undef RKD_LAUNCH
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }
@@ -1771,18 +1782,29 @@ extern "C" int favae_decoder_input_bwd_reparam(const float* dact, const void* w,
                                                float* dbias_fc, int dtype, void* stream) {
     FAVAE_CHECK_ARG(dact && w && draw && dbias_di && dz && fc && eps && stdq && dfc && dbias_fc && B > 0 && z > 0 && N > 0 && tau > 0,
                     "favae_decoder_input_bwd_reparam: bad argument");
-    FAVAE_CHECK_ARG(z <= RKD_ZMAX && N % 64 == 0 && (long long)B * 2 * z <= RKB_MAX,
-                    "favae_decoder_input_bwd_reparam: z <= %d, N a multiple of 64, B * 2z <= %d", RKD_ZMAX, RKB_MAX);
+    const bool big = z > RKD_ZMAX;
+    const int vmax = big ? DecinBwdSmem<RKD_ZMAX_BIG>::VALS : DecinBwdSmem<RKD_ZMAX>::VALS;
+    FAVAE_CHECK_ARG(z <= RKD_ZMAX_BIG && N % 64 == 0 && (long long)B * 2 * z <= vmax,
+                    "favae_decoder_input_bwd_reparam: z <= %d, N a multiple of 64, B * 2z <= %d", RKD_ZMAX_BIG, vmax);
     FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_decoder_input_bwd_reparam: dtype");
     unsigned* ticket = nullptr;
     int trc = ticket_base(1, &ticket);
     if (trc) return trc;
-    if (dtype == FAVAE_F32)
-        hipLaunchKernelGGL(decin_bwd_reparam<float>, dim3(N / 64), dim3(RKB_THREADS), 0, ST, dact, (const float*)w, (float*)draw, dbias_di, dz,
-                           ticket, fc, eps, prior, idx, stdq, tau, beta, B, z, N, (float*)dfc, dbias_fc);
-    else
-        hipLaunchKernelGGL(decin_bwd_reparam<bf16_t>, dim3(N / 64), dim3(RKB_THREADS), 0, ST, dact, (const bf16_t*)w, (bf16_t*)draw, dbias_di, dz,
-                           ticket, fc, eps, prior, idx, stdq, tau, beta, B, z, N, (bf16_t*)dfc, dbias_fc);
+#define DBR_LAUNCH(TT, ZM) hipLaunchKernelGGL((decin_bwd_reparam<TT, ZM>), dim3(N / 64), dim3(RKB_THREADS), DecinBwdSmem<ZM>::BYTES, ST, dact, (const TT*)w, \
+                                              (TT*)draw, dbias_di, dz, ticket, fc, eps, prior, idx, stdq, tau, beta, B, z, N, (TT*)dfc, dbias_fc)
+    if (!big) {
+        if (dtype == FAVAE_F32) DBR_LAUNCH(float, RKD_ZMAX); else DBR_LAUNCH(bf16_t, RKD_ZMAX);
+    } else {
+        // 72 KB of dynamic LDS: above the 64 KB a kernel gets without asking
+        static bool raised = false;
+        if (!raised) {
+            FAVAE_HIP(hipFuncSetAttribute((const void*)decin_bwd_reparam<float, RKD_ZMAX_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, DecinBwdSmem<RKD_ZMAX_BIG>::BYTES));
+            FAVAE_HIP(hipFuncSetAttribute((const void*)decin_bwd_reparam<bf16_t, RKD_ZMAX_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, DecinBwdSmem<RKD_ZMAX_BIG>::BYTES));
+            raised = true;
+        }
+        if (dtype == FAVAE_F32) DBR_LAUNCH(float, RKD_ZMAX_BIG); else DBR_LAUNCH(bf16_t, RKD_ZMAX_BIG);
+    }
+#undef DBR_LAUNCH
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

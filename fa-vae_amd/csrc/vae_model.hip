@@ -886,7 +886,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             v.join_pending = false;
         }
         RC(encoder_fwd(v, B, true, st, true));
-        const bool decin = !(v.fuse & 0x4000u) && v.z <= 32 && (long long)B * v.z <= 12288;   // reparameterise + KL + decoder_input in one launch
+        const bool decin = !(v.fuse & 0x4000u) && v.z <= 128 && (long long)B * v.z <= 12288;   // reparameterise + KL + decoder_input in one launch
         if (decin)
             RC(favae_reparam_kl_decoder_input(v.raw[L_FC], eps, prior, idx, tau, B, v.z, v.zlat, v.stdq, metrics2_out + 1, v.Wf(L_DI),
                                               v.P + v.L[L_DI].b_off, v.act[L_DI], v.L[L_DI].Cout, v.dtype, st));
@@ -923,7 +923,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1], v.dact_bf[l - 1], l > 7 ? l - 1 : -1));
             RC(after_dgrad(v, l, st));
         } else if (sg == 6) {
-            v.rk_done = !(v.fuse & 0x8000u) && (v.fuse & 16u) && v.z <= 32 && (long long)B * 2 * v.z <= 8192;
+            v.rk_done = !(v.fuse & 0x8000u) && (v.fuse & 16u) && v.z <= 128 && (long long)B * 2 * v.z <= (v.z <= 32 ? 8192 : 16384);
             if (v.rk_done) {   // decoder_input backward (cast, bias gradient, dz) + reparameterisation / KL backward in one launch
                 RC(favae_decoder_input_bwd_reparam(v.dact[L_DI], v.Wf(L_DI), v.draw[L_DI], v.G + v.L[L_DI].b_off, v.dz, v.raw[L_FC], eps, prior,
                                                    idx, v.stdq, tau, beta, B, v.z, v.L[L_DI].Cout, v.draw[L_FC], v.G + v.L[L_FC].b_off, v.dtype, st));

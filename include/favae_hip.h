@@ -188,14 +188,16 @@ int favae_reparam_kl_fwd(const float* fc, const float* eps, const double* prior,
                          void* zlat, float* stdq, double* kl_out, int dtype, void* stream);
 /* favae_reparam_kl_fwd followed by decoder_input (nn.Linear z -> N, :41-45, the first layer of decode(), :100-104) in one
  * launch: out [B][N] (dtype) = zlat (as stored, i.e. rounded to dtype) @ w^T + bias, w [N][z] dtype, bias [N] fp32.
- * z <= 32, B*z <= 12288.  Same results as the two calls up to the summation order of the z products. */
+ * z <= 128 (two instances: z <= 32 and z <= 128), B*z <= 12288.  Same results as the two calls up to the summation order of
+ * the z products. */
 int favae_reparam_kl_decoder_input(const float* fc, const float* eps, const double* prior, const int* idx, float tau, int B,
                                    int z, void* zlat, float* stdq, double* kl_out, const void* w, const float* bias, void* out,
                                    int N, int dtype, void* stream);
 /* Backward of decoder_input and of the reparameterisation in one launch (autograd of :41-45 and :89-92/:137-150 under
  * loss.backward(), :249): given dact [B][N] fp32 (gradient w.r.t. the decoder_input output) and w [N][z] (dtype):
  * draw [B][N] = dact as dtype, dbias_di [N] = column sums of dact, dz [B][z] += draw @ w (fp32 atomics, dz ZERO on entry),
- * then, as favae_reparam_kl_bwd_bias with that dz: dfc [B][2z] (dtype) and dbias_fc [2z].  z <= 32, N % 64 == 0, B*2z <= 8192. */
+ * then, as favae_reparam_kl_bwd_bias with that dz: dfc [B][2z] (dtype) and dbias_fc [2z].  z <= 128, N % 64 == 0,
+ * B*2z <= 8192 (z <= 32) / 16384 (z <= 128). */
 int favae_decoder_input_bwd_reparam(const float* dact, const void* w, void* draw, float* dbias_di, float* dz, const float* fc,
                                     const float* eps, const double* prior, const int* idx, const float* stdq, float tau,
                                     float beta, int B, int z, int N, void* dfc, float* dbias_fc, int dtype, void* stream);

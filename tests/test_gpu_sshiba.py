@@ -277,7 +277,7 @@ def test_full_variant_B_two_image_views_matches_oracle():
 
 def test_stress_shape_four_views_latent_512_kc_200_matches_oracle():
     """BASELINE config 5 at a size the oracle finishes in seconds: two image views with a 512-dimensional latent (beyond the
-    fused launches around the latent, which take z <= 32 / 128), a 64-column 'reg' view and the 40-label view, Kc = 200 (the
+    fused launches around the latent, which take z <= 128), a 64-column 'reg' view and the 40-label view, Kc = 200 (the
     K x K inverses leave LDS for the global workspace), N = 64, one iteration of one epoch per image view, variant B.
     Like-for-like quantities (first epoch of either VAE: shared initial state) at 1e-5; the state after the iteration at the
     tolerances of the smoke test (the two sides take one Adam step from the same gradients up to fp32 rounding)."""

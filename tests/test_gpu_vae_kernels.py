@@ -110,7 +110,8 @@ def test_reparam_kl_forward_backward(with_prior):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,z,N,with_prior", [(64, 20, 4096, True), (37, 32, 200, False), (512, 20, 4096, True)])
+@pytest.mark.parametrize("B,z,N,with_prior", [(64, 20, 4096, True), (37, 32, 200, False), (512, 20, 4096, True),
+                                               (64, 100, 4096, True), (96, 128, 2048, False), (33, 65, 200, True)])
 def test_reparam_kl_with_decoder_input_in_one_launch(dt, B, z, N, with_prior):
     """favae_reparam_kl_decoder_input: zlat / stdq / KL identical to favae_reparam_kl_fwd, and
     out = decoder_input(zlat) (nn.Linear z -> N, celeba_deepvanilla_vae.py:41-45) on the stored (dtype-rounded) latent."""
@@ -140,7 +141,8 @@ def test_reparam_kl_with_decoder_input_in_one_launch(dt, B, z, N, with_prior):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,z,N,with_prior", [(64, 20, 4096, True), (37, 32, 192, False), (100, 20, 4096, True)])
+@pytest.mark.parametrize("B,z,N,with_prior", [(64, 20, 4096, True), (37, 32, 192, False), (100, 20, 4096, True),
+                                               (64, 100, 4096, True), (64, 128, 2048, False), (33, 65, 192, True)])
 def test_decoder_input_backward_with_reparam_backward_in_one_launch(dt, B, z, N, with_prior):
     """favae_decoder_input_bwd_reparam == favae_colsum_cast + (dz = draw @ W) + favae_reparam_kl_bwd_bias; called twice
     in a row (the ticket word must be left at zero)."""
@@ -164,8 +166,14 @@ def test_decoder_input_backward_with_reparam_backward_in_one_launch(dt, B, z, N,
                                    L.stream_ptr()))
     dz0 = (draw0.double() @ w.double()).float().contiguous()
     dfc0, dbf0 = torch.zeros(B, 2 * z, dtype=dt, device=dev), torch.zeros(2 * z, device=dev)
-    L.check(raw_.favae_reparam_kl_bwd_bias(L.ptr(fc), L.ptr(eps), L.ptr(prior), L.ptr(idx), L.ptr(stdq), L.ptr(dz0), f_(tau), f_(beta),
-                                           i_(B), i_(z), L.ptr(dfc0), L.ptr(dbf0), i_(code), L.stream_ptr()))
+    if B * 2 * z <= 8192:
+        L.check(raw_.favae_reparam_kl_bwd_bias(L.ptr(fc), L.ptr(eps), L.ptr(prior), L.ptr(idx), L.ptr(stdq), L.ptr(dz0), f_(tau), f_(beta),
+                                               i_(B), i_(z), L.ptr(dfc0), L.ptr(dbf0), i_(code), L.stream_ptr()))
+    else:                      # beyond the one-block form's limit: the grid form in fp32, bias gradient = its column sums
+        dfc32 = torch.zeros(B, 2 * z, device=dev)
+        L.check(raw_.favae_reparam_kl_bwd(L.ptr(fc), L.ptr(eps), L.ptr(prior), L.ptr(idx), L.ptr(stdq), L.ptr(dz0), f_(tau), f_(beta),
+                                          i_(B), i_(z), L.ptr(dfc32), i_(0), L.stream_ptr()))
+        dfc0, dbf0 = dfc32.to(dt), dfc32.sum(0)
     for _ in range(2):
         draw1, db1, dz1 = torch.zeros_like(draw0), torch.zeros_like(db0), torch.zeros(B, z, device=dev)
         dfc1, dbf1 = torch.zeros_like(dfc0), torch.zeros_like(dbf0)
