@@ -42,6 +42,21 @@ def sum_(t):
     return t
 
 
+def sum_many_(ts):
+    """In-place sum over ranks of several statistics in ONE all-reduce: the tensors of a phase are packed into one buffer,
+    reduced and scattered back (small K x K / d x K blocks: one collective's latency instead of one per statistic)."""
+    if active() and len(ts) > 0:
+        if len(ts) == 1:
+            return [sum_(ts[0])]
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        sum_(flat)
+        o = 0
+        for t in ts:
+            t.copy_(flat[o:o + t.numel()].view_as(t))
+            o += t.numel()
+    return ts
+
+
 def mean_(t):
     """In-place mean over ranks.  RCCL has a native AVG; gloo does not."""
     if active():

@@ -138,19 +138,26 @@ class SSHIBA(object):
         X = self.X[m]
         Xd = X.dev("mean", self.dev)
         d = self.d[m]
-        xtx1 = dist.sum_(fa.atb(Xd, Xd, True, self.sc))
+        stats = [fa.atb(Xd, Xd, True, self.sc)]
+        with_cov = self.method[m] != "reg" or self.SS[m]
+        if with_cov:
+            stats.append(fa.atb(X.dev("cov", self.dev), None, True, self.sc))
+        dist.sum_many_(stats)                              # one all-reduce for the statistics of this view
+        xtx1 = stats[0]
         prod = xtx1[:, :d].cpu().numpy()
-        if self.method[m] != "reg" or self.SS[m]:
-            csum = dist.sum_(fa.atb(X.dev("cov", self.dev), None, True, self.sc)).cpu().numpy().ravel()
-            prod = prod + np.diag(csum)
+        if with_cov:
+            prod = prod + np.diag(stats[1].cpu().numpy().ravel())
         dict.__setitem__(X, "prodT", prod)
         self._xsum[m] = xtx1[:, d].contiguous()
         self._trxx[m] = float(np.trace(prod))
 
-    def _refresh_zstats(self):
+    def _refresh_zstats(self, also=()):
+        """Z^T [Z | 1] summed over the shards; `also`: further local statistics of the same phase, reduced in the same
+        all-reduce (in place)."""
         q = self.q_dist
         K = q.Kc
-        ztz1 = dist.sum_(fa.atb(q.Z.dev("mean", self.dev), q.Z.dev("mean", self.dev), True, self.sc))
+        ztz1 = fa.atb(q.Z.dev("mean", self.dev), q.Z.dev("mean", self.dev), True, self.sc)
+        dist.sum_many_([ztz1] + list(also))
         self._zsum = ztz1[:, K].contiguous()
         return ztz1[:, :K].contiguous()
 
@@ -342,8 +349,11 @@ class SSHIBA(object):
     # ---- update (:743-902) ---------------------------------------------------------------------------------------
     def update(self, Y_tst=[None], X_tst=[None], X_tr=[None], Y_ss=None, HL=0, AUC=0, ACC=0, mse=0, R2=0, m_in=[0], m_out=1,
                steps=100, mc_it=1, store=True, iter_count=0):
+        # X_m^T [Z | 1] of every view in one all-reduce (Z does not change between the W updates)
+        Zd = self.q_dist.Z.dev("mean", self.dev)
+        xtz = dist.sum_many_([fa.atb(self.X[m].dev("mean", self.dev), Zd, True, self.sc) for m in range(self.m)])
         for m in range(self.m):
-            self.update_w(m)
+            self.update_w(m, xtz[m])
         self.update_Z()
         for m in range(self.m):
             meth = self.method[m]
@@ -549,8 +559,8 @@ class SSHIBA(object):
         return self._predict_outputs(m_outs, n_pred, Zd, Z_cov, X_sample, True)
 
     # ---- mean-field updates ----------------------------------------------------------------------------------------
-    def update_w(self, m):
-        """:1058-1075"""
+    def update_w(self, m, xtz1=None):
+        """:1058-1075 (xtz1: X_m^T [Z | 1] already summed over the shards)"""
         q = self.q_dist
         tau = self._tau(m)
         s = self._up(1 / np.sqrt(q.alpha_mean(m)))
@@ -558,8 +568,9 @@ class SSHIBA(object):
         if not ok:
             print("Cov W" + str(m) + " is not invertible, not updated")
             return
-        Xd, Zd = self.X[m].dev("mean", self.dev), q.Z.dev("mean", self.dev)
-        xtz1 = dist.sum_(fa.atb(Xd, Zd, True, self.sc))
+        if xtz1 is None:
+            Xd, Zd = self.X[m].dev("mean", self.dev), q.Z.dev("mean", self.dev)
+            xtz1 = dist.sum_(fa.atb(Xd, Zd, True, self.sc))
         wmean = torch.empty(self.d[m], q.Kc, dtype=F64, device=self.dev)
         wprod = torch.empty(q.Kc, q.Kc, dtype=F64, device=self.dev)
         fa.w_update(xtz1, self._zsum, self._up(np.ravel(q.b[m]["mean"])), wcov, tau, wmean, wprod, self.sc)
@@ -609,18 +620,19 @@ class SSHIBA(object):
         Zold = q.Z.dev("mean", self.dev)
         Znew = combine(list(M), Zcov, Zold, torch.empty_like(Zold))
         q.Z.set_dev("mean", Znew)
-        ztz = self._refresh_zstats()
-        q.Z["prodT"] = fa.axpby(1.0, ztz, float(self.n_max), Zcov).cpu().numpy()                     # :989
+        zz = []
         if self.VARIANT == "A":
-            q.Z["prodT_pred"] = []
             for m in M:
                 others = [j for j in M if j != m]
                 if not others:
                     raise ValueError("variant A needs at least two views (reference :996 stacks the other views)")
                 zp = combine(others, covs_pred[m], Znew, torch.empty_like(Znew))                     # :996-997
                 q.Z.set_dev("mean_pred%d" % m, zp)
-                zz = dist.sum_(fa.atb(zp, zp, False, self.sc))
-                q.Z["prodT_pred"].append(fa.axpby(1.0, zz, float(self.n_max), covs_pred[m]).cpu().numpy())
+                zz.append(fa.atb(zp, zp, False, self.sc))
+        ztz = self._refresh_zstats(also=zz)               # Z^T Z and the predictive Z^T Z of every view: one all-reduce
+        q.Z["prodT"] = fa.axpby(1.0, ztz, float(self.n_max), Zcov).cpu().numpy()                     # :989
+        if self.VARIANT == "A":
+            q.Z["prodT_pred"] = [fa.axpby(1.0, zz[m], float(self.n_max), covs_pred[m]).cpu().numpy() for m in M]
             q.Z["mean_pred"] = _PredList(q.Z, self.m)
 
     def update_xs(self, m):

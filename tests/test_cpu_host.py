@@ -184,6 +184,14 @@ def _gloo_worker(rank, ws, port, q):
     dist.broadcast_(w)
     ok = ok and torch.equal(w, torch.zeros(3))
     ok = ok and dist.sum_scalar(hi - lo) == N and dist.all_equal(3) and not dist.all_equal(rank)
+    # the statistics of one phase packed into one all-reduce give the per-statistic sums
+    a, b2, c = torch.full((3, 4), rank + 1.0, dtype=torch.float64), torch.arange(5, dtype=torch.float64) * (rank + 1), torch.ones(1, 2, dtype=torch.float64)
+    ref = [t.clone() for t in (a, b2, c)]
+    for t in ref:
+        dist.sum_(t)
+    out = dist.sum_many_([a, b2, c])
+    ok = ok and all(o is t and torch.equal(t, r) for o, t, r in zip(out, (a, b2, c), ref))
+    ok = ok and dist.min_scalar(rank) == 0 and dist.max_scalar(rank) == ws - 1
     q.put((rank, bool(ok)))
     td.destroy_process_group()
 
