@@ -30,6 +30,13 @@ constexpr int BK = 64;  // reduction elements per LDS stage
 
 int g_force_kc_tile = -1, g_force_pm_tile = -1;  // developer override (favae_debug_force_tile), -1 = heuristic
 
+#ifdef FAVAE_KC_STAMPS   // developer build: cycle stamps of one wave of the middle block (tools/kc_stamps.py)
+__device__ unsigned long long g_kc_stamps[64];
+#define KC_STAMP(i) do { if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_kc_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define KC_STAMP(i)
+#endif
+
 template <class T> struct Frag;
 template <> struct Frag<float> { float v[8]; };
 template <> struct Frag<bf16_t> { bf16x8 v; };
@@ -146,6 +153,22 @@ template <> __device__ __forceinline__ uint4 bn_act_vec<bf16_t>(const uint4* raw
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// 16 bytes through a buffer descriptor: a 32-bit per-lane byte offset + a wave-uniform offset, and the range check of the
+// descriptor returns zeros for an offset at or past its size -- which is how halo taps, tail rows and tail output channels
+// read as zero without a select per element (their offsets get bit 31 set; descriptors are at most 0x7FFFFFF0 bytes long)
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 buf_ld16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes < (size_t)0x7FFFFFF0 ? bytes : (size_t)0x7FFFFFF0), 0x00020000);
+}
+constexpr unsigned BUF_OOB = 0x80000000u;
+__device__ __forceinline__ unsigned outside_bit(int v, int n) { return (unsigned)v >= (unsigned)n ? 1u : 0u; }
+// kernel row / column of the i-th valid tap of a launch slice: stride-2 scatter form: parity class pp uses taps {1} or {0, 2}
+template <bool TR> __device__ __forceinline__ int tap_k(bool s2, int pp, int i) { return (TR && s2) ? (pp ? 2 * i : 1) : i; }
+
 // ---------------------------------------------------------------------------------------------------------
 // K-contiguous implicit GEMM (gather / scatter forms)
 // ---------------------------------------------------------------------------------------------------------
@@ -176,6 +199,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
     __shared__ __attribute__((aligned(16))) char lds_all[KG * NBUF * STAGE];
     __shared__ __attribute__((aligned(16))) float ab_s[FI ? 512 : 4];   // a[Cin] | b[Cin], Cin <= 256
 
+    KC_STAMP(0);
     const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);          // reduction group of this wave
     const int tid = KG == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 255);   // thread index inside the group
     const int lane = tid & 63, wave = tid >> 6;
@@ -190,8 +214,11 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
     int nkh, nkw;
     if (TR && p.stride == 2) { nkh = 1 + py; nkw = 1 + px; } else { nkh = p.ks; nkw = p.ks; }
     const int ntap = nkh * nkw;
-    auto tap_kh = [&](int i) { return (TR && p.stride == 2) ? (py ? 2 * i : 1) : i; };
-    auto tap_kw = [&](int i) { return (TR && p.stride == 2) ? (px ? 2 * i : 1) : i; };
+    const bool s2 = p.stride == 2;
+    // (free functions of values, not lambdas holding references: a closure that ends up in memory drags the whole parameter
+    // struct into scratch with it)
+#define tap_kh(i) tap_k<TR>(s2, py, (i))
+#define tap_kw(i) tap_k<TR>(s2, px, (i))
 
     const int cpt = SLOW ? 1 : p.Cin / BK;
     const int nchunk = SLOW ? (ntap * p.Cin + BK - 1) / BK : ntap * cpt;
@@ -212,6 +239,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
         a_y[i] = rem / p.WoC;
         a_x[i] = rem - a_y[i] * p.WoC;
     }
+    KC_STAMP(30);
     const int vecA = tid % VPR;  // same for every i because 256 % VPR == 0
     int b_row[VB];
     bool b_ok[VB];
@@ -233,33 +261,87 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
         return iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
     };
 
-    // returns the validity bits of the A vectors (bit i); the zeroing select is applied when the registers are written
-    // to LDS, D chunks later, so that nothing waits on a load at issue time
-    auto load_chunk = [&](int c, uint4 (&va)[VA * VAL], uint4 (&vb)[VB]) -> unsigned {
+    // ---- whole-chunk channel counts: lean addressing.  Measured on MI355X (SQ counters, tools/pmc_gemm.sh) the batch-64 layers
+    // were bound by instruction issue, not by MFMA or memory: ~140 instructions of index arithmetic per chunk (two scalar
+    // divisions, 64-bit address products, clamps and selects) against 4 MFMAs.  Everything that does not change from chunk
+    // to chunk is hoisted: per staged row one 32-bit byte offset relative to the tile's first image and a 9-bit mask of the
+    // taps that fall outside the image; per chunk a wave-uniform tap offset and the channel offset in the scalar offset of
+    // the buffer load.  Invalid taps / rows / output channels get bit 31 of the offset, past the descriptor: they read zeros.
+    KC_STAMP(31);
+    constexpr int ESZ_IN = FI ? 4 : (int)sizeof(T);
+    [[maybe_unused]] unsigned a_off[VA], a_inv[VA], b_off[VB];
+    // (plain scalars, not an array: a dynamically indexed private array is promoted to LDS, and the promoted form reads the
+    // workgroup size from the dispatch packet in host memory -- measured 28 000 cycles at the top of every block)
+    [[maybe_unused]] int dy0 = 0, dy1 = 0, dy2 = 0, dx0 = 0, dx1 = 0, dx2 = 0;
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_in, rs_w;
+    [[maybe_unused]] int ld_t = 0, ld_cc = 0;   // tap / channel chunk of the next load (advanced by KG per load)
+    if constexpr (!SLOW) {
+        const int hw = p.HoC * p.WoC;
+        const int img0 = m0 / hw;   // first image of this tile (block-uniform)
+        const size_t img_bytes = (size_t)p.Hi * p.Wi * p.Cin * ESZ_IN;
+        rs_in = buf_rsrc((const char*)p.in + (size_t)img0 * img_bytes, (size_t)(p.Nb - img0) * img_bytes);
+        rs_w = buf_rsrc(p.w, (size_t)p.Cout * p.ldw * sizeof(T));
+        KC_STAMP(32);
+        const int st_ = p.stride, pd_ = p.pad;
+        if (TR) {
+            dy0 = (py + pd_ - tap_kh(0)) / st_; dy1 = (py + pd_ - tap_kh(1)) / st_; dy2 = (py + pd_ - tap_kh(2)) / st_;
+            dx0 = (px + pd_ - tap_kw(0)) / st_; dx1 = (px + pd_ - tap_kw(1)) / st_; dx2 = (px + pd_ - tap_kw(2)) / st_;
+        } else {
+            dy0 = tap_kh(0) - pd_; dy1 = tap_kh(1) - pd_; dy2 = tap_kh(2) - pd_;
+            dx0 = tap_kw(0) - pd_; dx1 = tap_kw(1) - pd_; dx2 = tap_kw(2) - pd_;
+        }
+        KC_STAMP(33);
+#pragma unroll
+        for (int i = 0; i < VA; ++i) {
+            const int by = TR ? a_y[i] : a_y[i] * p.stride, bx = TR ? a_x[i] : a_x[i] * p.stride;
+            a_off[i] = (unsigned)((((a_n[i] - img0) * p.Hi + by) * p.Wi + bx) * p.Cin * ESZ_IN + vecA * VE * ESZ_IN);
+            unsigned invh = 0, invw = 0;
+            invh = outside_bit(by + dy0, p.Hi) | (outside_bit(by + dy1, p.Hi) << 1) | (outside_bit(by + dy2, p.Hi) << 2);
+            invw = outside_bit(bx + dx0, p.Wi) | (outside_bit(bx + dx1, p.Wi) << 1) | (outside_bit(bx + dx2, p.Wi) << 2);
+            // bit (kh * nkw + kw): a tap row outside the image invalidates its nkw taps, otherwise the columns decide (bits of tap
+            // rows >= nkh land at or above ntap and are never tested)
+            const unsigned roww = (1u << nkw) - 1u, colw = invw & roww;
+            const unsigned inv = ((invh & 1u) ? roww : colw) | (((invh & 2u) ? roww : colw) << nkw) | (((invh & 4u) ? roww : colw) << (2 * nkw));
+            a_inv[i] = a_ok[i] ? inv : 0x1FFu;
+        }
+#pragma unroll
+        for (int j = 0; j < VB; ++j) b_off[j] = b_ok[j] ? (unsigned)((b_row[j] * p.ldw + vecA * VE) * (int)sizeof(T)) : BUF_OOB;
+        KC_STAMP(34);
+        const int c0 = c_begin + grp;
+        ld_t = c0 / cpt;
+        ld_cc = c0 - ld_t * cpt;
+    }
+    // the next chunk of this group (chunks are loaded in ascending order, KG apart); returns the validity bits of the A
+    // vectors (fused input only: there a zero input is not a zero operand)
+    auto load_next = [&](uint4 (&va)[VA * VAL], uint4 (&vb)[VB]) __attribute__((always_inline)) -> unsigned {
         unsigned mask = 0;
-        if (!SLOW) {
-            // branch-free: out-of-image taps and tail rows read a clamped (valid) address
-            const int t = c / cpt, ci0 = (c - t * cpt) * BK;
-            const int kh = tap_kh(t / nkw), kw = tap_kw(t % nkw);
-            const int kg = (kh * p.ks + kw) * p.Cin + ci0 + vecA * VE;
+        const int ti = ld_t >= 2 * nkw ? 2 : ld_t >= nkw ? 1 : 0, tj = ld_t - ti * nkw;
+        // (the tap offsets are linear in the tap index in every form; a select among the variables would become a load through a
+        // selected address and pin them, the closure and the parameter struct to scratch memory)
+        const int dy = dy0 + ti * (dy1 - dy0), dx = dx0 + tj * (dx1 - dx0);
+        const unsigned tap_off = (unsigned)((dy * p.Wi + dx) * p.Cin * ESZ_IN);
+        const unsigned so_a = (unsigned)(ld_cc * BK * ESZ_IN);
+        const unsigned so_w = (unsigned)(((tap_kh(ti) * p.ks + tap_kw(tj)) * p.Cin + ld_cc * BK) * (int)sizeof(T));
+        const unsigned sh = 31u - (unsigned)ld_t;
 #pragma unroll
-            for (int i = 0; i < VA; ++i) {
-                int iy, ix;
-                const bool ok = in_coord(a_y[i], a_x[i], kh, kw, iy, ix) && a_ok[i];
-                iy = min(max(iy, 0), p.Hi - 1);
-                ix = min(max(ix, 0), p.Wi - 1);
-                const size_t off = ((size_t)(a_n[i] * p.Hi + iy) * p.Wi + ix) * p.Cin + ci0 + vecA * VE;
-                if constexpr (FI) {
-                    const float* src = (const float*)p.in + off;
-                    va[i * VAL] = *(const uint4*)src;
-                    if constexpr (VAL == 2) va[i * VAL + 1] = *(const uint4*)(src + 4);
-                } else {
-                    va[i] = *(const uint4*)((const T*)p.in + off);
-                }
-                mask |= ok ? (1u << i) : 0u;
-            }
+        for (int i = 0; i < VA; ++i) {
+            const unsigned off = (a_off[i] + tap_off) | ((a_inv[i] << sh) & BUF_OOB);
+            if constexpr (FI) mask |= ((a_inv[i] >> ld_t) & 1u) ? 0u : (1u << i);
+            va[i * VAL] = buf_ld16(rs_in, off, so_a);
+            if constexpr (VAL == 2) va[i * VAL + 1] = buf_ld16(rs_in, off + 16u, so_a);
+        }
 #pragma unroll
-            for (int j = 0; j < VB; ++j) vb[j] = *(const uint4*)((const T*)p.w + (size_t)b_row[j] * p.ldw + kg);
+        for (int j = 0; j < VB; ++j) vb[j] = buf_ld16(rs_w, b_off[j], so_w);
+        ld_cc += KG;
+        while (ld_cc >= cpt) { ld_cc -= cpt; ++ld_t; }
+        return mask;
+    };
+
+    // elementwise-load form (channel counts that do not fill chunks): returns the validity bits of the A vectors (bit i)
+    auto load_chunk = [&](int c, uint4 (&va)[VA * VAL], uint4 (&vb)[VB]) __attribute__((always_inline)) -> unsigned {
+        unsigned mask = 0;
+        if constexpr (!SLOW) {
+            return load_next(va, vb);
         } else {
             mask = ~0u;
             const int ktot = ntap * p.Cin;
@@ -312,9 +394,11 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
     unsigned am[D];
     const int n_it = (max(c_end - c_begin, 0) + KG - 1) / KG;
     auto chunk_of = [&](int j) { return c_begin + grp + KG * j; };
+    KC_STAMP(1);
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (chunk_of(d) < c_end) am[d] = load_chunk(chunk_of(d), va[d], vb[d]);
+    KC_STAMP(2);
     if constexpr (FI) {
         for (int i = (int)threadIdx.x; i < 2 * p.Cin; i += 256 * KG) ab_s[i] = p.in_ab[i];
         __syncthreads();
@@ -335,15 +419,18 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
                     for (int i = 0; i < VA; ++i)
                         if (NVA % 256 == 0 || (tid + i * 256) < NVA) {
                             uint4 v;
-                            if constexpr (FI) v = bn_act_vec<T>(&va[d][i * VAL], ab_s, cfi, p.Cin);
-                            else v = va[d][i];
-                            *(uint4*)(ldsA + ((tid + i * 256) / VPR) * RS + vecA * 16) = keep_if((am[d] >> i) & 1u, v);
+                            if constexpr (FI) v = keep_if((am[d] >> i) & 1u, bn_act_vec<T>(&va[d][i * VAL], ab_s, cfi, p.Cin));
+                            else if constexpr (SLOW) v = keep_if((am[d] >> i) & 1u, va[d][i]);
+                            else v = va[d][i];   // (out-of-range loads came back as zeros)
+                            *(uint4*)(ldsA + ((tid + i * 256) / VPR) * RS + vecA * 16) = v;
                         }
 #pragma unroll
                     for (int jj = 0; jj < VB; ++jj)
-                        if (NVB % 256 == 0 || (tid + jj * 256) < NVB) *(uint4*)(ldsB + ((tid + jj * 256) / VPR) * RS + vecA * 16) = keep_if(b_ok[jj], vb[d][jj]);
+                        if (NVB % 256 == 0 || (tid + jj * 256) < NVB) *(uint4*)(ldsB + ((tid + jj * 256) / VPR) * RS + vecA * 16) =
+                            SLOW ? keep_if(b_ok[jj], vb[d][jj]) : vb[d][jj];
                 }
                 __syncthreads();
+                KC_STAMP(3 + (j < 16 ? j : 16));
                 if (chunk_of(j + D) < c_end) am[d] = load_chunk(chunk_of(j + D), va[d], vb[d]);  // D chunks ahead of the MFMAs below
                 if (mine) {
 #pragma unroll
@@ -364,6 +451,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
             }
         }
     }
+    KC_STAMP(20);
     if (c_begin >= c_end && !(blockIdx.y == 0)) return;
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -544,6 +632,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
                     }
                 }
             }
+            KC_STAMP(21);
             return;
         }
     }
@@ -585,6 +674,9 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
         }
     }
 }
+
+#undef tap_kh
+#undef tap_kw
 
 // ---------------------------------------------------------------------------------------------------------
 // pixel-major implicit GEMM (weight gradients)
@@ -1034,6 +1126,14 @@ extern "C" int favae_conv_wgrad_folded(const void* rows, int Rc, const void* col
     if (rc) return rc;
     return favae_conv_wgrad_prefolded(scratch, 32, 9 * Rc, cols, Cc, Cc, dw, (long long)Nb * Hl * Wl, splitk, dtype, stream);
 }
+
+#ifdef FAVAE_KC_STAMPS
+extern "C" int favae_debug_kc_stamps(unsigned long long* out64) {
+    FAVAE_HIP(hipDeviceSynchronize());
+    FAVAE_HIP(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_kc_stamps), 64 * sizeof(unsigned long long)));
+    return FAVAE_OK;
+}
+#endif
 
 extern "C" int favae_debug_force_tile(int kc_tile, int pm_tile) {
     g_force_kc_tile = kc_tile;

@@ -16,12 +16,16 @@ def timeit(fn, reps=30):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
 rows = []
+import os
+ONLY = os.environ.get('ONLY')       # run only the layers whose name contains this (for rocprofv3 --pmc passes)
 def conv(name, Cin, Cout, Hi, Ho, ks, stride, scatter, taps_eff):
+    if ONLY and ONLY not in name: return
     x = t(B, Hi, Hi, Cin); w = t(Cout, ks * ks, Cin); out = torch.empty(B, Ho, Ho, Cout, device=dev)
     us = timeit(lambda: lib.conv_igemm(x, w, None, out, ks, stride, 1 if ks == 3 else 0, scatter, 0))
     fl = 2.0 * B * Ho * Ho * Cout * taps_eff * Cin
     rows.append((name, us, fl / us / 1e6))
 def wgrad(name, Rc, rl, Cc, cl, Hs, Hl, ks, stride):
+    if ONLY and ONLY not in name: return
     r = t(B, Hl if rl else Hs, Hl if rl else Hs, Rc); c = t(B, Hl if cl else Hs, Hl if cl else Hs, Cc)
     dw = torch.zeros(Rc, ks * ks, Cc, device=dev)
     us = timeit(lambda: lib.conv_wgrad(r, rl, c, cl, dw, B, Hs, Hs, Hl, Hl, ks, stride, 1 if ks == 3 else 0, 0))
