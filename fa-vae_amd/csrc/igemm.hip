@@ -33,8 +33,13 @@ int g_force_kc_tile = -1, g_force_pm_tile = -1;  // developer override (favae_de
 #ifdef FAVAE_KC_STAMPS   // developer build: cycle stamps of one wave of the middle block (tools/kc_stamps.py)
 __device__ unsigned long long g_kc_stamps[64];
 #define KC_STAMP(i) do { if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_kc_stamps[i] = __builtin_readcyclecounter(); } while (0)
+// start / end of every block on the constant 100 MHz clock (comparable across CUs), up to 8192 blocks
+__device__ unsigned long long g_kc_blocks[8192 * 2];
+#define KC_BLOCK(e) do { const unsigned b_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+                         if (threadIdx.x == 0 && b_ < 8192) g_kc_blocks[2 * b_ + (e)] = wall_clock64(); } while (0)
 #else
 #define KC_STAMP(i)
+#define KC_BLOCK(e)
 #endif
 
 template <class T> struct Frag;
@@ -200,6 +205,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
     __shared__ __attribute__((aligned(16))) float ab_s[FI ? 512 : 4];   // a[Cin] | b[Cin], Cin <= 256
 
     KC_STAMP(0);
+    KC_BLOCK(0);
     const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);          // reduction group of this wave
     const int tid = KG == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 255);   // thread index inside the group
     const int lane = tid & 63, wave = tid >> 6;
@@ -633,6 +639,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
                 }
             }
             KC_STAMP(21);
+            KC_BLOCK(1);
             return;
         }
     }
@@ -673,6 +680,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
             }
         }
     }
+    KC_BLOCK(1);
 }
 
 #undef tap_kh
@@ -884,7 +892,7 @@ int dispatch_kc(KcParams p, int classes, int target_blocks, int* fused, hipStrea
     // (enc.2 forward, dec.2 input gradient: 256 tiles x 18 chunks, 14.1 -> 11.6 us); with two blocks per CU already
     // resident the second group only adds its hand-over (12.1 -> 14.1 us).  With every piece of the chunk loop removed
     // these launches still take ~9 us (launch, first loads, epilogue, drain): the loop itself is 3-5 us of a 12-17 us launch.
-    const bool two = kg_env == 2 || (kg_env == 0 && blocks * p.splitk <= 256 && per_block >= 12);
+    const bool two = kg_env == 2 || (kg_env == 0 && blocks * p.splitk <= (TR ? 512 : 256) && per_block >= 12);
     if (p.in_ab) {   // fused input (checked by the caller: whole-chunk channel count <= 256, 64x64 tile)
         if (two) return launch_kc<T, TR, false, 64, 64, 2, 2, 2, true>(p, classes, st);
         return launch_kc<T, TR, false, 64, 64, 2, 2, 1, true>(p, classes, st);
@@ -995,7 +1003,10 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
     else { p.HoC = Ho; p.WoC = Wo; }
     p.M = Nb * p.HoC * p.WoC;
     p.ntn = 1;
-    const int target = scatter ? 1024 : 512;
+    // scatter form: four parity classes of 1 / 2 / 2 / 4 taps.  Up to 512 tiles in all the reduction stays whole (fp32 atomics of a
+    // split reduction cost more than they bring: decoder.1 forward 23.5 -> 16.7 us unsplit with two reduction groups per tile,
+    // and the BatchNorm sums ride in the epilogue again); below that it is split 4-way
+    const int target = 512;
     if (dtype == FAVAE_F32)
         return scatter ? dispatch_kc<float, true>(p, classes, target, red.fused, st) : dispatch_kc<float, false>(p, classes, target, red.fused, st);
     return scatter ? dispatch_kc<bf16_t, true>(p, classes, target, red.fused, st) : dispatch_kc<bf16_t, false>(p, classes, target, red.fused, st);
@@ -1131,6 +1142,11 @@ extern "C" int favae_conv_wgrad_folded(const void* rows, int Rc, const void* col
 extern "C" int favae_debug_kc_stamps(unsigned long long* out64) {
     FAVAE_HIP(hipDeviceSynchronize());
     FAVAE_HIP(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_kc_stamps), 64 * sizeof(unsigned long long)));
+    return FAVAE_OK;
+}
+extern "C" int favae_debug_kc_blocks(unsigned long long* out16384) {
+    FAVAE_HIP(hipDeviceSynchronize());
+    FAVAE_HIP(hipMemcpyFromSymbol(out16384, HIP_SYMBOL(g_kc_blocks), 8192 * 2 * sizeof(unsigned long long)));
     return FAVAE_OK;
 }
 #endif

@@ -17,11 +17,12 @@ def timeit(fn, reps=30):
     return a.elapsed_time(b) / reps * 1e3
 rows = []
 import os
+SPLITK = int(os.environ.get('SPLITK', '0'))    # 0: the library's choice, 1: unsplit reductions
 ONLY = os.environ.get('ONLY')       # run only the layers whose name contains this (for rocprofv3 --pmc passes)
 def conv(name, Cin, Cout, Hi, Ho, ks, stride, scatter, taps_eff):
     if ONLY and ONLY not in name: return
     x = t(B, Hi, Hi, Cin); w = t(Cout, ks * ks, Cin); out = torch.empty(B, Ho, Ho, Cout, device=dev)
-    us = timeit(lambda: lib.conv_igemm(x, w, None, out, ks, stride, 1 if ks == 3 else 0, scatter, 0))
+    us = timeit(lambda: lib.conv_igemm(x, w, None, out, ks, stride, 1 if ks == 3 else 0, scatter, SPLITK))
     fl = 2.0 * B * Ho * Ho * Cout * taps_eff * Cin
     rows.append((name, us, fl / us / 1e6))
 def wgrad(name, Rc, rl, Cc, cl, Hs, Hl, ks, stride):

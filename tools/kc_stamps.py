@@ -23,3 +23,14 @@ names = {0: 'start', 1: 'addressing done', 2: 'first loads issued', 20: 'loop do
 for i in [0, 30, 31, 32, 33, 34] + list(range(1, 20)) + [20, 21]:
     if s[i]:
         print('%2d %-20s %8d cycles' % (i, names.get(i, 'chunk %d past barrier' % (i - 3)), s[i] - t0))
+
+import numpy as np
+blk = (ctypes.c_ulonglong * 16384)()
+raw.favae_debug_kc_blocks.argtypes = [ctypes.c_void_p]
+assert raw.favae_debug_kc_blocks(blk) == 0
+b = np.array(list(blk), dtype=np.float64).reshape(-1, 2)
+b = b[(b[:, 0] > 0) & (b[:, 1] > 0)]
+t0 = b[:, 0].min()
+st, en = (b[:, 0] - t0) / 100.0, (b[:, 1] - t0) / 100.0          # us (100 MHz clock)
+print('blocks %d: start us min %.2f median %.2f max %.2f; end us median %.2f max %.2f; lifetime us median %.2f max %.2f' % (
+    len(b), st.min(), np.median(st), st.max(), np.median(en), en.max(), np.median(en - st), (en - st).max()))
