@@ -7,6 +7,10 @@
 #include "favae_hip.h"
 
 static thread_local char g_err[512] = "";
+FlagCarry& favae_flag_carry() {
+    static thread_local FlagCarry c = {{nullptr, nullptr, nullptr, nullptr}, 0u, 0};
+    return c;
+}
 
 extern "C" void favae_set_error(const char* fmt, ...) {
     va_list ap;

@@ -74,6 +74,23 @@ __device__ __forceinline__ float wave_sum(float v) {
 // waits for outstanding vector memory operations on gfx950.
 __device__ __forceinline__ void wait_vm_writes() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Words to be stored by the first block of the next GEMM launch of this host thread (vae_model.hip, sp_record): dependency
+// points of the stream the launch goes to, passed when everything queued before that launch is complete.
+struct FlagCarry { unsigned* p[4]; unsigned val; int n; };
+FlagCarry& favae_flag_carry();                       // this thread's pending words (api.hip)
+inline FlagCarry favae_take_flag_carry() { FlagCarry& c = favae_flag_carry(); const FlagCarry k = c; c.n = 0; return k; }
+#ifdef __HIPCC__
+__device__ __forceinline__ void carry_store(const FlagCarry& c) {
+    if (c.n > 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+        // (explicit members: a dynamically indexed kernel argument would be copied to scratch memory)
+        __hip_atomic_store(c.p[0], c.val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (c.n > 1) __hip_atomic_store(c.p[1], c.val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (c.n > 2) __hip_atomic_store(c.p[2], c.val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (c.n > 3) __hip_atomic_store(c.p[3], c.val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+#endif
+
 // Optional live timing of selected launches (bench.py roofline): every `stride`-th launch of a kernel class is bracketed by
 // HIP events on its launch stream (api.hip); `work` is the algorithmic flops (GEMM classes) or bytes (HBM-bound classes).
 extern "C" int favae_prof_begin(int cls, double work, void* stream);

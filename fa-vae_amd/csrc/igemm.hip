@@ -132,6 +132,7 @@ struct KcParams {
     // eval-mode BatchNorm + LeakyReLU in the epilogue (staged 64x64 epilogue of unsplit reductions): the stored value is
     // lrelu(y * a[c] + b[c]) with ep_ab = a[Cout] | b[Cout] from the running statistics
     const float* ep_ab;
+    FlagCarry carry;   // dependency words of the launch stream, stored by the first block (common.h)
 };
 
 // 8 (bf16) or 4 (fp32) channels c0.. of the fused-input operand: BN affine + LeakyReLU(0.01), same expressions and rounding as
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
 
     KC_STAMP(0);
     KC_BLOCK(0);
+    carry_store(p.carry);
     const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);          // reduction group of this wave
     const int tid = KG == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 255);   // thread index inside the group
     const int lane = tid & 63, wave = tid >> 6;
@@ -697,6 +699,7 @@ struct PmParams {
     int Nb, Hs, Ws, Hl, Wl, ks, stride, pad, splitk, ntn, K;
     int overwrite;  // unsplit reductions store instead of adding (the caller guarantees dw == 0: splitk < 0)
     int Rst, Cst;   // rows / columns of dw that exist (<= Rc, Cc: operands padded to whole vectors, see favae_conv_wgrad_folded)
+    FlagCarry carry;   // dependency words of the launch stream, stored by the first block (common.h)
 };
 
 template <class T, int BM, int BN, int WM, int WN>
@@ -713,6 +716,7 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
     constexpr int NBUF = 2 * STAGE <= 65536 ? 2 : 1;
     __shared__ __attribute__((aligned(16))) char lds[NBUF * STAGE];
 
+    carry_store(p.carry);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int r0 = (blockIdx.x / p.ntn) * BM, c0 = (blockIdx.x % p.ntn) * BN;
@@ -858,6 +862,7 @@ int launch_kc(const KcParams& p, int classes, hipStream_t st) {
 template <class T, bool TR>
 int dispatch_kc(KcParams p, int classes, int target_blocks, int* fused, hipStream_t st) {
     const bool slow = (p.Cin % BK) != 0;
+    p.carry = favae_take_flag_carry();
     // Batch-64 layers are 2-5 GFLOP each: a 64x64 tile grid of 256-1024 blocks beat 128-wide tiles with deeper split-K
     // on every layer of the step (sweep on MI355X), because the fp32 atomic traffic of split-K grows with the tile
     // area while these grids already cover the 256 CUs.  128x32 serves the few-output-channel gather layers.
@@ -903,6 +908,7 @@ int dispatch_kc(KcParams p, int classes, int target_blocks, int* fused, hipStrea
 
 template <class T>
 int dispatch_pm(PmParams p, hipStream_t st) {
+    p.carry = favae_take_flag_carry();
     int tile = p.Rc <= 32 ? 0 : p.Cc <= 32 ? 1 : 2;   // 32x128, 128x32, 64x64
     if (g_force_pm_tile >= 0 && g_force_pm_tile <= 2) tile = g_force_pm_tile;
     const int BM = tile == 0 ? 32 : tile == 1 ? 128 : 64, BN = tile == 0 ? 128 : tile == 1 ? 32 : 64;

@@ -135,7 +135,9 @@ namespace {
 template <class T, int CS, int CO, bool RED>
 __global__ __launch_bounds__(256) void conv_thin_in(const T* __restrict__ in, const float* __restrict__ wk /* [9*CS][CO] fp32 */,
                                                     const float* __restrict__ bias, float* __restrict__ out, int Hi, int Wi,
-                                                    int Ho, int Wo, int stride, int flip, int total, int out_bf16, const ThinRed red) {
+                                                    int Ho, int Wo, int stride, int flip, int total, int out_bf16, const ThinRed red,
+                                                    const FlagCarry carry) {
+    carry_store(carry);
     const int pix = min(blockIdx.x * 256 + (int)threadIdx.x, total - 1);   // tail threads redo the last pixel, store nothing
     const int n = pix / (Ho * Wo), rem = pix - n * Ho * Wo, y = rem / Wo, x = rem - y * Wo;
     float v[9 * CS];
@@ -282,6 +284,7 @@ int thin_in_launch(const void* in, const void* w, const float* bias, float* out,
     float* wk_scratch = per_device[dev] + (size_t)(g_wk_next.fetch_add(1u) % WK_SLOTS) * WK_FLOATS;
     const int total = Nb * Ho * Wo, K = 9 * Cs;
     const int grid = cdiv(total, 256);
+    const FlagCarry carry = favae_take_flag_carry();
     if (dtype == FAVAE_F32)
         hipLaunchKernelGGL(thin_in_wprep<float>, dim3(cdiv(K * Co, 256)), dim3(256), 0, st, (const float*)w, wk_scratch, K, Co);
     else
@@ -289,10 +292,10 @@ int thin_in_launch(const void* in, const void* w, const float* bias, float* out,
 #define TI_CASE(T_, CS_)                                                                                                   \
     if (red.bins)                                                                                                          \
         hipLaunchKernelGGL((conv_thin_in<T_, CS_, 64, true>), dim3(grid), dim3(256), 4 * 64 * (32 + 4) * sizeof(float), st, (const T_*)in, wk_scratch, bias, out, Hi, Wi, \
-                           Ho, Wo, stride, scatter, total, out_bf16, red);                                                 \
+                           Ho, Wo, stride, scatter, total, out_bf16, red, carry);                                          \
     else                                                                                                                   \
         hipLaunchKernelGGL((conv_thin_in<T_, CS_, 64, false>), dim3(grid), dim3(256), 4 * 64 * (32 + 4) * sizeof(float), st, (const T_*)in, wk_scratch, bias, out, Hi, Wi, \
-                           Ho, Wo, stride, scatter, total, out_bf16, red)
+                           Ho, Wo, stride, scatter, total, out_bf16, red, carry)
     if (dtype == FAVAE_F32) {
         switch (Cs) { case 1: TI_CASE(float, 1); break; case 2: TI_CASE(float, 2); break; case 3: TI_CASE(float, 3); break; default: TI_CASE(float, 4); }
     } else {

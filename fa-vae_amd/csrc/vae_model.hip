@@ -129,6 +129,16 @@ struct Worker {
         if (r != FAVAE_OK) favae_set_error("%s", err);
         return r;
     }
+    // queue position now; wait_until(m): everything handed over before mark() returned m has been issued
+    unsigned mark() const { return tail.load(std::memory_order_relaxed); }
+    int wait_until(unsigned m) {
+        const double t0 = now();
+        while ((int)(head.load(std::memory_order_acquire) - m) < 0) __builtin_ia32_pause();
+        drain_wait += now() - t0;
+        const int r = rc.load(std::memory_order_acquire);
+        if (r != FAVAE_OK) favae_set_error("%s", err);
+        return r;
+    }
     void finish() { stop.store(true, std::memory_order_release); if (th.joinable()) th.join(); }
 };
 
@@ -188,11 +198,78 @@ struct Vae {
     bool data_u8;   // the resident data set handed to the step / encode / reconstruction calls is uint8 (favae_vae_set_data_u8)
     bool eval_fused, eval_ab_ready;   // eval-mode BatchNorm in the GEMM epilogues (large-batch eval executor); ab[] holds the running-stat form
     float* ab[NL]; bool act_deferred[NL]; bool bn_published[NL]; bool fi_on; int fi_pend[NL], fi_npend, fi_flushes; hipEvent_t ev_fi[2], ev_acts; bool acts_wait;
+    // Dependency points between the streams (see sp_record / sp_wait): in threaded single-device epochs they are 32-bit words in
+    // device memory written / awaited by stream memory operations with the step number as value, otherwise the events above.
+    unsigned* flags; unsigned step_no, join_seq; bool vals; int vals_ok;   // vals_ok: -1 not probed, 0 unsupported, 1 usable
+    unsigned mark_prev, mark_cur;   // worker queue positions at the start of the previous / this step (bounded run-ahead)
     char* shp(int half) const { return SH + (size_t)half * sh_half; }
     const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(shp(sh_sel) + L[l].wc_off * esz); }
     const void* Wt(int l) const { return (const void*)(shp(sh_sel) + L[l].wt_off * esz); }
     long long rows(int l, int B) const { return (long long)B * L[l].Hout * L[l].Hout; }
 };
+
+// Dependency points.  A point is recorded on one stream once per training step and awaited on others.
+enum { SP_FORK = 0 /* + layer */, SP_WG = NL /* + layer */, SP_DG = 2 * NL /* + layer */, SP_BATCH = 3 * NL, SP_FOLD, SP_JOIN, SP_JOIN2, SP_X,
+       SP_FI0, SP_FI1, SP_ACTS, SP_COUNT };
+
+hipEvent_t sp_event(Vae& v, int sp) {
+    if (sp < SP_WG) return v.ev_fork[sp - SP_FORK];
+    if (sp < SP_DG) return v.ev_wg[sp - SP_WG];
+    if (sp < SP_BATCH) return v.ev_dg[sp - SP_DG];
+    switch (sp) {
+    case SP_BATCH: return v.ev_batch;
+    case SP_FOLD: return v.ev_fold;
+    case SP_JOIN: return v.ev_join;
+    case SP_JOIN2: return v.ev_join2;
+    case SP_X: return v.ev_x;
+    case SP_FI0: return v.ev_fi[0];
+    case SP_FI1: return v.ev_fi[1];
+    default: return v.ev_acts;
+    }
+}
+
+// Values mode (v.vals): hipStreamWriteValue32 / hipStreamWaitValue32 on flags[sp] with the step number `seq` of the record.
+// Measured on MI355X / ROCm 7.2 (tools/micro/stream_value.hip): 2.1-2.3 us of host time per call against ~12 us for an event
+// record + wait pair, half the hand-over latency on the device -- and, unlike an event, the wait may be issued before the record,
+// so the caller's thread and the enqueue worker need not meet once per step.  A word only grows, so a late wait is satisfied by
+// a later record of the same point, which the stream order of the recording side places after the one that was meant.
+__global__ void set_flag_kernel(FlagCarry c) { carry_store(c); }
+long long g_carry_flushes = 0;   // FAVAE_VERBOSE accounting: dependency words that needed a launch of their own
+
+// Values mode (v.vals): the points are 32-bit words in device memory that hold the number of the step that last passed them.
+// Measured on MI355X / ROCm 7.2 (tools/micro/stream_value.hip):
+//  * an event record between two kernels of a chain costs the chain ~4.1 us (a barrier packet), hipStreamWriteValue32 ~4.6 us, a
+//    one-wave kernel 2.3 us -- and a store at the top of the chain's NEXT kernel costs nothing.  So a point passed on the caller's
+//    stream is not enqueued at all: its word rides with the next GEMM launch of that stream (FlagCarry, common.h), whose first
+//    block stores it -- that kernel runs only when everything before it on the stream is complete;
+//  * hipStreamWaitValue32 / hipStreamWriteValue32 take 2.1-2.4 us of host time, an event record + wait pair ~12 us;
+//  * a wait may be issued before the write it waits for, so the caller's thread and the enqueue worker need not meet once per step.
+// A word only grows, so a late wait is satisfied by a later pass of the same point, which stream order places after the one meant.
+int sp_record(Vae& v, int sp, hipStream_t s, unsigned seq, bool carry = false) {
+    if (!v.vals) { FAVAE_HIP(hipEventRecord(sp_event(v, sp), s)); return FAVAE_OK; }
+    if (carry) {
+        FlagCarry& c = favae_flag_carry();
+        if (c.n < 4 && (c.n == 0 || c.val == seq)) { c.p[c.n++] = v.flags + sp; c.val = seq; return FAVAE_OK; }
+    }
+    FAVAE_HIP(hipStreamWriteValue32(s, v.flags + sp, seq, 0));
+    return FAVAE_OK;
+}
+// the words handed to favae_flag_carry() that no launch has taken along: a launch of their own
+int sp_flush_carry(hipStream_t s) {
+    FlagCarry& c = favae_flag_carry();
+    if (!c.n) return FAVAE_OK;
+    const FlagCarry k = c;
+    c.n = 0;
+    ++g_carry_flushes;
+    hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(64), 0, s, k);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+int sp_wait(Vae& v, int sp, hipStream_t s, unsigned seq) {
+    if (v.vals) { FAVAE_HIP(hipStreamWaitValue32(s, v.flags + sp, seq, hipStreamWaitValueGte, 0xFFFFFFFFu)); }
+    else { FAVAE_HIP(hipStreamWaitEvent(s, sp_event(v, sp), 0)); }
+    return FAVAE_OK;
+}
 
 struct Carver {
     char* base; size_t off, cap;
@@ -275,6 +352,7 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
     v.scratch_doubles = 2 * 1024 * 64 + 4096;
     v.scratch = (double*)c.take(v.scratch_doubles * 8);
     v.metrics2 = (double*)c.take(2 * 8);
+    v.flags = (unsigned*)c.take((SP_COUNT + 1) * sizeof(unsigned));   // (+1: the word the support probe writes)
     *need = c.off + 256;
 }
 
@@ -442,18 +520,18 @@ bool fi_ok(const Vae& v, int l, bool train, bool pooled) {
 int fi_flush(Vae& v, int B, void* st) {
     if (!v.fi_npend) return FAVAE_OK;
     const int k = v.fi_flushes++ & 1;
-    FAVAE_HIP(hipEventRecord(v.ev_fi[k], (hipStream_t)st));
+    const unsigned seq = v.step_no;
+    RC(sp_record(v, SP_FI0 + k, (hipStream_t)st, seq));
     int ls[NL]; const int n = v.fi_npend;
     for (int i = 0; i < n; ++i) ls[i] = v.fi_pend[i];
     v.fi_npend = 0;
     v.acts_wait = true;
     int l0 = ls[0], l1 = n > 1 ? ls[1] : -1, l2 = n > 2 ? ls[2] : -1, l3 = n > 3 ? ls[3] : -1;
-    return side_do(v, [&v, k, B, l0, l1, l2, l3]() -> int {
-        FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_fi[k], 0));
+    return side_do(v, [&v, k, B, l0, l1, l2, l3, seq]() -> int {
+        RC(sp_wait(v, SP_FI0 + k, v.side, seq));
         for (int l : {l0, l1, l2, l3})
             if (l >= 0) RC(favae_bn_lrelu_fwd_ab(v.raw[l], v.ab[l], v.act[l], v.rows(l, B), v.L[l].Cout, v.dtype, (void*)v.side));
-        FAVAE_HIP(hipEventRecord(v.ev_acts, v.side));
-        return FAVAE_OK;
+        return sp_record(v, SP_ACTS, v.side, seq);
     });
 }
 
@@ -536,17 +614,18 @@ template <class F> int side_do(Vae& v, F&& f) {
 // is queued on the side stream behind an event, so the main stream continues with the input gradient at once
 int wgrad(Vae& v, int l, const void* in, int B, void* st) {
     if (!v.overlap) return wgrad_launch(v, l, in, B, st);
-    FAVAE_HIP(hipEventRecord(v.ev_fork[l], (hipStream_t)st));
+    const unsigned seq = v.step_no;
+    RC(sp_record(v, SP_FORK + l, (hipStream_t)st, seq, true));   // rides with the input-gradient GEMM queued next
     const Ada ada = v.ada;
     const bool merged = v.merged; const int half = v.upd_half;
-    return side_do(v, [&v, l, in, B, ada, merged, half]() -> int {
-        FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_fork[l], 0));
+    return side_do(v, [&v, l, in, B, ada, merged, half, seq]() -> int {
+        RC(sp_wait(v, SP_FORK + l, v.side, seq));
         RC(wgrad_launch(v, l, in, B, (void*)v.side));
         if (!ada.on) return FAVAE_OK;
         if (merged && (v.fuse & 0x20000u)) return adam_layer(v, l, (void*)v.side, ada, half);   // same stream: no further event
-        FAVAE_HIP(hipEventRecord(v.ev_wg[l], v.side));
+        RC(sp_record(v, SP_WG + l, v.side, seq));
         if (merged) {   // optimiser stream, one wait: the update writes the shadow half no queued GEMM reads
-            FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[l], 0));
+            RC(sp_wait(v, SP_WG + l, v.side2, seq));
             return adam_layer(v, l, (void*)v.side2, ada, half);
         }
         // Layer-wise optimiser step on the third stream.  The layer whose weight gradient was queued before this one may be
@@ -554,8 +633,8 @@ int wgrad(Vae& v, int l, const void* in, int B, void* st) {
         // has run: this fork event was recorded after that GEMM was queued on the main stream.  Its BN / bias gradients
         // were complete before its own fork.
         if (v.pending >= 0) {
-            FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_fork[l], 0));
-            FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[v.pending], 0));
+            RC(sp_wait(v, SP_FORK + l, v.side2, seq));
+            RC(sp_wait(v, SP_WG + v.pending, v.side2, seq));
             RC(adam_layer(v, v.pending, (void*)v.side2, ada, half));
             v.pending = -1;
         }
@@ -568,12 +647,13 @@ int wgrad(Vae& v, int l, const void* in, int B, void* st) {
 // (encoder.1, whose update would otherwise sit between the last weight gradient and the end of the step) get an event
 int after_dgrad(Vae& v, int l, void* st) {
     if (!(v.overlap && v.ada.on && !v.merged && (v.dg_all || l == 1))) return FAVAE_OK;
-    FAVAE_HIP(hipEventRecord(v.ev_dg[l], (hipStream_t)st));
+    const unsigned seq = v.step_no;
+    RC(sp_record(v, SP_DG + l, (hipStream_t)st, seq));
     const Ada ada = v.ada;
     const int half = v.upd_half;
-    return side_do(v, [&v, l, ada, half]() -> int {
-        FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_dg[l], 0));
-        FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[l], 0));
+    return side_do(v, [&v, l, ada, half, seq]() -> int {
+        RC(sp_wait(v, SP_DG + l, v.side2, seq));
+        RC(sp_wait(v, SP_WG + l, v.side2, seq));
         return adam_layer(v, l, (void*)v.side2, ada, half);
     });
 }
@@ -711,6 +791,11 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
         favae_set_error("favae_vae_create: workspace %zu < %zu or shadow %zu < %zu", workspace_bytes, need, shadow_bytes, 2 * v.sh_half);
         return FAVAE_ERR_ARG;
     }
+    if (hipMemset(v.flags, 0, (SP_COUNT + 1) * sizeof(unsigned)) != hipSuccess) {
+        delete h;
+        favae_set_error("favae_vae_create: could not clear the dependency words");
+        return FAVAE_ERR_HIP;
+    }
     const char* e = getenv("FAVAE_SINGLE_STREAM");
     v.overlap = !(e && e[0] == '1');
     v.side = nullptr;
@@ -721,6 +806,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.wk = nullptr;
     v.eval_fused = batch_max >= 256 && !(getenv("FAVAE_EVAL_FUSED") && getenv("FAVAE_EVAL_FUSED")[0] == '0');
     v.eval_ab_ready = false;
+    v.step_no = 0; v.join_seq = 0; v.vals = false; v.vals_ok = -1; v.mark_prev = v.mark_cur = 0;
     v.data_u8 = false;
     v.fi_on = false; v.fi_npend = 0; v.fi_flushes = 0; v.acts_wait = false;
     for (int l = 0; l < NL; ++l) v.act_deferred[l] = v.bn_published[l] = false;
@@ -812,8 +898,8 @@ int wait_join(Vae& v, hipStream_t st) {
     if (v.ev_join_ext) {
         FAVAE_HIP(hipStreamWaitEvent(st, v.ev_join_ext, 0));
     } else {
-        FAVAE_HIP(hipStreamWaitEvent(st, v.ev_join, 0));
-        if (v.join2) FAVAE_HIP(hipStreamWaitEvent(st, v.ev_join2, 0));
+        RC(sp_wait(v, SP_JOIN, st, v.join_seq));
+        if (v.join2) RC(sp_wait(v, SP_JOIN2, st, v.join_seq));
     }
     return FAVAE_OK;
 }
@@ -829,6 +915,13 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
         // the tap gather of the NEXT step -- moves to the weight-gradient stream, which is idle at that point.
         v.inline_tail = epoch && !v.dp_epoch && can_fold && !(v.fuse & 0x2000u);
         v.x_folded = false;
+        ++v.step_no;
+        const unsigned seq = v.step_no;
+        if (v.vals && v.wk) {   // bounded run-ahead: the worker has issued everything handed over before the previous step began
+            RC(v.wk->wait_until(v.mark_prev));
+            v.mark_prev = v.mark_cur;
+            v.mark_cur = v.wk->mark();
+        }
         // single-device epochs: a layer's update follows its weight gradient at once (optimiser stream, one event wait) and
         // writes the other shadow half (FAVAE_FUSE_MASK bit 0x10000: in place, behind the layer's input-gradient GEMM, i.e.
         // two more waits per layer; bit 0x20000: on the weight-gradient stream itself, no wait)
@@ -846,23 +939,23 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             v.fold_sel ^= 1;
             v.fold0 = v.fold0_buf[v.fold_sel];   // the previous step's gradient GEMM may still read the other one
             const bool jp = v.join_pending;
-            if (!jp) FAVAE_HIP(hipEventRecord(v.ev_x, (hipStream_t)st));
+            if (!jp) RC(sp_record(v, SP_X, (hipStream_t)st, seq));
             float* xf = v.xf; char* xt = v.xt; char* fold0 = v.fold0;
-            RC(side_do(v, [&v, jp, xf, xt, fold0, data_nhwc, idx, B]() -> int {
+            RC(side_do(v, [&v, jp, xf, xt, fold0, data_nhwc, idx, B, seq]() -> int {
                 // behind the previous step's last reader of the zero pool (BN backward of encoder.0), not behind its tail
-                FAVAE_HIP(hipStreamWaitEvent(v.side, jp ? v.ev_fork[0] : v.ev_x, 0));
+                if (jp) RC(sp_wait(v, SP_FORK + 0, v.side, seq - 1)); else RC(sp_wait(v, SP_X, v.side, seq));
                 FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, v.side));
                 RC(gather(v, data_nhwc, idx, B, xf, xt, (void*)v.side));
-                FAVAE_HIP(hipEventRecord(v.ev_batch, v.side));
+                RC(sp_record(v, SP_BATCH, v.side, seq));
                 RC(favae_conv_fold_taps(xt, fold0, v.fold0_bytes, B, 32, 32, 64, 64, v.ch, 2, 0, v.dtype, (void*)v.side));
-                FAVAE_HIP(hipEventRecord(v.ev_fold, v.side));
-                return FAVAE_OK;
+                return sp_record(v, SP_FOLD, v.side, seq);
             }));
             v.x_folded = true;
-            // the worker has issued everything of the previous step and the job above: ev_batch / ev_fold / ev_join are
-            // recorded, and every event of the previous step has been consumed before this step records it again
-            if (v.wk) RC(v.wk->drain());
-            FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_batch, 0));
+            // events: the worker has issued everything of the previous step and the job above, so ev_batch / ev_fold / ev_join are
+            // recorded, and every event of the previous step has been consumed before this step records it again.  Values: the
+            // waits below may be issued before the worker issues the writes; nothing to meet for.
+            if (v.wk && !v.vals) RC(v.wk->drain());
+            RC(sp_wait(v, SP_BATCH, (hipStream_t)st, seq));
         } else {
             if (!epoch) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));
             FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, (hipStream_t)st));
@@ -871,15 +964,15 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             if (can_fold) {
                 // encoder.0's weight gradient ends the step: its tap gather needs the batch only, so it runs now, on the
                 // weight-gradient stream (idle during the forward pass; in order behind the previous step's last reader of fold0)
-                FAVAE_HIP(hipEventRecord(v.ev_x, (hipStream_t)st));
+                RC(sp_record(v, SP_X, (hipStream_t)st, seq));
                 char* xt = v.xt; char* fold0 = v.fold0;
-                RC(side_do(v, [&v, xt, fold0, B]() -> int {
-                    FAVAE_HIP(hipStreamWaitEvent(v.side, v.ev_x, 0));
+                RC(side_do(v, [&v, xt, fold0, B, seq]() -> int {
+                    RC(sp_wait(v, SP_X, v.side, seq));
                     return favae_conv_fold_taps(xt, fold0, v.fold0_bytes, B, 32, 32, 64, 64, v.ch, 2, 0, v.dtype, (void*)v.side);
                 }));
                 v.x_folded = true;
             }
-            if (v.wk) RC(v.wk->drain());
+            if (v.wk && !v.vals) RC(v.wk->drain());
         }
         if (v.join_pending) {   // the previous step's weight gradients / updates, still running next to the launches above
             RC(wait_join(v, (hipStream_t)st));
@@ -908,19 +1001,21 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
     }
     for (int sg = stage_lo; sg < stage_hi; ++sg) {
         if (sg == 0 && v.acts_wait) {   // the backward pass reads activations that were materialised on the weight-gradient stream
-            if (v.wk) RC(v.wk->drain());
-            FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_acts, 0));
+            if (v.wk && !v.vals) RC(v.wk->drain());
+            RC(sp_wait(v, SP_ACTS, (hipStream_t)st, v.step_no));
             v.acts_wait = false;
         }
         if (sg == 0) {
             RC(wgrad(v, L_OUT, v.act[11], B, st));
             RC(dgrad(v, L_OUT, v.dact[11], B, st, v.dact_pooled[11], v.dact_bf[11], 11));
+            RC(sp_flush_carry((hipStream_t)st));
             RC(after_dgrad(v, L_OUT, st));
         } else if (sg <= 5) {
             const int l = 12 - sg;   // 11 .. 7
             RC(bn_bwd(v, l, B, st));
             RC(wgrad(v, l, v.act[l - 1], B, st));
             RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1], v.dact_bf[l - 1], l > 7 ? l - 1 : -1));
+            RC(sp_flush_carry((hipStream_t)st));
             RC(after_dgrad(v, l, st));
         } else if (sg == 6) {
             v.rk_done = !(v.fuse & 0x8000u) && (v.fuse & 16u) && v.z <= 128 && (long long)B * 2 * v.z <= (v.z <= 32 ? 8192 : 16384);
@@ -939,6 +1034,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             }
             RC(wgrad(v, L_DI, v.zlat, B, st));
             RC(dgrad(v, L_DI, v.dz, B, st, true));
+            RC(sp_flush_carry((hipStream_t)st));
             RC(after_dgrad(v, L_DI, st));
         } else if (sg == 7) {
             if (v.rk_done) {
@@ -952,24 +1048,28 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             }
             RC(wgrad(v, L_FC, v.act[4], B, st));
             RC(dgrad(v, L_FC, v.dact[4], B, st, v.dact_pooled[4]));
+            RC(sp_flush_carry((hipStream_t)st));
             RC(after_dgrad(v, L_FC, st));
         } else if (sg <= 11) {
             const int l = 12 - sg;   // 4 .. 1
             RC(bn_bwd(v, l, B, st));
             RC(wgrad(v, l, v.act[l - 1], B, st));
             RC(dgrad(v, l, v.dact[l - 1], B, st, v.dact_pooled[l - 1], v.dact_bf[l - 1], l - 1));
+            RC(sp_flush_carry((hipStream_t)st));
             RC(after_dgrad(v, l, st));
         } else {
             RC(bn_bwd(v, 0, B, st));
             if (v.inline_tail) {
-                FAVAE_HIP(hipEventRecord(v.ev_fork[0], (hipStream_t)st));   // the next step's memset / gather may start here
-                FAVAE_HIP(hipStreamWaitEvent((hipStream_t)st, v.ev_fold, 0));
+                RC(sp_record(v, SP_FORK + 0, (hipStream_t)st, v.step_no, true));   // the next step's memset / gather may start here (rides with the weight-gradient GEMM below)
+                RC(sp_wait(v, SP_FOLD, (hipStream_t)st, v.step_no));
                 RC(wgrad_launch(v, 0, v.xt, B, st));
+                RC(sp_flush_carry((hipStream_t)st));
             } else {
                 RC(wgrad(v, 0, v.xt, B, st));
             }
         }
     }
+    RC(sp_flush_carry((hipStream_t)st));   // (a point no launch of this call took along)
     if (stage_hi == N_STAGES && v.overlap && !v.dp_epoch) {   // (data-parallel epochs join through favae_vae_fence)
         if (v.ada.on && v.merged) {
             // every update has been queued behind its weight gradient on the weight-gradient stream; encoder.0's (no input
@@ -979,14 +1079,18 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             if (v.inline_tail) RC(adam_layer(v, 0, st, ada, half));
             v.join2 = false;
             // (the optimiser stream has waited for every weight gradient of the weight-gradient stream)
-            RC(side_do(v, [&v]() -> int { FAVAE_HIP(hipEventRecord(v.ev_join, (v.fuse & 0x20000u) ? v.side : v.side2)); return FAVAE_OK; }));
+            const unsigned seq = v.step_no;
+            v.join_seq = seq;
+            RC(side_do(v, [&v, seq]() -> int { return sp_record(v, SP_JOIN, (v.fuse & 0x20000u) ? v.side : v.side2, seq); }));
             v.sh_sel = half;   // the next step reads the half this step's updates wrote
         } else if (v.ada.on) {   // encoder.0: no input gradient reads its shadows
             const Ada ada = v.ada;
             const int half = v.upd_half;
-            RC(side_do(v, [&v, ada, half]() -> int {
+            const unsigned seq = v.step_no;
+            v.join_seq = seq;
+            RC(side_do(v, [&v, ada, half, seq]() -> int {
                 if (v.pending >= 0 && v.pending != 0) {
-                    FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[v.pending], 0));
+                    RC(sp_wait(v, SP_WG + v.pending, v.side2, seq));
                     RC(adam_layer(v, v.pending, (void*)v.side2, ada, half));
                 }
                 v.pending = -1;
@@ -999,20 +1103,22 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             if (v.inline_tail) {
                 RC(adam_layer(v, 0, st, ada, half));
             } else {
-                RC(side_do(v, [&v, ada, join2, half]() -> int {
-                    if (!join2) FAVAE_HIP(hipStreamWaitEvent(v.side2, v.ev_wg[0], 0));
+                RC(side_do(v, [&v, ada, join2, half, seq]() -> int {
+                    if (!join2) RC(sp_wait(v, SP_WG + 0, v.side2, seq));
                     return adam_layer(v, 0, (void*)(join2 ? v.side : v.side2), ada, half);
                 }));
             }
             // every other weight gradient of the side stream is awaited by the update of its layer on side2
-            RC(side_do(v, [&v, join2]() -> int {
-                FAVAE_HIP(hipEventRecord(v.ev_join, v.side2));
-                if (join2) FAVAE_HIP(hipEventRecord(v.ev_join2, v.side));
+            RC(side_do(v, [&v, join2, seq]() -> int {
+                RC(sp_record(v, SP_JOIN, v.side2, seq));
+                if (join2) RC(sp_record(v, SP_JOIN2, v.side, seq));
                 return FAVAE_OK;
             }));
         } else {
             v.join2 = false;
-            RC(side_do(v, [&v]() -> int { FAVAE_HIP(hipEventRecord(v.ev_join, v.side)); return FAVAE_OK; }));
+            const unsigned seq = v.step_no;
+            v.join_seq = seq;
+            RC(side_do(v, [&v, seq]() -> int { return sp_record(v, SP_JOIN, v.side, seq); }));
         }
         if (epoch) v.join_pending = true;   // favae_vae_train_epoch joins before the next forward pass / at its end
         else { if (v.wk) RC(v.wk->drain()); RC(wait_join(v, (hipStream_t)st)); }
@@ -1093,6 +1199,17 @@ extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const
         FAVAE_HIP(hipGetDevice(&dev));
         wk = new (std::nothrow) Worker();
         if (wk) { wk->start(dev); v.wk = wk; }
+        // dependency points as stream memory operations (sp_record / sp_wait); FAVAE_SYNC_VALUES=0: events, and the caller meets
+        // the worker once per step
+        const char* sv = getenv("FAVAE_SYNC_VALUES");
+        if (wk && !(sv && sv[0] == '0')) {
+            if (v.vals_ok < 0) {
+                v.vals_ok = hipStreamWriteValue32((hipStream_t)st, v.flags + SP_COUNT, 1u, 0) == hipSuccess ? 1 : 0;
+                if (!v.vals_ok) (void)hipGetLastError();
+            }
+            v.vals = v.vals_ok == 1;
+            v.mark_prev = v.mark_cur = wk->mark();
+        }
     }
     int rc = FAVAE_OK;
     for (long long o = 0; o < n && rc == FAVAE_OK; o += batch, ++s) {
@@ -1111,8 +1228,8 @@ extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const
         const int wrc = wk->drain();
         wk->finish();
         if (getenv("FAVAE_VERBOSE"))
-            fprintf(stderr, "favae: enqueue worker: %lld jobs, %.1f us busy per step; caller waited %.1f us per step for it\n", wk->jobs,
-                    1e6 * wk->busy / (double)s, 1e6 * wk->drain_wait / (double)s);
+            fprintf(stderr, "favae: enqueue worker: %lld jobs, %.1f us busy per step; caller waited %.1f us per step for it; %lld dependency words launched on their own so far\n", wk->jobs,
+                    1e6 * wk->busy / (double)s, 1e6 * wk->drain_wait / (double)s, g_carry_flushes);
         v.wk = nullptr;
         delete wk;
         if (rc == FAVAE_OK) rc = wrc;
@@ -1121,6 +1238,14 @@ extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const
         (void)wait_join(v, (hipStream_t)st);
         v.join_pending = false;
     }
+    if (v.vals && rc != FAVAE_OK) {
+        // a failed step may have left waits whose writes were never issued: satisfy every point, let the queues run dry, start over
+        (void)hipMemsetD32Async((hipDeviceptr_t)v.flags, 0x7FFFFFFF, SP_COUNT, v.side3);
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(v.flags, 0, SP_COUNT * sizeof(unsigned));
+        v.step_no = 0;
+    }
+    v.vals = false;
     v.pending = -1;
     v.merged = false;
     if (v.sh_sel != 0) {   // outside an epoch half 0 is the current one (a second executor may share the shadow buffer)

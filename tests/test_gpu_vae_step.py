@@ -204,9 +204,11 @@ def test_staged_step_equals_the_whole_step(dtype):
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("bf16", 1e-2)])
 def test_epoch_with_the_enqueue_worker_equals_the_single_threaded_epoch(dtype, tol):
     """Epochs of >= 4 steps hand their side-stream calls (weight gradients, layer-wise Adam, the next batch's gather) to a
-    second host thread (csrc/vae_model.hip, struct Worker).  Same launches on the same streams behind the same events:
-    the per-step metrics of a 7-step epoch (last batch ragged) agree with FAVAE_ENQUEUE_THREAD=0 up to the reordering of
-    split-K atomics, over two consecutive epochs (the worker is created per epoch)."""
+    second host thread (csrc/vae_model.hip, struct Worker), with the dependencies between the streams carried by 32-bit words
+    in device memory (stream memory operations; the words of the caller's stream ride with its next GEMM launch) or, with
+    FAVAE_SYNC_VALUES=0, by events.  Same launches on the same streams behind the same dependencies: the per-step metrics of
+    a 7-step epoch (last batch ragged) agree with FAVAE_ENQUEUE_THREAD=0 up to the reordering of split-K atomics, over two
+    consecutive epochs (the worker is created per epoch)."""
     import os
     z, Bn, N = 20, 64, 6 * 64 + 17
     torch.manual_seed(0)
@@ -219,9 +221,11 @@ def test_epoch_with_the_enqueue_worker_equals_the_single_threaded_epoch(dtype, t
     prior = torch.from_numpy(np.random.RandomState(7).randn(N, z) * 0.5).cuda()
     out = {}
     old = os.environ.get("FAVAE_ENQUEUE_THREAD")
+    old_sv = os.environ.get("FAVAE_SYNC_VALUES")
     try:
-        for mode in ("0", "1"):
-            os.environ["FAVAE_ENQUEUE_THREAD"] = mode
+        for mode in ("0", "1", "1e"):
+            os.environ["FAVAE_ENQUEUE_THREAD"] = mode[0]
+            os.environ["FAVAE_SYNC_VALUES"] = "0" if mode == "1e" else "1"
             eng = _engine(z, dtype)
             eng.load_state_dict(sd)
             data = eng.upload_images(img)
@@ -235,7 +239,16 @@ def test_epoch_with_the_enqueue_worker_equals_the_single_threaded_epoch(dtype, t
             os.environ.pop("FAVAE_ENQUEUE_THREAD", None)
         else:
             os.environ["FAVAE_ENQUEUE_THREAD"] = old
-    m0, m1 = out["0"][0], out["1"][0]
+        if old_sv is None:
+            os.environ.pop("FAVAE_SYNC_VALUES", None)
+        else:
+            os.environ["FAVAE_SYNC_VALUES"] = old_sv
+    _same_epochs(out["0"], out["1"], dtype)
+    _same_epochs(out["0"], out["1e"], dtype)
+
+
+def _same_epochs(a, b, dtype):
+    m0, m1 = a[0], b[0]
     assert np.isfinite(m1).all() and (m1[:, :, 0] > 0).all()
     assert np.allclose(m1[0, 0], m0[0, 0], rtol=1e-6 if dtype == "f32" else 1e-4)          # first step: identical inputs and weights
     # later steps: Adam's first steps move every entry by +-lr whatever the gradient magnitude, so entries whose gradient
@@ -244,7 +257,7 @@ def test_epoch_with_the_enqueue_worker_equals_the_single_threaded_epoch(dtype, t
     assert np.allclose(m1[:, :, 0], m0[:, :, 0], rtol=1e-2 if dtype == "f32" else 5e-2), np.abs(m1[:, :, 0] / m0[:, :, 0] - 1).max()
     assert np.median(np.abs(np.log(m1[:, :, 1] / m0[:, :, 1]))) < 0.2   # (single steps spike: the KL term is chaotic early on)
     for k in ("enc.0.1.running_mean", "final_layer.1.running_var"):
-        assert _rel(out["1"][1][k].numpy(), out["0"][1][k].numpy()) <= 5e-2, k
+        assert _rel(b[1][k].numpy(), a[1][k].numpy()) <= 5e-2, k
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
