@@ -171,6 +171,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, siz
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes < (size_t)0x7FFFFFF0 ? bytes : (size_t)0x7FFFFFF0), 0x00020000);
 }
 constexpr unsigned BUF_OOB = 0x80000000u;
+// sum of two byte offsets either of which may carry the out-of-range bit
+__device__ __forceinline__ unsigned buf_off_add(unsigned a, unsigned b) { return ((a & ~BUF_OOB) + (b & ~BUF_OOB)) | ((a | b) & BUF_OOB); }
 __device__ __forceinline__ unsigned outside_bit(int v, int n) { return (unsigned)v >= (unsigned)n ? 1u : 0u; }
 // kernel row / column of the i-th valid tap of a launch slice: stride-2 scatter form: parity class pp uses taps {1} or {0, 2}
 template <bool TR> __device__ __forceinline__ int tap_k(bool s2, int pp, int i) { return (TR && s2) ? (pp ? 2 * i : 1) : i; }
@@ -700,9 +702,16 @@ struct PmParams {
     int overwrite;  // unsplit reductions store instead of adding (the caller guarantees dw == 0: splitk < 0)
     int Rst, Cst;   // rows / columns of dw that exist (<= Rc, Cc: operands padded to whole vectors, see favae_conv_wgrad_folded)
     FlagCarry carry;   // dependency words of the launch stream, stored by the first block (common.h)
+    int hw_shift, ws_shift;   // log2 of Hs*Ws and Ws when both are powers of two (every layer of the model), else -1
 };
 
-template <class T, int BM, int BN, int WM, int WN>
+// LEAN: both channel counts fill 16-byte vectors and both operands are below 2 GB.  The operands come through buffer
+// descriptors: the small-grid operand's descriptor is moved to the chunk (scalar arithmetic), so its per-lane offset is a
+// constant and the tail of the reduction falls off the end of the descriptor; the gathered operand's offset is rebuilt per chunk
+// from shifts (power-of-two feature maps) and halo pixels get an out-of-range offset.  Out-of-range loads return zeros: no
+// select per vector.  (The general form below spent ~100 instructions per vector on two integer divisions, clamps and 64-bit
+// products, against two MFMAs per chunk and wave: issue-bound, like igemm_kc before its addressing was hoisted.)
+template <class T, int BM, int BN, int WM, int WN, bool LEAN>
 __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
     constexpr int VE = 16 / sizeof(T);
     constexpr int RSR = BM * sizeof(T) + 16, RSC = BN * sizeof(T) + 16;
@@ -777,6 +786,68 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
         return mask;
     };
 
+    // ---- lean form ----
+    [[maybe_unused]] unsigned r_off[VR], c_off[VC];   // small-grid operand: (row in chunk * C + channel) bytes; gathered: channel bytes
+    [[maybe_unused]] int r_prow[VR], c_prow[VC];
+    if constexpr (LEAN) {
+#pragma unroll
+        for (int i = 0; i < VR; ++i) {
+            const int v = tid + i * 256, prow = v / VPR_R, ch = r0 + (v - prow * VPR_R) * VE;
+            r_prow[i] = prow;
+            r_off[i] = (v < NVR && ch < p.Rc) ? (unsigned)(((p.r_large ? 0 : prow * p.Rc) + ch) * (int)sizeof(T)) : BUF_OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < VC; ++i) {
+            const int v = tid + i * 256, prow = v / VPR_C, ch = c0 + (v - prow * VPR_C) * VE;
+            c_prow[i] = prow;
+            c_off[i] = (v < NVC && ch < p.Cc) ? (unsigned)(((p.c_large ? 0 : prow * p.Cc) + ch) * (int)sizeof(T)) : BUF_OOB;
+        }
+    }
+    // byte offset of the gathered pixel that small-grid pixel `pix` meets at this launch's tap (bit 31: outside the image / past the end)
+    auto gathered = [&](int pix, int C) __attribute__((always_inline)) -> unsigned {
+        int n, h, w;
+        if (p.hw_shift >= 0) {   // uniform
+            n = pix >> p.hw_shift;
+            const int rem = pix & ((1 << p.hw_shift) - 1);
+            h = rem >> p.ws_shift;
+            w = rem & ((1 << p.ws_shift) - 1);
+        } else {
+            const int hw = p.Hs * p.Ws;
+            n = pix / hw;
+            const int rem = pix - n * hw;
+            h = rem / p.Ws;
+            w = rem - h * p.Ws;
+        }
+        const int y = h * p.stride - p.pad + kh, x = w * p.stride - p.pad + kw;
+        const bool ok = pix < p.K && (unsigned)y < (unsigned)p.Hl && (unsigned)x < (unsigned)p.Wl;
+        return ok ? (unsigned)((((n * p.Hl + y) * p.Wl + x) * C) * (int)sizeof(T)) : BUF_OOB;
+    };
+    auto load_lean = [&](int chunk, uint4 (&vr)[VR], uint4 (&vc)[VC]) __attribute__((always_inline)) {
+        const int pix0 = chunk * BK;
+        if (p.r_large) {   // uniform
+            const __amdgpu_buffer_rsrc_t rs = buf_rsrc(p.rp, (size_t)p.Nb * p.Hl * p.Wl * p.Rc * sizeof(T));
+#pragma unroll
+            for (int i = 0; i < VR; ++i) vr[i] = buf_ld16(rs, buf_off_add(gathered(pix0 + r_prow[i], p.Rc), r_off[i]), 0u);
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = buf_rsrc((const char*)p.rp + (size_t)pix0 * p.Rc * sizeof(T), (size_t)(p.K - pix0) * p.Rc * sizeof(T));
+#pragma unroll
+            for (int i = 0; i < VR; ++i) vr[i] = buf_ld16(rs, r_off[i], 0u);
+        }
+        if (p.c_large) {
+            const __amdgpu_buffer_rsrc_t rs = buf_rsrc(p.cp, (size_t)p.Nb * p.Hl * p.Wl * p.Cc * sizeof(T));
+#pragma unroll
+            for (int i = 0; i < VC; ++i) vc[i] = buf_ld16(rs, buf_off_add(gathered(pix0 + c_prow[i], p.Cc), c_off[i]), 0u);
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = buf_rsrc((const char*)p.cp + (size_t)pix0 * p.Cc * sizeof(T), (size_t)(p.K - pix0) * p.Cc * sizeof(T));
+#pragma unroll
+            for (int i = 0; i < VC; ++i) vc[i] = buf_ld16(rs, c_off[i], 0u);
+        }
+    };
+    auto load_any = [&](int chunk, uint4 (&vr)[VR], uint4 (&vc)[VC]) __attribute__((always_inline)) -> unsigned {
+        if constexpr (LEAN) { load_lean(chunk, vr, vc); return ~0u; }
+        else return load_chunk(chunk, vr, vc);
+    };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -789,7 +860,7 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
     unsigned vm[D];
 #pragma unroll
     for (int d = 0; d < D; ++d)
-        if (c_begin + d < c_end) vm[d] = load_chunk(c_begin + d, vr[d], vc[d]);
+        if (c_begin + d < c_end) vm[d] = load_any(c_begin + d, vr[d], vc[d]);
     int buf = 0;
     for (int c = c_begin; c < c_end; c += D) {
 #pragma unroll
@@ -801,15 +872,15 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
 #pragma unroll
                 for (int i = 0; i < VR; ++i) {
                     const int v = tid + i * 256;
-                    if (NVR % 256 == 0 || v < NVR) *(uint4*)(ldsR + (v / VPR_R) * RSR + (v % VPR_R) * 16) = keep_if((vm[d] >> i) & 1u, vr[d][i]);
+                    if (NVR % 256 == 0 || v < NVR) *(uint4*)(ldsR + (v / VPR_R) * RSR + (v % VPR_R) * 16) = LEAN ? vr[d][i] : keep_if((vm[d] >> i) & 1u, vr[d][i]);
                 }
 #pragma unroll
                 for (int i = 0; i < VC; ++i) {
                     const int v = tid + i * 256;
-                    if (NVC % 256 == 0 || v < NVC) *(uint4*)(ldsC + (v / VPR_C) * RSC + (v % VPR_C) * 16) = keep_if((vm[d] >> (16 + i)) & 1u, vc[d][i]);
+                    if (NVC % 256 == 0 || v < NVC) *(uint4*)(ldsC + (v / VPR_C) * RSC + (v % VPR_C) * 16) = LEAN ? vc[d][i] : keep_if((vm[d] >> (16 + i)) & 1u, vc[d][i]);
                 }
                 __syncthreads();
-                if (cc + D < c_end) vm[d] = load_chunk(cc + D, vr[d], vc[d]);
+                if (cc + D < c_end) vm[d] = load_any(cc + D, vr[d], vc[d]);
 #pragma unroll
                 for (int kk = 0; kk < BK / 16; ++kk) {
                     Frag<T> fa[TM], fb[TN];
@@ -924,9 +995,22 @@ int dispatch_pm(PmParams p, hipStream_t st) {
     p.splitk = std::max(1, std::min(sk, nchunk));
     dim3 grid(cdiv(p.Rc, BM) * p.ntn, p.splitk, p.ks * p.ks);
     ProfScope prof(10 + tile, 2.0 * p.Rc * (double)p.Cc * p.K * p.ks * p.ks, st);
-    if (tile == 0) hipLaunchKernelGGL((igemm_pm<T, 32, 128, 1, 4>), grid, dim3(256), 0, st, p);
-    else if (tile == 1) hipLaunchKernelGGL((igemm_pm<T, 128, 32, 4, 1>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((igemm_pm<T, 64, 64, 2, 2>), grid, dim3(256), 0, st, p);
+    constexpr int VE = 16 / (int)sizeof(T);
+    const size_t big = std::max((size_t)p.Nb * p.Hl * p.Wl, (size_t)p.K) * (size_t)std::max(p.Rc, p.Cc) * sizeof(T);
+    static const bool lean_off = getenv("FAVAE_PM_LEAN") && getenv("FAVAE_PM_LEAN")[0] == '0';
+    const bool lean = !lean_off && p.Rc % VE == 0 && p.Cc % VE == 0 && big < (size_t)0x7FFFFFF0;
+    const int hw = p.Hs * p.Ws;
+    p.hw_shift = p.ws_shift = -1;
+    if ((hw & (hw - 1)) == 0 && (p.Ws & (p.Ws - 1)) == 0) { p.hw_shift = __builtin_ctz((unsigned)hw); p.ws_shift = __builtin_ctz((unsigned)p.Ws); }
+#define PM_LAUNCH(BM_, BN_, WM_, WN_)                                                                        \
+    do {                                                                                                     \
+        if (lean) hipLaunchKernelGGL((igemm_pm<T, BM_, BN_, WM_, WN_, true>), grid, dim3(256), 0, st, p);    \
+        else hipLaunchKernelGGL((igemm_pm<T, BM_, BN_, WM_, WN_, false>), grid, dim3(256), 0, st, p);        \
+    } while (0)
+    if (tile == 0) PM_LAUNCH(32, 128, 1, 4);
+    else if (tile == 1) PM_LAUNCH(128, 32, 4, 1);
+    else PM_LAUNCH(64, 64, 2, 2);
+#undef PM_LAUNCH
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }
