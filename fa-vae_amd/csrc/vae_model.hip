@@ -825,7 +825,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
         const char* d = getenv("FAVAE_DG_EVENTS");
         v.dg_all = d && d[0] == '1';
         const char* f = getenv("FAVAE_FUSE_MASK");
-        v.fuse = f ? (unsigned)strtoul(f, nullptr, 0) : 0x17bu;   // 128 (fused Adam) measured slower in the step: its bandwidth bursts sit on the main chain   // 4 (thin-input path) measured slower: the prefetch costs occupancy
+        v.fuse = f ? (unsigned)strtoul(f, nullptr, 0) : 0x17fu;   // 128 (fused Adam) measured slower in the step: its bandwidth bursts sit on the main chain   // (4, the sums on the thin-input path, was slower while the weight gradients beside it were issue-bound; since their addressing became lean it is 0.9 % faster)
     }
     if (v.overlap) {
         // the side streams themselves are created at the first training step (ensure_streams), next to the caller's stream
