@@ -257,7 +257,7 @@ def _same_epochs(a, b, dtype):
     assert np.allclose(m1[:, :, 0], m0[:, :, 0], rtol=1e-2 if dtype == "f32" else 5e-2), np.abs(m1[:, :, 0] / m0[:, :, 0] - 1).max()
     assert np.median(np.abs(np.log(m1[:, :, 1] / m0[:, :, 1]))) < 0.2   # (single steps spike: the KL term is chaotic early on)
     for k in ("enc.0.1.running_mean", "final_layer.1.running_var"):
-        assert _rel(b[1][k].numpy(), a[1][k].numpy()) <= 5e-2, k
+        assert _rel(b[1][k].numpy(), a[1][k].numpy()) <= (5e-2 if dtype == "f32" else 1e-1), k   # (bf16: 14 free-running steps apart)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
