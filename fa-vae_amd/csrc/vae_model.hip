@@ -1203,8 +1203,12 @@ extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const
         if (wk) { wk->start(dev); v.wk = wk; }
         // dependency points as stream memory operations (sp_record / sp_wait); FAVAE_SYNC_VALUES=0: events, and the caller meets
         // the worker once per step
+        // Under rocprofv3 the default is events: the stream memory operations are one-wave kernels that poll, and counter collection
+        // runs one kernel at a time, so a wait queued ahead of its write would never see it (FAVAE_SYNC_VALUES=1 forces values).
         const char* sv = getenv("FAVAE_SYNC_VALUES");
-        if (wk && !(sv && sv[0] == '0')) {
+        const char* pre = getenv("LD_PRELOAD");
+        const bool profiled = getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || (pre && strstr(pre, "rocprofiler"));
+        if (wk && (sv ? sv[0] != '0' : !profiled)) {
             if (v.vals_ok < 0) {
                 v.vals_ok = hipStreamWriteValue32((hipStream_t)st, v.flags + SP_COUNT, 1u, 0) == hipSuccess ? 1 : 0;
                 if (!v.vals_ok) (void)hipGetLastError();
