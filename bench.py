@@ -57,7 +57,7 @@ def pmc_traffic(cls, dtype, key=None):
     name = CLASS_KERNEL.get(cls)
     rec = d.get(name) if name else None
     if rec is None and name:      # kernel signatures carry template / argument lists: match on the prefix before the arguments
-        stem = name.split("(")[0]
+        stem = name.split("(")[0].rstrip(">")      # (later template parameters have been appended since: match the leading ones)
         rec = next((v for k, v in d.items() if k.startswith(stem)), None)
     return None if rec is None else rec["hbm_bytes"]
 
