@@ -1192,6 +1192,15 @@ extern "C" int favae_conv_fold_taps(const void* src, void* dst, size_t dst_bytes
     return fold_taps_launch(src, dst, Nb, Hs, Ws, Hl, Wl, C, stride, shifted, dtype, (hipStream_t)stream);
 }
 
+extern "C" int favae_conv_folded_fwd(const void* fold, const void* w, const float* bias, float* out, long long P, int K, int Cout,
+                                     double* bins, int nbins, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(fold && w && out && P > 0 && P < (1ll << 31), "favae_conv_folded_fwd: bad argument");
+    FAVAE_CHECK_ARG(dtype == FAVAE_BF16 && Cout == 64 && K >= 1 && K <= 32, "favae_conv_folded_fwd: bf16, 64 outputs, K <= 32");
+    FAVAE_CHECK_ARG(!bins || nbins >= 1, "favae_conv_folded_fwd: nbins");
+    FAVAE_CHECK_ARG(((uintptr_t)fold % 16) == 0 && ((uintptr_t)out % 16) == 0, "favae_conv_folded_fwd: 16-byte alignment");
+    return folded_fwd_launch(fold, w, K, bias, out, P, bins, nbins, (hipStream_t)stream);
+}
+
 extern "C" int favae_conv_wgrad_prefolded(const void* rows, int Rc, int Rst, const void* cols, int Cc, int Cst, float* dw,
                                           long long K, int splitk, int dtype, void* stream) {
     FAVAE_CHECK_ARG(rows && cols && dw, "favae_conv_wgrad_prefolded: null pointer");

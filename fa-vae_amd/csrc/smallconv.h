@@ -18,3 +18,8 @@ int thin_in_launch(const void* in, const void* w, const float* bias, float* out,
 //   shifted = 1: dst[pix][c*9 + tap] = src[n][y + 1 - kh][x + 1 - kw][c]          (stride 1, same grid)
 int fold_taps_launch(const void* src, void* dst, int Nb, int Hq, int Wq, int Hn, int Wn, int Cs, int stride, int shifted,
                      int dtype, hipStream_t st);
+
+// out [P][64] fp32 = fold [P][32] (bf16, columns >= K zero) x w [64][K]^T (bf16) + bias; optional BatchNorm sums (sum, sum of
+// squares per channel, fp64) added to bins [nbin][2][64].  See folded_fwd_kernel.
+int folded_fwd_launch(const void* fold, const void* w, int K, const float* bias, float* out, long long P, double* bins, int nbin,
+                      hipStream_t st);

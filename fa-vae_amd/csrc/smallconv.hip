@@ -307,6 +307,94 @@ int thin_in_launch(const void* in, const void* w, const float* bias, float* out,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Forward convolution with an image-sized input channel count over the tap-FOLDED input (bf16): out [P][64] =
+// fold [P][32] x w [64][K]^T + bias, K = 9 * Cs <= 27 (columns K..31 of fold are zero).  encoder.0 of the training step: the
+// folded batch exists anyway (its weight gradient reads it) and is built before the step begins, so the layer becomes a
+// plain K = 32 GEMM on the matrix cores -- 4 MFMAs (32x32x16) per 32 pixels instead of 27 * 64 FMAs per pixel -- bound by
+// its 16.8 MB fp32 output.  A wave owns 32 pixels x 64 outputs per turn: the A fragments come straight from global memory
+// (a pixel row is 64 contiguous bytes), the weights sit in LDS (zero padded to [64][32]), the result leaves from the
+// accumulators (a store instruction writes two whole 128-byte pixel-row halves), and the per-channel sums of the BatchNorm
+// statistics (sum, sum of squares; fp64) go to bins[bin][2][64] like the epilogue sums of igemm_kc (red_mode 1).
+namespace {
+__device__ __forceinline__ f32x16 mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void folded_fwd_kernel(const bf16_t* __restrict__ fold, const bf16_t* __restrict__ w, int K,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int P,
+                                                         double* __restrict__ bins, int nbin, const FlagCarry carry) {
+    carry_store(carry);
+    __shared__ __attribute__((aligned(16))) bf16_t wl[64 * 40];   // [cout][32] + 8 columns of padding (80-byte rows: conflict-free 16-B reads)
+    __shared__ double redsm[4 * 2 * 64];
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+        const int co = i >> 5, k = i & 31;
+        wl[co * 40 + k] = k < K ? w[co * K + k] : (bf16_t)0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    union U { uint4 u; bf16x8 b; };
+    U b00, b01, b10, b11;   // [n tile][k step]
+    b00.u = *(const uint4*)(wl + r * 40 + h * 8);
+    b01.u = *(const uint4*)(wl + r * 40 + 16 + h * 8);
+    b10.u = *(const uint4*)(wl + (32 + r) * 40 + h * 8);
+    b11.u = *(const uint4*)(wl + (32 + r) * 40 + 16 + h * 8);
+    const float bias0 = bias ? bias[r] : 0.f, bias1 = bias ? bias[32 + r] : 0.f;
+    double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;   // sums of this lane's two output channels (r, 32 + r) over its pixel rows
+    const int ngroup = (P + 31) / 32, nw = gridDim.x * 4;
+    for (int g = blockIdx.x * 4 + wave; g < ngroup; g += nw) {
+        const int p0 = g * 32, pa = min(p0 + r, P - 1);
+        U a0, a1;
+        a0.u = *(const uint4*)(fold + (size_t)pa * 32 + h * 8);
+        a1.u = *(const uint4*)(fold + (size_t)pa * 32 + 16 + h * 8);
+        f32x16 c0, c1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { c0[i] = bias0; c1[i] = bias1; }
+        c0 = mfma_bf16_32x32x16(a0.b, b00.b, c0);
+        c0 = mfma_bf16_32x32x16(a1.b, b01.b, c0);
+        c1 = mfma_bf16_32x32x16(a0.b, b10.b, c1);
+        c1 = mfma_bf16_32x32x16(a1.b, b11.b, c1);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int p = p0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (p < P) {
+                out[(size_t)p * 64 + r] = c0[i];
+                out[(size_t)p * 64 + 32 + r] = c1[i];
+                if (bins) {
+                    s0 += c0[i]; q0 += (double)c0[i] * c0[i];
+                    s1 += c1[i]; q1 += (double)c1[i] * c1[i];
+                }
+            }
+        }
+    }
+    if (!bins) return;   // uniform
+    // lanes r and r + 32 hold the same channels; then the four waves through LDS; 128 fp64 atomics per block
+    s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+    if (h == 0) {
+        redsm[(wave * 2 + 0) * 64 + r] = s0; redsm[(wave * 2 + 0) * 64 + 32 + r] = s1;
+        redsm[(wave * 2 + 1) * 64 + r] = q0; redsm[(wave * 2 + 1) * 64 + 32 + r] = q1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int qq = threadIdx.x >> 6, col = threadIdx.x & 63;
+        const double t = (redsm[(0 * 2 + qq) * 64 + col] + redsm[(1 * 2 + qq) * 64 + col]) + (redsm[(2 * 2 + qq) * 64 + col] + redsm[(3 * 2 + qq) * 64 + col]);
+        unsafeAtomicAdd(bins + ((size_t)(blockIdx.x % (unsigned)nbin) * 2 + qq) * 64 + col, t);
+    }
+}
+}  // namespace
+
+int folded_fwd_launch(const void* fold, const void* w, int K, const float* bias, float* out, long long P, double* bins, int nbin,
+                      hipStream_t st) {
+    const FlagCarry carry = favae_take_flag_carry();
+    const int ngroup = (int)((P + 31) / 32);
+    const int grid = std::max(1, std::min(512, (ngroup + 3) / 4));
+    hipLaunchKernelGGL(folded_fwd_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)fold, (const bf16_t*)w, K, bias, out, (int)P, bins,
+                       std::max(1, nbin), carry);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Tap folding for the weight gradients with an image-sized channel count on one side (encoder.0, final_layer.3):
 // the 9 taps x <= 3 channels of the narrow operand become the 27 (padded to 32) columns of a plain [pixels][32] matrix,
 // after which the weight gradient is ONE pixel-major GEMM over the pixels (igemm.hip) that reads the wide operand

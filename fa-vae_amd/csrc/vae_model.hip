@@ -14,6 +14,7 @@
 #include "common.h"
 #include "favae_hip.h"
 #include "comm_internal.h"
+#include "smallconv.h"
 
 namespace {
 
@@ -186,6 +187,7 @@ struct Vae {
     float* xf_alt; char* xt_alt;
     char* wk_out;   // weights of final_layer.3 in the MFMA operand order for favae_conv_out_ll (rebuilt whenever the layer changes)
     char* fold0_buf[2]; int fold_sel; hipEvent_t ev_batch, ev_fold; bool inline_tail;   // see train_stages
+    bool fwd_folded;   // this step's encoder.0 forward reads the folded batch (the caller's stream has waited for the fold)
     char* fold0; size_t fold0_bytes; hipEvent_t ev_x; bool x_folded;   // encoder.0's folded input batch, gathered on the side stream while the forward pass runs
     char* fold; size_t fold_bytes;   // [pixels][32] tap-folded operand of the two image-side weight gradients (side stream only)   // second batch buffer: the next gather must not overwrite what wgrad(encoder.0) still reads
     // The dtype copies / transposes of the weights exist twice.  In single-device epochs the optimiser step of a layer follows
@@ -451,6 +453,12 @@ int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false
     const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_OUT_BF16 : 0);
     v.stats_fused[l] = false;
     v.bn_published[l] = false;
+    if (l == 0 && v.fwd_folded && pooled && fi < 0 && (v.fuse & 1u) && v.sbins[0] && !v.raw_bf[0]) {
+        // encoder.0 of the training step as a K = 32 GEMM over the tap-folded batch (smallconv.hip, folded_fwd_kernel)
+        RC(folded_fwd_launch(v.fold0, v.Wf(0), 9 * v.ch, bias, v.raw[0], v.rows(0, B), v.sbins[0], bins_for(v.rows(0, B)), (hipStream_t)st));
+        v.stats_fused[0] = true;
+        return FAVAE_OK;
+    }
     const bool publish = pooled && v.fi_on && (v.fuse & 1u) && v.sbins[l] && L.kind != LINEAR && L.bn && !v.raw_bf[l];
     if (fi >= 0 || publish) {
         // fused chain: the launch publishes this layer's BatchNorm quantities from its epilogue sums (where the shape runs
@@ -808,6 +816,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.wk = nullptr;
     v.eval_fused = batch_max >= 256 && !(getenv("FAVAE_EVAL_FUSED") && getenv("FAVAE_EVAL_FUSED")[0] == '0');
     v.eval_ab_ready = false;
+    v.fwd_folded = false;
     v.step_no = 0; v.join_seq = 0; v.vals = false; v.vals_ok = -1; v.mark_prev = v.mark_cur = 0;
     v.data_u8 = false;
     v.fi_on = false; v.fi_npend = 0; v.fi_flushes = 0; v.acts_wait = false;
@@ -917,6 +926,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
         // the tap gather of the NEXT step -- moves to the weight-gradient stream, which is idle at that point.
         v.inline_tail = epoch && !v.dp_epoch && can_fold && !(v.fuse & 0x2000u);
         v.x_folded = false;
+        v.fwd_folded = false;
         ++v.step_no;
         const unsigned seq = v.step_no;
         if (v.vals && v.wk) {   // bounded run-ahead: the worker has issued everything handed over before the previous step began
@@ -958,6 +968,9 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             // waits below may be issued before the worker issues the writes; nothing to meet for.
             if (v.wk && !v.vals) RC(v.wk->drain());
             RC(sp_wait(v, SP_BATCH, (hipStream_t)st, seq));
+            // bf16: encoder.0's forward pass reads the folded batch (FAVAE_FUSE_MASK bit 0x100000: the gathered batch, as before)
+            v.fwd_folded = v.dtype == FAVAE_BF16 && v.L[0].Cout == 64 && !(v.fuse & 0x100000u) && !v.fi_on;
+            if (v.fwd_folded) RC(sp_wait(v, SP_FOLD, (hipStream_t)st, seq));
         } else {
             if (!epoch) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));
             FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, (hipStream_t)st));
@@ -1063,7 +1076,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             RC(bn_bwd(v, 0, B, st));
             if (v.inline_tail) {
                 RC(sp_record(v, SP_FORK + 0, (hipStream_t)st, v.step_no, true));   // the next step's memset / gather may start here (rides with the weight-gradient GEMM below)
-                RC(sp_wait(v, SP_FOLD, (hipStream_t)st, v.step_no));
+                if (!v.fwd_folded) RC(sp_wait(v, SP_FOLD, (hipStream_t)st, v.step_no));
                 RC(wgrad_launch(v, 0, v.xt, B, st));
                 RC(sp_flush_carry((hipStream_t)st));
             } else {

@@ -122,6 +122,16 @@ def conv_fold_taps(src, Nb, Hs, Ws, Hl, Wl, stride, shifted=0):
     return dst
 
 
+def conv_folded_fwd(folded, w, bias, out, bins=None):
+    """favae_conv_folded_fwd: out [P, 64] f32 = folded [P, 32] x w [64, K]^T + bias (bf16 operands); optional BatchNorm sums
+    into bins [nbins, 2, 64] f64 (zeroed by the caller)."""
+    P, Cout, K = folded.shape[0], w.shape[0], w.numel() // w.shape[0]
+    assert folded.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and out.dtype == torch.float32 and out.shape == (P, Cout)
+    check(_lib.favae_conv_folded_fwd(ptr(folded), ptr(w), ptr(bias), ptr(out), ctypes.c_longlong(P), _i(K), _i(Cout), ptr(bins),
+                                     _i(0 if bins is None else bins.shape[0]), _i(dtype_code(folded)), stream_ptr()))
+    return out
+
+
 def conv_wgrad_prefolded(rows, cols, dw, Rst, Cst, splitk=0):
     """favae_conv_wgrad_prefolded: dw [Rst][Cst] += rows^T cols over the K rows of two plain matrices."""
     assert rows.dtype == cols.dtype and dw.dtype == torch.float32 and rows.shape[0] == cols.shape[0]

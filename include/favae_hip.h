@@ -120,6 +120,14 @@ int favae_conv_wgrad_folded(const void* rows, int Rc, const void* cols, int Cc, 
  *   wgrad_prefolded: dw [Rst][Cst] += sum_k rows[k][r] * cols[k][c] over K pixel rows of two plain matrices
  *     ([K][Rc], [K][Cc]; Rst <= Rc, Cst <= Cc: the padding columns are not stored).  splitk: 0 auto, > 0 that many
  *     slices of the reduction, -1 auto with dw known to be zero, < -1 that many slices with dw known to be zero. */
+/* Forward convolution over the tap-folded input (no counterpart launch in the reference: it is Conv2d(3 -> 64, k3 s2 p1) of
+ * celeba_deepvanilla_vae.py:31-33 computed as one K <= 32 GEMM): out [P][Cout] fp32 = fold [P][32] x w [Cout][K]^T + bias, with
+ * fold from favae_conv_fold_taps(shifted = 0) and w the layer's [Cout][9][C] weights (K = 9 * C).  bf16 operands, Cout = 64.
+ * bins != NULL: per-channel sum / sum of squares of the output (fp64) are added to bins [nbins][2][Cout], the input of
+ * favae_bn_train_fwd_bins (the caller zeroes them). */
+int favae_conv_folded_fwd(const void* fold, const void* w, const float* bias, float* out, long long P, int K, int Cout, double* bins,
+                          int nbins, int dtype, void* stream);
+
 int favae_conv_fold_taps(const void* src, void* dst, size_t dst_bytes, int Nb, int Hs, int Ws, int Hl, int Wl, int C,
                          int stride, int shifted, int dtype, void* stream);
 int favae_conv_wgrad_prefolded(const void* rows, int Rc, int Rst, const void* cols, int Cc, int Cst, float* dw, long long K,

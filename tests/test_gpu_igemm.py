@@ -422,6 +422,33 @@ def test_fold_then_gemm_in_two_calls(dt, tol, split):
     assert_close(dw.cpu(), ref, tol)
 
 
+@pytest.mark.parametrize("Nb,H,Cs", [(64, 64, 3), (5, 32, 3), (3, 18, 1), (7, 10, 2)])
+def test_forward_convolution_over_the_folded_batch(Nb, H, Cs):
+    """favae_conv_folded_fwd: encoder.0 (Conv2d Cs -> 64, k3 s2 p1, celeba_deepvanilla_vae.py:31-33) as one K <= 32 GEMM over the
+    matrix favae_conv_fold_taps builds, bf16 operands: against F.conv2d on the rounded operands, with the per-channel sums of
+    the BatchNorm statistics (pixel counts that are not multiples of 32 included)."""
+    lib = _lib()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(71 + H)
+    Cout = 64
+    x = q(torch.rand(Nb, Cs, H, H, generator=g), dt)
+    w = q(torch.randn(Cout, Cs, 3, 3, generator=g) * 0.3, dt)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    folded = lib.conv_fold_taps(nhwc(x).to(dt).cuda(), Nb, H // 2, H // 2, H, H, 2)
+    wd = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cs).contiguous().to(dt).cuda()
+    out = torch.full((ref.shape[0], Cout), float("nan"), device="cuda")
+    bins = torch.zeros(8, 2, Cout, dtype=torch.float64, device="cuda")
+    lib.conv_folded_fwd(folded, wd, b.cuda(), out, bins)
+    assert_close(out.cpu().double(), ref, 1e-5)                  # fp32 accumulation of exactly representable products
+    tot = bins.sum(0).cpu()
+    assert_close(tot[0], out.double().sum(0).cpu(), 1e-10)
+    assert_close(tot[1], (out.double() ** 2).sum(0).cpu(), 1e-10)
+    out2 = torch.empty_like(out)
+    lib.conv_folded_fwd(folded, wd, None, out2)                  # no bias, no sums
+    assert_close(out2.cpu().double(), ref - b.double(), 1e-5)
+
+
 @pytest.mark.parametrize("dt,tol", DT)
 @pytest.mark.parametrize("Nb,H,Co", [(2, 64, 3), (3, 18, 2), (64, 64, 3)])
 def test_folded_weight_gradient_final_conv(dt, tol, Nb, H, Co):
