@@ -212,12 +212,14 @@ struct Vae {
 
 // Dependency points.  A point is recorded on one stream once per training step and awaited on others.
 enum { SP_FORK = 0 /* + layer */, SP_WG = NL /* + layer */, SP_DG = 2 * NL /* + layer */, SP_BATCH = 3 * NL, SP_FOLD, SP_JOIN, SP_JOIN2, SP_X,
-       SP_FI0, SP_FI1, SP_ACTS, SP_COUNT };
+       SP_FI0, SP_FI1, SP_ACTS, SP_FENCE_M /* + bucket: the caller's stream */, SP_FENCE_S = SP_FENCE_M + 4 /* + bucket: weight-gradient stream */,
+       SP_COUNT = SP_FENCE_S + 4 };
 
 hipEvent_t sp_event(Vae& v, int sp) {
     if (sp < SP_WG) return v.ev_fork[sp - SP_FORK];
     if (sp < SP_DG) return v.ev_wg[sp - SP_WG];
     if (sp < SP_BATCH) return v.ev_dg[sp - SP_DG];
+    if (sp >= SP_FENCE_M) return v.ev_fence[sp >= SP_FENCE_S ? 1 : 0];   // (events mode: favae_vae_fence records these itself)
     switch (sp) {
     case SP_BATCH: return v.ev_batch;
     case SP_FOLD: return v.ev_fold;
@@ -924,7 +926,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
         // Single-device epochs: encoder.0's weight gradient and update, the last links of a step, stay on the caller's
         // stream (no event hop on that chain); what used to hide under them -- the zero-pool memset, the batch gather and
         // the tap gather of the NEXT step -- moves to the weight-gradient stream, which is idle at that point.
-        v.inline_tail = epoch && !v.dp_epoch && can_fold && !(v.fuse & 0x2000u);
+        v.inline_tail = epoch && can_fold && !(v.fuse & 0x2000u) && !(v.dp_epoch && (v.fuse & 0x200000u));   // (0x200000: not in data-parallel epochs)
         v.x_folded = false;
         v.fwd_folded = false;
         ++v.step_no;
@@ -979,7 +981,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             if (can_fold) {
                 // encoder.0's weight gradient ends the step: its tap gather needs the batch only, so it runs now, on the
                 // weight-gradient stream (idle during the forward pass; in order behind the previous step's last reader of fold0)
-                RC(sp_record(v, SP_X, (hipStream_t)st, seq));
+                RC(sp_record(v, SP_X, (hipStream_t)st, seq, true));   // (rides with encoder.0's forward GEMM)
                 char* xt = v.xt; char* fold0 = v.fold0;
                 RC(side_do(v, [&v, xt, fold0, B, seq]() -> int {
                     RC(sp_wait(v, SP_X, v.side, seq));
@@ -1195,6 +1197,61 @@ extern "C" int favae_vae_adam(favae_vae* h, float lr, float beta1, float beta2, 
     return favae_vae_refresh_weights(h, st);
 }
 
+namespace {
+// epochs of more than a few steps hand their side-stream calls to an enqueue worker (see struct Worker) and carry the
+// dependencies between the streams as words in device memory (sp_record / sp_wait)
+int epoch_worker_start(Vae& v, long long nsteps, hipStream_t st) {
+    const char* et = getenv("FAVAE_ENQUEUE_THREAD");   // "0": every call from the caller's thread (A/B and debugging)
+    const bool threaded = !(et && et[0] == '0');
+    v.vals = false;
+    if (!(v.overlap && threaded && nsteps >= 4)) return FAVAE_OK;
+    RC(ensure_streams(v, st));
+    int dev = 0;
+    FAVAE_HIP(hipGetDevice(&dev));
+    Worker* wk = new (std::nothrow) Worker();
+    if (!wk) return FAVAE_OK;
+    wk->start(dev);
+    v.wk = wk;
+    // Under rocprofv3 the default is events: the stream memory operations are one-wave kernels that poll, and counter collection
+    // runs one kernel at a time, so a wait queued ahead of its write would never see it (FAVAE_SYNC_VALUES=1 forces values).
+    const char* sv = getenv("FAVAE_SYNC_VALUES");
+    const char* pre = getenv("LD_PRELOAD");
+    const bool profiled = getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || (pre && strstr(pre, "rocprofiler"));
+    if (sv ? sv[0] != '0' : !profiled) {
+        if (v.vals_ok < 0) {
+            v.vals_ok = hipStreamWriteValue32(st, v.flags + SP_COUNT, 1u, 0) == hipSuccess ? 1 : 0;
+            if (!v.vals_ok) (void)hipGetLastError();
+        }
+        v.vals = v.vals_ok == 1;
+        v.mark_prev = v.mark_cur = wk->mark();
+    }
+    return FAVAE_OK;
+}
+// everything handed over has been issued; the worker ends with the epoch.  Returns the worker's status.
+int epoch_worker_stop(Vae& v, long long nsteps) {
+    Worker* wk = v.wk;
+    if (!wk) return FAVAE_OK;
+    const int wrc = wk->drain();
+    wk->finish();
+    if (getenv("FAVAE_VERBOSE"))
+        fprintf(stderr, "favae: enqueue worker: %lld jobs, %.1f us busy per step; caller waited %.1f us per step for it; %lld dependency words launched on their own so far\n", wk->jobs,
+                1e6 * wk->busy / (double)std::max(1LL, nsteps), 1e6 * wk->drain_wait / (double)std::max(1LL, nsteps), g_carry_flushes);
+    v.wk = nullptr;
+    delete wk;
+    return wrc;
+}
+// a failed step may have left waits whose writes were never issued: satisfy every point, let the queues run dry, start over
+void epoch_values_end(Vae& v, int rc) {
+    if (v.vals && rc != FAVAE_OK) {
+        (void)hipMemsetD32Async((hipDeviceptr_t)v.flags, 0x7FFFFFFF, SP_COUNT, v.side3);
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(v.flags, 0, SP_COUNT * sizeof(unsigned));
+        v.step_no = 0;
+    }
+    v.vals = false;
+}
+}  // namespace
+
 /* A whole epoch of steps on one device: perm [n] sample order, eps [n][z] in visiting order, metrics [nsteps][2].
  * Equivalent to the inner loop :227-255 with batch size `batch`; the last batch may be short. */
 extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const int* perm, long long n, int batch,
@@ -1204,32 +1261,7 @@ extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const
     Vae& v = h->v;
     long long s = 0;
     if (v.overlap) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));   // the steps keep it cleared
-    // epochs of more than a few steps hand their side-stream calls to an enqueue worker (see struct Worker)
-    const char* et = getenv("FAVAE_ENQUEUE_THREAD");   // "0": every call from the caller's thread (A/B and debugging)
-    const bool threaded = !(et && et[0] == '0');
-    Worker* wk = nullptr;
-    if (v.overlap && threaded && (n + batch - 1) / batch >= 4) {
-        RC(ensure_streams(v, (hipStream_t)st));
-        int dev = 0;
-        FAVAE_HIP(hipGetDevice(&dev));
-        wk = new (std::nothrow) Worker();
-        if (wk) { wk->start(dev); v.wk = wk; }
-        // dependency points as stream memory operations (sp_record / sp_wait); FAVAE_SYNC_VALUES=0: events, and the caller meets
-        // the worker once per step
-        // Under rocprofv3 the default is events: the stream memory operations are one-wave kernels that poll, and counter collection
-        // runs one kernel at a time, so a wait queued ahead of its write would never see it (FAVAE_SYNC_VALUES=1 forces values).
-        const char* sv = getenv("FAVAE_SYNC_VALUES");
-        const char* pre = getenv("LD_PRELOAD");
-        const bool profiled = getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || (pre && strstr(pre, "rocprofiler"));
-        if (wk && (sv ? sv[0] != '0' : !profiled)) {
-            if (v.vals_ok < 0) {
-                v.vals_ok = hipStreamWriteValue32((hipStream_t)st, v.flags + SP_COUNT, 1u, 0) == hipSuccess ? 1 : 0;
-                if (!v.vals_ok) (void)hipGetLastError();
-            }
-            v.vals = v.vals_ok == 1;
-            v.mark_prev = v.mark_cur = wk->mark();
-        }
-    }
+    RC(epoch_worker_start(v, (n + batch - 1) / batch, (hipStream_t)st));
     int rc = FAVAE_OK;
     for (long long o = 0; o < n && rc == FAVAE_OK; o += batch, ++s) {
         const int B = (int)std::min<long long>(batch, n - o);
@@ -1243,28 +1275,15 @@ extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const
             if (rc == FAVAE_OK) rc = favae_vae_adam(h, lr, 0.9f, 0.999f, 1e-8f, step0 + s + 1, st);
         }
     }
-    if (wk) {   // everything handed over has been issued; the worker ends with the epoch
-        const int wrc = wk->drain();
-        wk->finish();
-        if (getenv("FAVAE_VERBOSE"))
-            fprintf(stderr, "favae: enqueue worker: %lld jobs, %.1f us busy per step; caller waited %.1f us per step for it; %lld dependency words launched on their own so far\n", wk->jobs,
-                    1e6 * wk->busy / (double)s, 1e6 * wk->drain_wait / (double)s, g_carry_flushes);
-        v.wk = nullptr;
-        delete wk;
+    {
+        const int wrc = epoch_worker_stop(v, s);
         if (rc == FAVAE_OK) rc = wrc;
     }
     if (v.overlap && v.join_pending) {   // last step (or failure): the caller's stream waits for the side streams
         (void)wait_join(v, (hipStream_t)st);
         v.join_pending = false;
     }
-    if (v.vals && rc != FAVAE_OK) {
-        // a failed step may have left waits whose writes were never issued: satisfy every point, let the queues run dry, start over
-        (void)hipMemsetD32Async((hipDeviceptr_t)v.flags, 0x7FFFFFFF, SP_COUNT, v.side3);
-        (void)hipDeviceSynchronize();
-        (void)hipMemset(v.flags, 0, SP_COUNT * sizeof(unsigned));
-        v.step_no = 0;
-    }
-    v.vals = false;
+    epoch_values_end(v, rc);
     v.pending = -1;
     v.merged = false;
     if (v.sh_sel != 0) {   // outside an epoch half 0 is the current one (a second executor may share the shadow buffer)
@@ -1293,6 +1312,14 @@ extern "C" int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float
     const struct { long long lo, hi; int l0, l1, stage_hi; } bk[NBK] = {
         {w6, v.nparam, 6, NL - 1, 7}, {w4, w6, 4, 5, 9}, {w3, w4, 3, 3, 10}, {0, w3, 0, 2, N_STAGES}};
     FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));   // the bucket-wise Adam keeps it cleared
+    // the weight gradients go through the enqueue worker here too (FAVAE_DP_THREAD=0: everything from the caller's thread)
+    if (!v.ev_fence_ok) {
+        FAVAE_HIP(hipEventCreateWithFlags(&v.ev_fence[0], hipEventDisableTiming));
+        FAVAE_HIP(hipEventCreateWithFlags(&v.ev_fence[1], hipEventDisableTiming));
+        v.ev_fence_ok = true;
+    }
+    const char* dpt = getenv("FAVAE_DP_THREAD");
+    if (!(dpt && dpt[0] == '0')) RC(epoch_worker_start(v, (n + batch - 1) / batch, (hipStream_t)st));
     int rc = FAVAE_OK;
     long long s = 0;
     v.dp_epoch = true;
@@ -1303,7 +1330,20 @@ extern "C" int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float
             rc = train_stages(v, data_nhwc, perm + o, B, eps + o * v.z, prior, tau, beta, var_x, metrics + 2 * s, lo, bk[b].stage_hi, st);
             lo = bk[b].stage_hi;
             if (rc) break;
-            rc = favae_vae_fence(h, st, (void*)cs);       // cs waits for the main and the weight-gradient stream, neither waits
+            // cs waits for the main and the weight-gradient stream, neither waits
+            if (v.wk) {
+                // the weight gradients of these stages are issued by the worker: it passes the point of the weight-gradient stream
+                // behind them; the caller's stream passes its own (a one-wave launch: no GEMM follows at once to take the word along)
+                const unsigned seq = v.step_no;
+                rc = sp_record(v, SP_FENCE_M + b, (hipStream_t)st, seq, true);
+                if (rc == FAVAE_OK) rc = sp_flush_carry((hipStream_t)st);
+                if (rc == FAVAE_OK) rc = side_do(v, [&v, b, seq]() -> int { return sp_record(v, SP_FENCE_S + b, v.side, seq); });
+                if (rc == FAVAE_OK && !v.vals) rc = v.wk->drain();   // events: recorded before they are awaited
+                if (rc == FAVAE_OK) rc = sp_wait(v, SP_FENCE_M + b, cs, seq);
+                if (rc == FAVAE_OK) rc = sp_wait(v, SP_FENCE_S + b, cs, seq);
+            } else {
+                rc = favae_vae_fence(h, st, (void*)cs);
+            }
             if (rc) break;
             rc = favae_allreduce_f32(c, v.G + bk[b].lo, bk[b].hi - bk[b].lo, 1, (void*)cs);
             if (rc) break;
@@ -1329,12 +1369,17 @@ extern "C" int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float
         v.ev_join_ext = done;
         v.join_pending = true;
     }
+    {
+        const int wrc = epoch_worker_stop(v, s);
+        if (rc == FAVAE_OK) rc = wrc;
+    }
     v.dp_epoch = false;
     if (v.join_pending) {
         (void)wait_join(v, (hipStream_t)st);
         v.join_pending = false;
     }
     v.ev_join_ext = nullptr;
+    epoch_values_end(v, rc);
     return rc;
 }
 
