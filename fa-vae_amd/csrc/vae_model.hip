@@ -176,6 +176,7 @@ struct Vae {
     Ada ada;
     int pending;   // layer whose optimiser step waits for the next fork event (-1: none); touched by side-stream jobs only
     Worker* wk;    // non-null while an epoch hands its side-stream calls to the enqueue worker
+    unsigned beside;    // ensure_streams: pairs of streams measured to run on hardware queues of their own (bits: see there)
     int stream_score;   // ensure_streams: 21 = all three side streams run beside the main stream and each other
     bool join_pending; bool dg_all;
     bool dp_epoch;   // steps of favae_vae_train_epoch_dp: gradients cleared by the bucket-wise Adam, joins through the communication stream
@@ -403,6 +404,7 @@ int ensure_streams(Vae& v, hipStream_t main) {
     bool beside[NS][NS];
     const char* e = getenv("FAVAE_STREAM_PROBE");
     const bool probe = !(e && e[0] == '0');
+    bool measured = false;
     for (int i = 0; i < NS; ++i)
         for (int j = 0; j < NS; ++j) beside[i][j] = i != j;
     if (probe) {
@@ -419,6 +421,7 @@ int ensure_streams(Vae& v, hipStream_t main) {
             for (int i = 0; i < NS; ++i)
                 for (int j = 0; j < NS; ++j)
                     if (i != j) beside[i][j] = host[i * NS + j] < host[i * NS + i];
+        measured = ok;
     }
     auto ok2 = [&](int a, int b) { return beside[a][b] && beside[b][a]; };
     int pick[3] = {-1, -1, -1}, best = -1;
@@ -434,6 +437,10 @@ int ensure_streams(Vae& v, hipStream_t main) {
     for (int i = 1; i < NS; ++i)
         if (i != pick[0] && i != pick[1] && i != pick[2]) (void)hipStreamDestroy(s[i]);
     v.stream_score = best;
+    // which pairs run side by side: bit 0 main-side, 1 main-side2, 2 main-side3, 3 side-side2, 4 side-side3, 5 side2-side3
+    v.beside = (ok2(0, pick[0]) ? 1u : 0u) | (ok2(0, pick[1]) ? 2u : 0u) | (ok2(0, pick[2]) ? 4u : 0u) | (ok2(pick[0], pick[1]) ? 8u : 0u) |
+               (ok2(pick[0], pick[2]) ? 16u : 0u) | (ok2(pick[1], pick[2]) ? 32u : 0u);
+    if (!measured) v.beside = 0;   // (not probed: nothing is known about the queues)
     if (getenv("FAVAE_VERBOSE")) fprintf(stderr, "favae: side streams picked %d %d %d of 4 (score %d of 21)\n", pick[0], pick[1], pick[2], best);
     return FAVAE_OK;
 }
@@ -1200,7 +1207,7 @@ extern "C" int favae_vae_adam(favae_vae* h, float lr, float beta1, float beta2, 
 namespace {
 // epochs of more than a few steps hand their side-stream calls to an enqueue worker (see struct Worker) and carry the
 // dependencies between the streams as words in device memory (sp_record / sp_wait)
-int epoch_worker_start(Vae& v, long long nsteps, hipStream_t st) {
+int epoch_worker_start(Vae& v, long long nsteps, hipStream_t st, unsigned need_beside) {
     const char* et = getenv("FAVAE_ENQUEUE_THREAD");   // "0": every call from the caller's thread (A/B and debugging)
     const bool threaded = !(et && et[0] == '0');
     v.vals = false;
@@ -1222,7 +1229,12 @@ int epoch_worker_start(Vae& v, long long nsteps, hipStream_t st) {
             v.vals_ok = hipStreamWriteValue32(st, v.flags + SP_COUNT, 1u, 0) == hipSuccess ? 1 : 0;
             if (!v.vals_ok) (void)hipGetLastError();
         }
-        v.vals = v.vals_ok == 1;
+        // A wait may be queued before the write it waits for, so the streams of this epoch must sit on hardware queues of their own:
+        // a polling wait ahead of its writer in ONE queue would never end.  The probe of ensure_streams has measured exactly that,
+        // pair by pair; if a pair this epoch uses shares a queue, the events stay.
+        v.vals = v.vals_ok == 1 && (v.beside & need_beside) == need_beside;
+        if (getenv("FAVAE_VERBOSE") && v.vals_ok == 1 && !v.vals)
+            fprintf(stderr, "favae: stream words not used: streams of this epoch share a hardware queue (pairs 0x%x of 0x%x)\n", v.beside & need_beside, need_beside);
         v.mark_prev = v.mark_cur = wk->mark();
     }
     return FAVAE_OK;
@@ -1261,7 +1273,7 @@ extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const
     Vae& v = h->v;
     long long s = 0;
     if (v.overlap) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));   // the steps keep it cleared
-    RC(epoch_worker_start(v, (n + batch - 1) / batch, (hipStream_t)st));
+    RC(epoch_worker_start(v, (n + batch - 1) / batch, (hipStream_t)st, 1u | 2u | 8u));   // main, weight-gradient and optimiser stream
     int rc = FAVAE_OK;
     for (long long o = 0; o < n && rc == FAVAE_OK; o += batch, ++s) {
         const int B = (int)std::min<long long>(batch, n - o);
@@ -1319,7 +1331,7 @@ extern "C" int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float
         v.ev_fence_ok = true;
     }
     const char* dpt = getenv("FAVAE_DP_THREAD");
-    if (!(dpt && dpt[0] == '0')) RC(epoch_worker_start(v, (n + batch - 1) / batch, (hipStream_t)st));
+    if (!(dpt && dpt[0] == '0')) RC(epoch_worker_start(v, (n + batch - 1) / batch, (hipStream_t)st, 1u | 4u | 16u));   // main, weight-gradient and communication stream
     int rc = FAVAE_OK;
     long long s = 0;
     v.dp_epoch = true;
