@@ -109,6 +109,10 @@ struct KcParams {
     int Nb, Hi, Wi, Cin, Ho, Wo, Cout;
     int ks, stride, pad, ldw, splitk, M, ntn, HoC, WoC;
     int out_bf16;   // store the result as bf16 (unsplit reductions only)
+    // > 0: blocks are dealt to the 8 XCDs round-robin in launch order, so block b of the launch computes tile
+    // (b % 8) * xcd_chunk + b / 8: every XCD works on one contiguous run of tiles, and the tiles that share activation rows
+    // (the n-tiles of one m-tile, the halo rows of neighbouring m-tiles) meet in one L2 instead of eight
+    int xcd_chunk;
     // optional per-channel sums over the output tile, added to red_bins[bin][2][Cout] (fp64 atomics; staged 64x64
     // epilogue of unsplit reductions only).  mode 1: sum(y), sum(y^2) of the stored output (BatchNorm statistics);
     // mode 2: y is the gradient w.r.t. a BN+LeakyReLU output: sum(dd), sum(dd * xhat) with dd = y * lrelu'(act),
@@ -215,7 +219,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
     const int lane = tid & 63, wave = tid >> 6;
     char* const lds = lds_all + grp * (NBUF * STAGE);
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = (blockIdx.x / p.ntn) * BM, n0 = (blockIdx.x % p.ntn) * BN;
+    const unsigned bx = p.xcd_chunk ? (blockIdx.x & 7u) * (unsigned)p.xcd_chunk + (blockIdx.x >> 3) : blockIdx.x;
+    const int m0 = (bx / p.ntn) * BM, n0 = (bx % p.ntn) * BN;
     // parity classes in the order 4, 2, 2, 1 taps: the blocks with the longest reduction are dispatched first
     // (unsplit reductions only: with split-K, measured on MI355X, the light classes first is the faster order)
     const int zc = TR ? (p.splitk == 1 ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z) : 0;
@@ -573,7 +578,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
                         if constexpr (KG == 2)
                             t += (redsm[(4 * 2 + qq) * 64 + col] + redsm[(5 * 2 + qq) * 64 + col]) +
                                  (redsm[(6 * 2 + qq) * 64 + col] + redsm[(7 * 2 + qq) * 64 + col]);
-                        const int bin = (int)((blockIdx.x / p.ntn + blockIdx.z * 5u) % (unsigned)p.red_nbin);
+                        const int bin = (int)((bx / p.ntn + blockIdx.z * 5u) % (unsigned)p.red_nbin);
                         unsafeAtomicAdd(p.red_bins + ((size_t)bin * 2 + qq) * p.Cout + n0 + col, t);
                     }
                 }
@@ -919,8 +924,14 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
 }
 
 template <class T, bool TR, bool SLOW, int BM, int BN, int WM, int WN, int KG = 1, bool FI = false>
-int launch_kc(const KcParams& p, int classes, hipStream_t st) {
+int launch_kc(KcParams p, int classes, hipStream_t st) {
     dim3 grid(cdiv(p.M, BM) * p.ntn, p.splitk, classes);
+    // FAVAE_KC_XCD: 0 launch order = tile order, 1 XCD-contiguous tiles wherever the grid allows, 2 (default) only where
+    // activation rows are what the tiles share (few n-tiles); with many n-tiles launch order already gives every XCD its own
+    // slice of the weights (1 is slower there: enc.4 forward 15.1 -> 16.3 us).  Measured alone (tools/bench_gemm.py): dec.3 input
+    // gradient 11.6 -> 9.7 us, the other layers within noise; no measurable change of the step (these launches are not bound by L2 misses).
+    static const int xcd_mode = getenv("FAVAE_KC_XCD") ? atoi(getenv("FAVAE_KC_XCD")) : 2;
+    p.xcd_chunk = (xcd_mode && grid.x % 8 == 0 && grid.x >= 16 && (xcd_mode == 1 || p.ntn <= 4)) ? (int)(grid.x / 8) : 0;
     const int cls = SLOW ? (TR ? 9 : 8) : (TR ? 4 : 0) + (BM == 64 ? 2 : 3);
     // algorithmic work, dense-tap convention: gather form ks*ks taps per output pixel, stride-2 scatter form 9/4
     const double taps = (TR && p.stride == 2) ? 2.25 : (double)(p.ks * p.ks);

@@ -142,6 +142,29 @@ def sum_scalar(x, device=None):
     return t.item()
 
 
+def masked_col_stats(A, keep, device=None):
+    """Per-column count, mean and population standard deviation of the entries of A where `keep`, over the rows of ALL
+    ranks: what np.nanmean / np.nanstd give the reference on the whole data set (cA/favae.py:251, 278-286).  Host arrays
+    in and out; two passes (the mean first), fp64.  Columns without a kept entry come back as NaN."""
+    import numpy as np
+
+    def total(x):
+        if not active():
+            return x
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
+        if td.get_backend() == "nccl":
+            t = t.to(device)
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    cs = total(np.stack([keep.sum(0).astype(np.float64), np.where(keep, A, 0.0).sum(0)]))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mean = cs[1] / cs[0]
+        dev2 = total(np.where(keep, (A - mean) ** 2, 0.0).sum(0))
+        std = np.sqrt(dev2 / cs[0])
+    return cs[0], mean, std
+
+
 def min_scalar(x, device=None):
     """Minimum of a Python int/float over ranks."""
     if not active():

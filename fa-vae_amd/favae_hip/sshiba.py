@@ -214,13 +214,14 @@ class SSHIBA(object):
                 self.SS_mask[m] = mask
                 if dist.sum_scalar(float(mask.sum()), self.dev) > 0:                                 # semi-supervised view
                     self.SS[m] = True
-                    if dist.active():
-                        raise NotImplementedError("semi-supervised 'reg' views: the initial imputation statistics (:251) are "
-                                                  "per data set, not per shard; single process only")
+                    # the imputation draws use the column statistics of the whole data set (:251): over all shards when sharded
+                    gobs, gmean, gstd = dist.masked_col_stats(mean, ~mask, self.dev) if dist.active() else (None, None, None)
                     for dd in range(d):
                         cnt = int(np.sum(mask[:, dd]))
-                        if cnt == mask.shape[0]:
+                        if (gobs[dd] == 0) if dist.active() else (cnt == mask.shape[0]):
                             mean[mask[:, dd], dd] = np.random.normal(0.0, 1.0, cnt)
+                        elif dist.active():
+                            mean[mask[:, dd], dd] = np.random.normal(gmean[dd], gstd[dd], cnt)
                         else:
                             mean[mask[:, dd], dd] = np.random.normal(np.nanmean(mean[:, dd], axis=0), np.nanstd(mean[:, dd], axis=0), cnt)
                     cov = np.copy(info["cov"])
@@ -229,7 +230,7 @@ class SSHIBA(object):
                     self._ss_mask_dev = getattr(self, "_ss_mask_dev", {})
                     self._ss_mask_dev[m] = torch.from_numpy(mask).to(self.dev)
                     self._ss_count = getattr(self, "_ss_count", {})
-                    self._ss_count[m] = float(mask.sum())
+                    self._ss_count[m] = float(mask.sum())                                            # (summed over the shards where used)
                 else:
                     info["mean"] = mean
                     info["cov"] = np.zeros(mean.shape)
@@ -246,21 +247,25 @@ class SSHIBA(object):
                 self.SS_mask[m] = mask
                 self.t[m] = LazyDict(data=tdata, LH=0, Elogp=0, sumlogdet=0, epochs=20)
                 if dist.sum_scalar(float(mask.sum()), self.dev) > 0:                                 # semi-supervised labels
-                    if dist.active() or self.SS_sep:
-                        raise NotImplementedError("semi-supervised multilabel views: single process, SS_sep=0 only")
+                    if self.SS_sep:
+                        raise NotImplementedError("semi-supervised multilabel views: SS_sep=0 only")
                     self.SS[m] = True
                     tmean, tcov = np.copy(info["mean"]), np.copy(info["cov"])                        # t = deepcopy(info) (:270)
                     mean, cov = np.copy(info["mean"]), np.copy(info["cov"])
                     tt = np.abs(tdata[~mask] - 0.05)
                     mean[~mask] = np.log(tt / (1 - tt))                                              # :276
                     cov[~mask] = 0
+                    if dist.active():     # column statistics of the whole data set (:278-286): over all shards
+                        _, omean, ostd = dist.masked_col_stats(mean, ~mask, self.dev)
+                        _, tmu, tsd = dist.masked_col_stats(tmean, np.ones_like(mask), self.dev)
                     for dd in range(d):                                                              # :278-280
                         obs, cnt = mean[~mask[:, dd], dd], int(np.sum(mask[:, dd]))
-                        mean[mask[:, dd], dd] = np.random.normal(np.nanmean(obs, axis=0), np.nanstd(obs, axis=0), cnt)
-                        cov[mask[:, dd], dd] = np.abs(np.random.normal(np.nanmean(obs, axis=0), np.nanstd(obs, axis=0), cnt))
+                        mu, sd = (omean[dd], ostd[dd]) if dist.active() else (np.nanmean(obs, axis=0), np.nanstd(obs, axis=0))
+                        mean[mask[:, dd], dd] = np.random.normal(mu, sd, cnt)
+                        cov[mask[:, dd], dd] = np.abs(np.random.normal(mu, sd, cnt))
                     for dd in range(d):                                                              # :285-286
-                        tmean[mask[:, dd], dd] = np.random.normal(np.nanmean(tmean[:, dd], axis=0), np.nanstd(tmean[:, dd], axis=0),
-                                                                  int(np.sum(mask[:, dd])))
+                        mu, sd = (tmu[dd], tsd[dd]) if dist.active() else (np.nanmean(tmean[:, dd], axis=0), np.nanstd(tmean[:, dd], axis=0))
+                        tmean[mask[:, dd], dd] = np.random.normal(mu, sd, int(np.sum(mask[:, dd])))
                     tmean[~mask] = tdata[~mask]
                     tcov[~mask] = 0
                     info["mean"], info["cov"] = mean, cov

@@ -192,6 +192,21 @@ def _gloo_worker(rank, ws, port, q):
     out = dist.sum_many_([a, b2, c])
     ok = ok and all(o is t and torch.equal(t, r) for o, t, r in zip(out, (a, b2, c), ref))
     ok = ok and dist.min_scalar(rank) == 0 and dist.max_scalar(rank) == ws - 1
+    # column statistics of the observed entries over all shards == np.nanmean / np.nanstd of the whole array (the imputation
+    # statistics of semi-supervised views, cA/favae.py:251); a column without an observed entry anywhere comes back as NaN
+    A = rs.randn(N, 5) * 3 + 1
+    A[rs.rand(N, 5) < 0.3] = np.nan
+    A[:, 4] = np.nan
+    A[lo:hi, 3] = np.nan if rank == 0 else A[lo:hi, 3]      # observed on one rank only
+    cnt, mu, sd = dist.masked_col_stats(A[lo:hi], ~np.isnan(A[lo:hi]))
+    full = A.copy()
+    full[:dist.shard_bounds(N, ws, 0)[1], 3] = np.nan
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")     # (the all-NaN column)
+        fm, fs = np.nanmean(full, axis=0), np.nanstd(full, axis=0)
+    ok = ok and np.array_equal(cnt, (~np.isnan(full)).sum(0)) and np.allclose(mu[:4], fm[:4], rtol=1e-12) and np.allclose(sd[:4], fs[:4], rtol=1e-12)
+    ok = ok and np.isnan(mu[4]) and np.isnan(sd[4]) and cnt[4] == 0
     q.put((rank, bool(ok)))
     td.destroy_process_group()
 

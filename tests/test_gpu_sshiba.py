@@ -414,3 +414,85 @@ def test_two_rank_sharded_fit_equals_single_rank_fit(golden):
         _close(Ls, ref.L, 1e-10)
         _close(W1, ref.q_dist.W[1]["mean"], 1e-9, 1e-12)
         _close(Z, ref.q_dist.Z["mean"][lo:hi], 1e-9, 1e-11)
+
+
+def _sharded_ss_worker(rank, ws, port, q):
+    """One rank of the N-sharded fit with unobserved entries in both views.  The random draws are kept in step with the
+    un-sharded run: N-sized draws are made at full size and sliced; an imputation draw (one per column, as many values as the
+    column has unobserved entries) is made at its whole-data-set size and the rank takes the values of its own rows."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK="0")
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=ws)
+    for p in (os.path.dirname(PKG), PKG, os.path.join(os.path.dirname(PKG), "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from conftest import ss2_inputs
+    from favae_hip import dist
+    fav = load_variant("condition_a_VAE")
+    X0, lab = ss2_inputs()
+    N = X0.shape[0]
+    lo, hi = dist.shard_bounds(N)
+    plan = []                                           # (values in the whole draw, first, last + 1 of this rank's), in call order
+
+    def per_column(mask, times):
+        for dd in range(mask.shape[1]):
+            rows = np.flatnonzero(mask[:, dd])
+            plan.extend([(rows.size, int(np.sum(rows < lo)), int(np.sum(rows < hi)))] * times)
+
+    per_column(np.isnan(X0), 1)                         # 'reg' view: one draw per column (cA/favae.py:251)
+    mlab = np.isnan(lab)
+    for dd in range(lab.shape[1]):                      # labels: mean and covariance draw per column (:278-280) ...
+        rows = np.flatnonzero(mlab[:, dd])
+        plan.extend([(rows.size, int(np.sum(rows < lo)), int(np.sum(rows < hi)))] * 2)
+    per_column(mlab, 1)                                 # ... then the label means (:285-286)
+    real_normal, real_rand, real_randint = np.random.normal, np.random.rand, np.random.randint
+
+    def normal(loc=0.0, scale=1.0, size=None):
+        if isinstance(loc, np.floating):                # an imputation draw: column statistics as location / scale
+            n_all, a, b = plan.pop(0)
+            assert b - a == size
+            return real_normal(loc, scale, n_all)[a:b]
+        if isinstance(size, (int, np.integer)) and size % (hi - lo) == 0 and np.ndim(loc) == 0:
+            d = size // (hi - lo)
+            return real_normal(loc, scale, N * d).reshape(N, d)[lo:hi].reshape(-1)
+        return real_normal(loc, scale, size)
+
+    np.random.normal = normal
+    np.random.rand = lambda n, d: real_rand(N, d)[lo:hi] if n == hi - lo else real_rand(n, d)
+    np.random.randint = lambda k, size=None: real_randint(k, size=[N, size[1]])[lo:hi] if size[0] == hi - lo else real_randint(k, size=size)
+    np.random.seed(0)
+    model = fav.SSHIBA(10, 1)
+    model.fit(model.struct_data(X0[lo:hi], "reg"), model.struct_data(lab[lo:hi], "mult"), max_iter=4, pruning_crit=1e-3,
+              verbose=0, store=False, pretrained=0)
+    assert not plan and model.SS == [True, True]
+    q.put((rank, list(model.L), model.q_dist.W[0]["mean"], np.asarray(model.X[0]["mean"]), np.asarray(model.t[1]["mean"]), lo, hi))
+    td.destroy_process_group()
+
+
+def test_two_rank_sharded_semi_supervised_fit_equals_single_rank_fit(golden):
+    """Unobserved entries in a 'reg' and a multilabel view, rows sharded over two ranks: the imputation statistics are taken
+    over all shards (cA/favae.py:251, 278-286 compute them on the whole data set), everything after that exchanges reduced
+    statistics only.  Equals the single-process fit, which the reference golden fa_A_ss2.npz pins."""
+    import torch.multiprocessing as mp
+    from conftest import ss2_inputs
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31700 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sharded_ss_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+    fav = load_variant("condition_a_VAE")
+    X0, lab = ss2_inputs()
+    np.random.seed(0)
+    ref = fav.SSHIBA(10, 1)
+    ref.fit(ref.struct_data(X0, "reg"), ref.struct_data(lab, "mult"), max_iter=4, pruning_crit=1e-3, verbose=0, store=False,
+            pretrained=0)
+    _close(ref.L, golden("fa_A_ss2.npz")["L"], 1e-8)
+    for rank, Ls, W0, X0m, t1, lo, hi in res:
+        _close(Ls, ref.L, 1e-9)
+        _close(W0, ref.q_dist.W[0]["mean"], 1e-8, 1e-10)
+        _close(X0m, np.asarray(ref.X[0]["mean"])[lo:hi], 1e-8, 1e-9)
+        _close(t1, np.asarray(ref.t[1]["mean"])[lo:hi], 1e-8, 1e-9)
