@@ -248,7 +248,8 @@ class SSHIBA(object):
                 self.t[m] = LazyDict(data=tdata, LH=0, Elogp=0, sumlogdet=0, epochs=20)
                 if dist.sum_scalar(float(mask.sum()), self.dev) > 0:                                 # semi-supervised labels
                     if self.SS_sep:
-                        raise NotImplementedError("semi-supervised multilabel views: SS_sep=0 only")
+                        raise NotImplementedError("semi-supervised multilabel views: SS_sep=0 only (the reference's SS_sep branch, "
+                                                  "cA/favae.py:294-331, appends to the dict self.t and cannot run)")
                     self.SS[m] = True
                     tmean, tcov = np.copy(info["mean"]), np.copy(info["cov"])                        # t = deepcopy(info) (:270)
                     mean, cov = np.copy(info["mean"]), np.copy(info["cov"])
