@@ -7,6 +7,7 @@
 // Border taps use a clamped coordinate and a 0/1 mask, so all loads of a pixel are issued together.
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <cstdlib>
 #include "common.h"
 #include <type_traits>
@@ -269,9 +270,29 @@ bool thin_in_applicable(int Cs, int Co, int ks, int stride, int scatter) {
 }
 
 namespace {
+// Re-laid-out weights of the launches in flight: one slot per (device, stream).  Launches of one stream run in order, so the
+// re-layout of a launch cannot overtake the convolution of the previous one that reads the same slot; launches of different
+// streams never share a slot.  A process that uses more than WK_SLOTS - 1 streams for this kernel shares the last slot among
+// the rest, and those launches wait for the device first (correct, slow, and not a case the executors produce).
 constexpr int WK_SLOTS = 16, WK_FLOATS = 36 * 64;
-__device__ float g_thin_wk[WK_SLOTS * WK_FLOATS];   // re-laid-out weights of the launches in flight (ring of slots)
-std::atomic<unsigned> g_wk_next{0};
+__device__ float g_thin_wk[WK_SLOTS * WK_FLOATS];
+struct WkOwner { int dev; hipStream_t st; };
+std::mutex g_wk_mu;
+WkOwner g_wk_owner[WK_SLOTS];
+int g_wk_owners = 0;
+
+int wk_slot(int dev, hipStream_t st, bool* shared) {
+    std::lock_guard<std::mutex> lk(g_wk_mu);
+    *shared = false;
+    for (int i = 0; i < g_wk_owners; ++i)
+        if (g_wk_owner[i].dev == dev && g_wk_owner[i].st == st) return i;
+    if (g_wk_owners < WK_SLOTS - 1) {
+        g_wk_owner[g_wk_owners] = WkOwner{dev, st};
+        return g_wk_owners++;
+    }
+    *shared = true;
+    return WK_SLOTS - 1;
+}
 }  // namespace
 
 int thin_in_launch(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cs, int Ho, int Wo,
@@ -281,7 +302,9 @@ int thin_in_launch(const void* in, const void* w, const float* bias, float* out,
     FAVAE_HIP(hipGetDevice(&dev));
     FAVAE_CHECK_ARG(dev >= 0 && dev < 64, "thin_in_launch: device index %d", dev);
     if (!per_device[dev]) FAVAE_HIP(hipGetSymbolAddress((void**)&per_device[dev], HIP_SYMBOL(g_thin_wk)));
-    float* wk_scratch = per_device[dev] + (size_t)(g_wk_next.fetch_add(1u) % WK_SLOTS) * WK_FLOATS;
+    bool shared = false;
+    float* wk_scratch = per_device[dev] + (size_t)wk_slot(dev, st, &shared) * WK_FLOATS;
+    if (shared) FAVAE_HIP(hipDeviceSynchronize());
     const int total = Nb * Ho * Wo, K = 9 * Cs;
     const int grid = cdiv(total, 256);
     const FlagCarry carry = favae_take_flag_carry();

@@ -20,7 +20,10 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int TICKET_SLOTS = 4096;
 __device__ unsigned g_tickets[TICKET_SLOTS];   // zero at load; every launch leaves the slots it used at zero
-std::atomic<unsigned> g_ticket_next{0};        // host: rotating slot base, so launches on different streams do not share
+// host: rotating slot base, so launches on different streams do not share.  Slots are touched only while a launch EXECUTES (a queued
+// launch holds nothing) and a launch takes at most 256 of the 3 840 positions, so two launches could only meet on a slot if 15 or
+// more ticketed launches were executing at the same time; a process has 4 hardware queues.
+std::atomic<unsigned> g_ticket_next{0};
 
 int ticket_base(int nslots, unsigned** out) {
     static unsigned* per_device[64] = {nullptr};

@@ -393,12 +393,14 @@ int ensure_streams(Vae& v, hipStream_t main) {
     if (v.side) return FAVAE_OK;
     constexpr int NC = 4, NS = NC + 1;
     hipStream_t s[NS] = {main, nullptr, nullptr, nullptr, nullptr};
-    // The side streams get the lowest priority the device offers: priorities have hardware-queue pools of their own, so the
-    // four candidates do not share a queue with the caller's stream or each other (probe score 21 of 21 where it was 20), and
-    // the main chain is favoured at dispatch (-0.6 % step time; FAVAE_SIDE_PRIO=0: default priority).
+    // FAVAE_SIDE_PRIO=1 (experiment, off by default): side streams at the lowest priority the device offers.  Priorities have
+    // hardware-queue pools of their own, so with ONE executor in the process the four candidates share no queue with the caller's
+    // stream or each other (probe score 21 of 21 where it was 20) and the step is 0.6 % faster; with a second executor (two image
+    // views) the first epoch of the second one never finished on the GPU (event mode, one step per epoch; tests/test_gpu_sshiba.py
+    // variant B).  Not understood, so not used.
     int prio_lo = 0, prio_hi = 0;
     const char* pe = getenv("FAVAE_SIDE_PRIO");
-    const bool low = !(pe && pe[0] == '0') && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_lo != prio_hi;
+    const bool low = pe && pe[0] == '1' && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_lo != prio_hi;
     for (int i = 1; i < NS; ++i)
         if ((low ? hipStreamCreateWithPriority(&s[i], hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking)) != hipSuccess) {
             for (int j = 1; j < i; ++j) (void)hipStreamDestroy(s[j]);
