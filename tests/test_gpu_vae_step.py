@@ -249,6 +249,46 @@ def test_epoch_with_the_enqueue_worker_equals_the_single_threaded_epoch(dtype, t
     _same_epochs(out["0"], out["1e"], dtype)
 
 
+def test_two_executors_in_one_process_take_turns():
+    """Two image views = two executors, each with side streams and an enqueue worker of its own, whose epochs alternate
+    (SSHIBA.update trains view after view).  The second executor's side streams share hardware queues with the first one's: its
+    probe decides per stream pair whether stream words may be used, and either way its epochs must complete and agree with the
+    unthreaded run."""
+    import os
+    z, Bn, N = 20, 64, 4 * 64 + 9
+    torch.manual_seed(0)
+    P, Bf = vt.init_state(z, 3)
+    sd = {k: v.detach().clone() for k, v in P.items()}
+    sd.update({k: v.clone() for k, v in Bf.items()})
+    imgs = [img_inputs(N)[0], img_inputs(N, seed=4)[0]]
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(5)).to(torch.int32).cuda()
+    eps = torch.randn(N, z, generator=torch.Generator().manual_seed(3)).cuda()
+    prior = torch.from_numpy(np.random.RandomState(7).randn(N, z) * 0.5).cuda()
+    out = {}
+    old = os.environ.get("FAVAE_ENQUEUE_THREAD")
+    try:
+        for mode in ("0", "1"):
+            os.environ["FAVAE_ENQUEUE_THREAD"] = mode
+            engs = [_engine(z, "bf16"), _engine(z, "bf16")]
+            datas = []
+            for e, im in zip(engs, imgs):
+                e.load_state_dict(sd)
+                datas.append(e.upload_images(im))
+            ms = torch.zeros(2, 2, 5, 2, dtype=torch.float64, device="cuda")
+            for ep in range(2):
+                for k in range(2):
+                    engs[k].train_epoch(datas[k], perm, eps, prior, 1.7, 1.0, 0.01, 1e-3, Bn, ms[k, ep])
+            torch.cuda.synchronize()
+            out[mode] = [(ms[k].cpu().numpy(), engs[k].state_dict()) for k in range(2)]
+    finally:
+        if old is None:
+            os.environ.pop("FAVAE_ENQUEUE_THREAD", None)
+        else:
+            os.environ["FAVAE_ENQUEUE_THREAD"] = old
+    for k in range(2):
+        _same_epochs(out["0"][k], out["1"][k], "bf16")
+
+
 def _same_epochs(a, b, dtype):
     m0, m1 = a[0], b[0]
     assert np.isfinite(m1).all() and (m1[:, :, 0] > 0).all()
