@@ -7,6 +7,11 @@
 #include "favae_hip.h"
 
 static thread_local char g_err[512] = "";
+SlabRider& favae_slab_rider() {
+    static thread_local SlabRider r = {nullptr, nullptr, 0, 0};
+    return r;
+}
+
 FlagCarry& favae_flag_carry() {
     static thread_local FlagCarry c = {{nullptr, nullptr, nullptr, nullptr}, 0u, 0};
     return c;

@@ -76,6 +76,12 @@ __device__ __forceinline__ void wait_vm_writes() { asm volatile("s_waitcnt vmcnt
 
 // Words to be stored by the first block of the next GEMM launch of this host thread (vae_model.hip, sp_record): dependency
 // points of the stream the launch goes to, passed when everything queued before that launch is complete.
+// A small reduction that rides with this thread's next weight-gradient launch (igemm_pm): out[c] = sum over the slabs of
+// partial[slab][c], the second half of favae_bn_lrelu_bwd_bins with FAVAE_DBIAS_DEFER.  The first cdiv(C, 8) blocks of the launch
+// take 8 channels each before their own work: no launch of its own on the stream beside the main chain.
+struct SlabRider { const double* partial; float* out; int nslab, C; };
+SlabRider& favae_slab_rider();                       // this thread's pending rider (api.hip)
+inline SlabRider favae_take_slab_rider() { SlabRider& r = favae_slab_rider(); const SlabRider k = r; r.partial = nullptr; return k; }
 struct FlagCarry { unsigned* p[4]; unsigned val; int n; };
 FlagCarry& favae_flag_carry();                       // this thread's pending words (api.hip)
 inline FlagCarry favae_take_flag_carry() { FlagCarry& c = favae_flag_carry(); const FlagCarry k = c; c.n = 0; return k; }

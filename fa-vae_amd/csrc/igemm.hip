@@ -707,6 +707,7 @@ struct PmParams {
     int overwrite;  // unsplit reductions store instead of adding (the caller guarantees dw == 0: splitk < 0)
     int Rst, Cst;   // rows / columns of dw that exist (<= Rc, Cc: operands padded to whole vectors, see favae_conv_wgrad_folded)
     FlagCarry carry;   // dependency words of the launch stream, stored by the first block (common.h)
+    SlabRider rider;   // a small reduction for the first blocks (common.h); partial == NULL: none
     int hw_shift, ws_shift;   // log2 of Hs*Ws and Ws when both are powers of two (every layer of the model), else -1
 };
 
@@ -732,6 +733,30 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
 
     carry_store(p.carry);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (p.rider.partial) {   // uniform: 8 channels x 32 slab parts per block, the parts added in LDS in a fixed order
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lin * 8 < (unsigned)p.rider.C) {   // block-uniform
+            double* rs = (double*)lds;          // [32][8]
+            const int ch = tid & 7, part = tid >> 3, c = (int)lin * 8 + ch;
+            double t = 0.0;
+            if (c < p.rider.C) {
+                double x[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int k = part + 32 * q; x[q] = k < p.rider.nslab ? p.rider.partial[(size_t)k * p.rider.C + c] : 0.0; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t += x[q];
+            }
+            rs[part * 8 + ch] = t;
+            __syncthreads();
+            if (tid < 8 && c < p.rider.C) {
+                double u = 0.0;
+#pragma unroll 8
+                for (int k = 0; k < 32; ++k) u += rs[k * 8 + tid];
+                p.rider.out[c] = (float)u;
+            }
+            __syncthreads();   // (the stages below reuse the LDS)
+        }
+    }
     const int wm = wave / WN, wn = wave % WN;
     const int r0 = (blockIdx.x / p.ntn) * BM, c0 = (blockIdx.x % p.ntn) * BN;
     const int tap = blockIdx.z, kh = tap / p.ks, kw = tap % p.ks;
@@ -991,6 +1016,9 @@ int dispatch_kc(KcParams p, int classes, int target_blocks, int* fused, hipStrea
 template <class T>
 int dispatch_pm(PmParams p, hipStream_t st) {
     p.carry = favae_take_flag_carry();
+    p.rider = favae_take_slab_rider();
+    FAVAE_CHECK_ARG(!(p.rider.partial && (p.rider.nslab < 1 || p.rider.nslab > 256 || p.rider.C < 1 || p.rider.C > 2048)),
+                    "weight gradient: slab rider of %d slabs x %d channels", p.rider.nslab, p.rider.C);
     int tile = p.Rc <= 32 ? 0 : p.Cc <= 32 ? 1 : 2;   // 32x128, 128x32, 64x64
     if (g_force_pm_tile >= 0 && g_force_pm_tile <= 2) tile = g_force_pm_tile;
     const int BM = tile == 0 ? 32 : tile == 1 ? 128 : 64, BN = tile == 0 ? 128 : tile == 1 ? 32 : 64;
@@ -1005,6 +1033,11 @@ int dispatch_pm(PmParams p, hipStream_t st) {
                                      : std::min(std::max(1, nchunk / 8), std::max(1, (pm_target + blocks / 2) / blocks));
     p.splitk = std::max(1, std::min(sk, nchunk));
     dim3 grid(cdiv(p.Rc, BM) * p.ntn, p.splitk, p.ks * p.ks);
+    if (p.rider.partial && (long long)cdiv(p.rider.C, 8) > (long long)grid.x * grid.y * grid.z) {   // too few blocks to carry it: a launch of its own
+        const int rc = favae_bn_dbias_finish(p.rider.partial, p.rider.nslab, p.rider.C, p.rider.out, st);
+        if (rc != FAVAE_OK) return rc;
+        p.rider.partial = nullptr;
+    }
     ProfScope prof(10 + tile, 2.0 * p.Rc * (double)p.Cc * p.K * p.ks * p.ks, st);
     constexpr int VE = 16 / (int)sizeof(T);
     const size_t big = std::max((size_t)p.Nb * p.Hl * p.Wl, (size_t)p.K) * (size_t)std::max(p.Rc, p.Cc) * sizeof(T);
@@ -1260,6 +1293,12 @@ extern "C" int favae_debug_kc_blocks(unsigned long long* out16384) {
     return FAVAE_OK;
 }
 #endif
+
+extern "C" int favae_bn_dbias_ride(const double* partial, int nslab, int C, float* dbias) {
+    FAVAE_CHECK_ARG(partial && dbias && nslab >= 1 && nslab <= 256 && C >= 1 && C <= 2048, "favae_bn_dbias_ride: bad argument");
+    favae_slab_rider() = SlabRider{partial, dbias, nslab, C};
+    return FAVAE_OK;
+}
 
 extern "C" int favae_debug_force_tile(int kc_tile, int pm_tile) {
     g_force_kc_tile = kc_tile;

@@ -94,6 +94,20 @@ __global__ __launch_bounds__(RED_THREADS) void colreduce(int R, int C, int TPR, 
             if (lane < TPR) sm[((v * VW + j) * RED_WAVES + wave) * TPR + lane] = t;
         }
     __syncthreads();
+    if constexpr (F::DEFER) {   // the slab's sums, plain stores; whoever needs the totals adds the slabs (slab_sums_finish)
+        if (tid < TPR && live) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int j = 0; j < VW; ++j) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int w = 0; w < RED_WAVES; ++w) t += sm[((v * VW + j) * RED_WAVES + w) * TPR + tid];
+                    if (c0 + j < C) partial[((size_t)blockIdx.x * NV + v) * C + c0 + j] = t;
+                }
+        }
+        return;
+    }
     if (nslab == 1) {
         if (tid < TPR && live) {
 #pragma unroll
@@ -163,6 +177,27 @@ __global__ __launch_bounds__(RED_THREADS) void colreduce(int R, int C, int TPR, 
     if (tid == 0) __hip_atomic_store(&tickets[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// out[c] = sum over the slabs, in slab order (fp64, reproducible), of partial[slab][c]: 64 channels x 4 slab parts per block
+__global__ __launch_bounds__(256) void slab_sums_finish(const double* __restrict__ partial, int nslab, int C, float* __restrict__ out) {
+    __shared__ double sm[4][64];
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    // contiguous quarter of the slabs per part, 8 independent loads in flight
+    const int per = (nslab + 3) / 4, k0 = part * per, k1 = min(nslab, k0 + per);
+    double t = 0.0;
+    if (c < C) {
+        for (int k = k0; k < k1; k += 8) {
+            double x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = k + q < k1 ? partial[(size_t)(k + q) * C + c] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += x[q];
+        }
+    }
+    sm[part][cl] = t;
+    __syncthreads();
+    if (part == 0 && c < C) out[c] = (float)(((sm[0][cl] + sm[1][cl]) + sm[2][cl]) + sm[3][cl]);
+}
+
 template <int NV, class F>
 int run_colreduce(long long R, int C, double* partial, size_t partial_cap, F f, hipStream_t st) {
     const RedGeom g = red_geom(R, C);
@@ -208,6 +243,7 @@ template <class RT>
 struct StatsF {
     const RT* x; int C; double R; float eps, mom; float *mean, *invstd, *run_mean, *run_var;
     static constexpr bool BLOCK_INIT = false;
+    static constexpr bool DEFER = false;
     struct Ctx {};
     __device__ void init(Ctx&, int, const double*) const {}
     template <int VW> __device__ void row(const Ctx&, int r, int c0, double (*acc)[VW]) const {
@@ -390,6 +426,7 @@ struct BnBwdRedF {
     const DT* dact; const T* act; const RT* raw; const float* mean; const float* invstd; int C;
     float *dgamma, *dbeta, *s1s2;
     static constexpr bool BLOCK_INIT = false;
+    static constexpr bool DEFER = false;
     struct Ctx { float mu[4], is[4]; };
     __device__ void init(Ctx& k, int c0, const double*) const {
         for (int j = 0; j < 4 && c0 + j < C; ++j) { k.mu[j] = mean[c0 + j]; k.is[j] = invstd[c0 + j]; }
@@ -415,8 +452,12 @@ struct BnBwdRedF {
     }
 };
 
-template <class T, class RT, class DT>
+// DEFERRED (FAVAE_DBIAS_DEFER): the per-slab column sums stay in the caller's buffer and favae_bn_dbias_finish adds them up
+// later, on any stream: the launch ends with its last row instead of waiting for its stores, taking a ticket and leaving
+// one block to read every partial (2 % of the training step over its seven launches)
+template <class T, class RT, class DT, bool DEFERRED = false>
 struct BnBwdApplyF {
+    static constexpr bool DEFER = DEFERRED;
     const DT* dact; const T* act; const RT* raw; const float* mean; const float* invstd; const float* gamma;
     const float* s1s2; T* draw; int C; float invR; float* dbias;
     // bins != NULL: the two sums come from the epilogue of the GEMM that produced dact (igemm.hip, red_mode 2) instead of
@@ -629,6 +670,7 @@ template <class T>
 struct ColsumF {
     const T* x; int C; float* out;
     static constexpr bool BLOCK_INIT = false;
+    static constexpr bool DEFER = false;
     struct Ctx {};
     __device__ void init(Ctx&, int, const double*) const {}
     template <int VW> __device__ void row(const Ctx&, int r, int c0, double (*acc)[VW]) const {
@@ -646,6 +688,7 @@ template <class T>
 struct ColsumCastF {
     const float* x; T* y; int C; float* out;
     static constexpr bool BLOCK_INIT = false;
+    static constexpr bool DEFER = false;
     struct Ctx {};
     __device__ void init(Ctx&, int, const double*) const {}
     template <int VW> __device__ void row(const Ctx&, int r, int c0, double (*acc)[VW]) const {
@@ -1675,9 +1718,13 @@ static int bn_bwd_impl(const void* dact_, const void* act_, const void* raw_, co
 template <class T, class RT, class DT>
 static int bn_bwd_bins_impl(const void* dact, const void* act, const void* raw, const float* mean, const float* invstd,
                             const float* gamma, const double* bins, int nbins, void* draw, float* dgamma, float* dbeta,
-                            float* dbias, long long R, int C, double* scratch, size_t cap, hipStream_t st) {
+                            float* dbias, long long R, int C, double* scratch, size_t cap, hipStream_t st, bool defer) {
     // algorithmic bytes: dact + raw + act read, draw written
     ProfScope prof(7, (double)R * C * (sizeof(DT) + sizeof(RT) + 2 * sizeof(T)), st);
+    if (defer)
+        return run_colreduce<1>(R, C, scratch, cap,
+                                BnBwdApplyF<T, RT, DT, true>{(const DT*)dact, (const T*)act, (const RT*)raw, mean, invstd, gamma, nullptr, (T*)draw,
+                                                             C, (float)(1.0 / (double)R), nullptr, bins, nbins, dgamma, dbeta}, st);
     return run_colreduce<1>(R, C, scratch, cap,
                             BnBwdApplyF<T, RT, DT>{(const DT*)dact, (const T*)act, (const RT*)raw, mean, invstd, gamma, nullptr, (T*)draw, C,
                                                    (float)(1.0 / (double)R), dbias, bins, nbins, dgamma, dbeta}, st);
@@ -1693,7 +1740,8 @@ extern "C" int favae_bn_lrelu_bwd_bins(const void* dact, const void* act, const 
     FAVAE_CHECK_ARG(DT_BASE(dtype) == FAVAE_F32 || DT_BASE(dtype) == FAVAE_BF16, "favae_bn_lrelu_bwd_bins: dtype");
     FAVAE_CHECK_ARG(!((RAW_IS_BF16(dtype) || DACT_IS_BF16(dtype)) && (DT_BASE(dtype) != FAVAE_BF16 || C % 4 != 0)),
                     "favae_bn_lrelu_bwd_bins: FAVAE_RAW_BF16 / FAVAE_DACT_BF16 need FAVAE_BF16 and C %% 4 == 0");
-#define BB_ARGS dact, act, raw, mean, invstd, gamma, bins, nbins, draw, dgamma, dbeta, dbias, R, C, scratch, scratch_doubles, ST
+    const bool defer = (dtype & FAVAE_DBIAS_DEFER) != 0;   // scratch keeps the per-slab column sums, dbias is not written
+#define BB_ARGS dact, act, raw, mean, invstd, gamma, bins, nbins, draw, dgamma, dbeta, dbias, R, C, scratch, scratch_doubles, ST, defer
     if (DT_BASE(dtype) == FAVAE_F32) return bn_bwd_bins_impl<float, float, float>(BB_ARGS);
     if (RAW_IS_BF16(dtype) && DACT_IS_BF16(dtype)) return bn_bwd_bins_impl<bf16_t, bf16_t, bf16_t>(BB_ARGS);
     if (RAW_IS_BF16(dtype)) return bn_bwd_bins_impl<bf16_t, bf16_t, float>(BB_ARGS);
@@ -1718,6 +1766,17 @@ extern "C" int favae_bn_lrelu_bwd(const void* dact, const void* act, const void*
     if (DACT_IS_BF16(dtype)) return bn_bwd_impl<bf16_t, float, bf16_t>(BWD_ARGS);
     return bn_bwd_impl<bf16_t, float, float>(BWD_ARGS);
 #undef BWD_ARGS
+}
+
+extern "C" int favae_bn_lrelu_bwd_slabs(long long R, int C) {
+    return (R > 0 && C > 0) ? red_geom(R, C).nslab : 0;
+}
+
+extern "C" int favae_bn_dbias_finish(const double* partial, int nslab, int C, float* dbias, void* stream) {
+    FAVAE_CHECK_ARG(partial && dbias && nslab >= 1 && C >= 1, "favae_bn_dbias_finish: bad argument");
+    hipLaunchKernelGGL(slab_sums_finish, dim3(cdiv(C, 64)), dim3(256), 0, ST, partial, nslab, C, dbias);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
 }
 
 extern "C" int favae_colsum(const void* x, long long R, int C, float* out, double* scratch, size_t scratch_doubles, int dtype,

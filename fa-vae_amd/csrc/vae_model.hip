@@ -31,6 +31,7 @@ struct Layer {
 constexpr int NL = 13;
 constexpr int L_FC = 5, L_DI = 6, L_OUT = 12;
 constexpr int MAX_BINS = 32;
+constexpr int DBP_SLABS = 256;   // slabs of a column reduction at most (red_geom, vae_kernels.hip)
 
 inline long long al8(long long x) { return (x + 7) & ~7LL; }
 
@@ -200,6 +201,9 @@ struct Vae {
     // LeakyReLU slopes) is materialised on the weight-gradient stream, which is idle during the forward pass
     bool data_u8;   // the resident data set handed to the step / encode / reconstruction calls is uint8 (favae_vae_set_data_u8)
     bool eval_fused, eval_ab_ready;   // eval-mode BatchNorm in the GEMM epilogues (large-batch eval executor); ab[] holds the running-stat form
+    // column sums of draw[l] per slab of rows, left by the BN-backward apply of this step (FAVAE_DBIAS_DEFER); dbias_slabs[l] > 0:
+    // the stream that takes layer l's weight gradient adds them up first (dbias_finish)
+    double* dbp[NL]; int dbias_slabs[NL];
     float* ab[NL]; bool act_deferred[NL]; bool bn_published[NL]; bool fi_on; int fi_pend[NL], fi_npend, fi_flushes; hipEvent_t ev_fi[2], ev_acts; bool acts_wait;
     // Dependency points between the streams (see sp_record / sp_wait): in threaded single-device epochs they are 32-bit words in
     // device memory written / awaited by stream memory operations with the step number as value, otherwise the events above.
@@ -340,6 +344,7 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
         v.mean[l] = (float*)c.take((size_t)v.L[l].Cout * 4);
         v.invstd[l] = (float*)c.take((size_t)v.L[l].Cout * 4);
         v.ab[l] = (float*)c.take((size_t)v.L[l].Cout * 8);
+        v.dbp[l] = v.L[l].bn ? (double*)c.take((size_t)DBP_SLABS * v.L[l].Cout * 8) : nullptr;
     }
     const size_t img = (size_t)B * 64 * 64 * v.ch;
     v.xf = (float*)c.take(img * 4);
@@ -618,10 +623,17 @@ int bn_bwd(Vae& v, int l, int B, void* st) {
     const Layer& L = v.L[l];
     if (v.grad_fused[l]) {   // the GEMM that produced dact[l] summed the two reductions in its epilogue
         v.grad_fused[l] = false;
+        // the bias gradient (column sums of draw: rounding noise in front of a BatchNorm) is finished beside the main chain, by the
+        // stream that takes the layer's weight gradient (FAVAE_FUSE_MASK bit 0x400000: inside this launch, as before)
+        const int slabs = favae_bn_lrelu_bwd_slabs(v.rows(l, B), L.Cout);
+        // (not for encoder.0 when its weight gradient ends the step on the caller's stream: the finish would sit on the main chain)
+        const bool defer = !(v.fuse & 0x400000u) && v.dbp[l] && slabs >= 1 && slabs <= DBP_SLABS && !(l == 0 && v.inline_tail);
+        v.dbias_slabs[l] = defer ? slabs : 0;
         return favae_bn_lrelu_bwd_bins(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.gbins[l],
                                        bins_for(v.rows(l, B)), v.draw[l], v.G + L.g_off, v.G + L.be_off, v.G + L.b_off,
-                                       v.rows(l, B), L.Cout, v.scratch, v.scratch_doubles,
-                                       v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0) | (v.dact_bf[l] ? FAVAE_DACT_BF16 : 0), st);
+                                       v.rows(l, B), L.Cout, defer ? v.dbp[l] : v.scratch, defer ? (size_t)DBP_SLABS * L.Cout : v.scratch_doubles,
+                                       v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0) | (v.dact_bf[l] ? FAVAE_DACT_BF16 : 0) |
+                                           (defer ? FAVAE_DBIAS_DEFER : 0), st);
     }
     return favae_bn_lrelu_bwd(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.draw[l], v.G + L.g_off,
                               v.G + L.be_off, v.G + L.b_off, v.rows(l, B), L.Cout, v.scratch, v.scratch_doubles, v.s1s2,
@@ -639,14 +651,28 @@ template <class F> int side_do(Vae& v, F&& f) {
 
 // weight gradient of layer l given draw[l] (just produced on the main stream) and the layer input; with overlap on it
 // is queued on the side stream behind an event, so the main stream continues with the input gradient at once
+// the deferred half of the BN-backward apply of layer l (see bn_bwd): on the stream that is about to take its weight gradient
+int dbias_finish(Vae& v, int l, int slabs, void* st) {
+    if (slabs <= 0) return FAVAE_OK;
+    // layers whose weight gradient is an igemm_pm launch on this thread, next: the sums ride with that launch (a launch of its own
+    // in front of every weight gradient costs the step 1.2 %, as much as the shorter BN-backward launches bring)
+    if (l != 0 && l != L_OUT && v.L[l].kind != LINEAR) {
+        return favae_bn_dbias_ride(v.dbp[l], slabs, v.L[l].Cout, v.G + v.L[l].b_off);
+    }
+    return favae_bn_dbias_finish(v.dbp[l], slabs, v.L[l].Cout, v.G + v.L[l].b_off, st);
+}
+int take_dbias_slabs(Vae& v, int l) { const int s = v.dbias_slabs[l]; v.dbias_slabs[l] = 0; return s; }
+
 int wgrad(Vae& v, int l, const void* in, int B, void* st) {
-    if (!v.overlap) return wgrad_launch(v, l, in, B, st);
+    const int slabs = take_dbias_slabs(v, l);   // (by value into the job: the caller's thread may be a step ahead of the worker)
+    if (!v.overlap) { RC(dbias_finish(v, l, slabs, st)); return wgrad_launch(v, l, in, B, st); }
     const unsigned seq = v.step_no;
     RC(sp_record(v, SP_FORK + l, (hipStream_t)st, seq, true));   // rides with the input-gradient GEMM queued next
     const Ada ada = v.ada;
     const bool merged = v.merged; const int half = v.upd_half;
-    return side_do(v, [&v, l, in, B, ada, merged, half, seq]() -> int {
+    return side_do(v, [&v, l, in, B, ada, merged, half, seq, slabs]() -> int {
         RC(sp_wait(v, SP_FORK + l, v.side, seq));
+        RC(dbias_finish(v, l, slabs, (void*)v.side));
         RC(wgrad_launch(v, l, in, B, (void*)v.side));
         if (!ada.on) return FAVAE_OK;
         if (merged && (v.fuse & 0x20000u)) return adam_layer(v, l, (void*)v.side, ada, half);   // same stream: no further event
@@ -1094,6 +1120,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             if (v.inline_tail) {
                 RC(sp_record(v, SP_FORK + 0, (hipStream_t)st, v.step_no, true));   // the next step's memset / gather may start here (rides with the weight-gradient GEMM below)
                 if (!v.fwd_folded) RC(sp_wait(v, SP_FOLD, (hipStream_t)st, v.step_no));
+                RC(dbias_finish(v, 0, take_dbias_slabs(v, 0), st));   // (nothing to do: see bn_bwd)
                 RC(wgrad_launch(v, 0, v.xt, B, st));
                 RC(sp_flush_carry((hipStream_t)st));
             } else {

@@ -32,6 +32,12 @@ extern "C" {
 #define FAVAE_RAW_BF16 0x10
 #define FAVAE_DACT_BF16 0x20
 #define FAVAE_OUT_BF16 0x40
+/* favae_bn_lrelu_bwd_bins: dbias is not written; `scratch` keeps the column sums of draw per slab of rows,
+ * [favae_bn_lrelu_bwd_slabs(R, C)][C] doubles, and favae_bn_dbias_finish adds them up later, on any stream that is ordered
+ * behind the launch.  The launch then ends with its last row: no wait for its stores, no ticket, no block that reads every
+ * partial.  (The bias of a convolution in front of a BatchNorm has a gradient of rounding noise, and nothing on the main
+ * chain of a training step waits for it.) */
+#define FAVAE_DBIAS_DEFER 0x80
 
 const char* favae_last_error(void);
 int favae_version(void);
@@ -182,6 +188,15 @@ int favae_bn_lrelu_bwd_bins(const void* dact, const void* act, const void* raw, 
                             const float* gamma, const double* bins, int nbins, void* draw, float* dgamma, float* dbeta,
                             float* dbias, long long R, int C, double* scratch, size_t scratch_doubles, int dtype,
                             void* stream);
+/* the two halves of FAVAE_DBIAS_DEFER: the slab count of favae_bn_lrelu_bwd_bins for (R, C) (host arithmetic only), and
+ * dbias[c] = sum over the slabs, in slab order, of partial[slab][c]. */
+int favae_bn_lrelu_bwd_slabs(long long R, int C);
+int favae_bn_dbias_finish(const double* partial, int nslab, int C, float* dbias, void* stream);
+/* favae_bn_dbias_finish without a launch of its own: the calling thread's NEXT favae_conv_wgrad launch does the sums in its
+ * first blocks, ahead of their own work (nslab <= 256).  What the training step uses: the weight gradient of the same layer
+ * is queued next, on the stream beside the main chain, and a separate launch in front of it costs as much as the deferral
+ * saves. */
+int favae_bn_dbias_ride(const double* partial, int nslab, int C, float* dbias);
 /* out[c] = sum_r x[r][c]  (bias gradients of layers without BN). */
 int favae_colsum(const void* x, long long R, int C, float* out, double* scratch, size_t scratch_doubles, int dtype,
                  void* stream);

@@ -356,6 +356,72 @@ def test_epilogue_sums_feed_batchnorm_backward(dt, tol, kind, Nb, Cin, Cout, H):
 
 
 @pytest.mark.parametrize("dt,tol", DT)
+@pytest.mark.parametrize("R,C", [(2048, 64), (16384, 128), (5000, 32), (262144, 64)])
+def test_bias_gradient_finished_by_a_second_launch(dt, tol, R, C):
+    """FAVAE_DBIAS_DEFER: favae_bn_lrelu_bwd_bins leaves the column sums of draw per slab of rows in the caller's buffer and
+    favae_bn_dbias_finish adds them up (what the training step does beside its main chain).  With the two BatchNorm sums set to
+    zero the column sum is a real number, gamma * invstd * sum(dact * slope): the two-launch form equals the one-launch form to
+    the last bit (same slabs, same order) and torch to fp32 accuracy; draw is the same."""
+    import ctypes
+    lib = _lib()
+    g = torch.Generator().manual_seed(R + C)
+    raw = torch.randn(R, C, generator=g).cuda()
+    dact = torch.randn(R, C, generator=g).cuda()
+    act = F.leaky_relu(torch.randn(R, C, generator=g), 0.01).to(dt).cuda()
+    gamma, mean, invstd = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    bins = torch.zeros(8, 2, C, dtype=torch.float64, device="cuda")
+    i_, ll_, sz_ = ctypes.c_int, ctypes.c_longlong, ctypes.c_size_t
+    rawl = lib.raw()
+    nslab = rawl.favae_bn_lrelu_bwd_slabs(ll_(R), i_(C))
+    assert 1 <= nslab <= 256
+    res = []
+    for flags in (0, 0x80):      # FAVAE_DBIAS_DEFER
+        scratch = torch.full((256 * C + 4096,), float("nan"), dtype=torch.float64, device="cuda")
+        draw = torch.empty(R, C, device="cuda", dtype=dt)
+        dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        dbias = torch.full((C,), 7.0, device="cuda")
+        lib.check(rawl.favae_bn_lrelu_bwd_bins(lib.ptr(dact), lib.ptr(act), lib.ptr(raw), lib.ptr(mean), lib.ptr(invstd), lib.ptr(gamma),
+                                               lib.ptr(bins), i_(8), lib.ptr(draw), lib.ptr(dg), lib.ptr(db), lib.ptr(dbias), ll_(R), i_(C),
+                                               lib.ptr(scratch), sz_(scratch.numel()), i_(lib.dtype_code(act) | flags), lib.stream_ptr()))
+        if flags:
+            assert torch.equal(dbias, torch.full((C,), 7.0, device="cuda"))     # untouched by the first launch
+            lib.check(rawl.favae_bn_dbias_finish(lib.ptr(scratch), i_(nslab), i_(C), lib.ptr(dbias), lib.stream_ptr()))
+        res.append((draw.float().cpu(), dbias.cpu()))
+    want = (gamma * invstd).double() * (dact.double() * torch.where(act.double() > 0, 1.0, 0.01)).sum(0)
+    assert torch.equal(res[1][0], res[0][0])
+    assert_close(res[0][1], want.float().cpu(), 1e-5)
+    assert_close(res[1][1], res[0][1], 1e-6)
+
+
+@pytest.mark.parametrize("nslab,C", [(128, 64), (7, 128), (256, 256), (33, 36)])
+def test_slab_sums_ride_with_the_next_weight_gradient(nslab, C):
+    """favae_bn_dbias_ride: the calling thread's next favae_conv_wgrad launch adds up [nslab][C] slab sums in its first blocks
+    (what favae_bn_dbias_finish does with a launch of its own); the weight gradient itself is unchanged, and the launch after
+    that carries nothing."""
+    import ctypes
+    lib = _lib()
+    g = torch.Generator().manual_seed(nslab + C)
+    partial = torch.randn(nslab, C, generator=g, dtype=torch.float64).cuda()
+    out = torch.full((C,), -5.0, device="cuda")
+    dt = torch.bfloat16
+    Nb, Hs, Hl, Rc, Cc = 8, 8, 16, 128, 64
+    rows = torch.randn(Nb, Hs, Hs, Rc, generator=g).to(dt).cuda()
+    cols = torch.randn(Nb, Hl, Hl, Cc, generator=g).to(dt).cuda()
+    dw0 = torch.zeros(Rc, 9, Cc, device="cuda")
+    lib.conv_wgrad(rows, 0, cols, 1, dw0, Nb, Hs, Hs, Hl, Hl, 3, 2, 1, -1)
+    lib.check(lib.raw().favae_bn_dbias_ride(lib.ptr(partial), ctypes.c_int(nslab), ctypes.c_int(C), lib.ptr(out)))
+    dw1 = torch.zeros(Rc, 9, Cc, device="cuda")
+    lib.conv_wgrad(rows, 0, cols, 1, dw1, Nb, Hs, Hs, Hl, Hl, 3, 2, 1, -1)
+    assert_close(dw1.cpu(), dw0.cpu(), 1e-6)      # (split reductions add with atomics: order)
+    assert_close(out.cpu(), partial.sum(0).float().cpu(), 1e-6)
+    out.fill_(-5.0)
+    dw2 = torch.zeros(Rc, 9, Cc, device="cuda")
+    lib.conv_wgrad(rows, 0, cols, 1, dw2, Nb, Hs, Hs, Hl, Hl, 3, 2, 1, -1)
+    assert_close(dw2.cpu(), dw0.cpu(), 1e-6)
+    assert torch.equal(out, torch.full((C,), -5.0, device="cuda"))
+
+
+@pytest.mark.parametrize("dt,tol", DT)
 def test_thin_input_gradient_takes_batchnorm_backward_sums(dt, tol):
     """Input gradient of final_layer.3 (3 -> 64 channels, one thread per pixel) with the BN-backward sums of the layer
     before it taken while the result is stored (favae_conv_igemm_red mode 2 on the thin-input path)."""
