@@ -1445,6 +1445,46 @@ __global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w,
     }
 }
 
+// The same for channel counts that are multiples of 4 (every layer but the image-side ends): a 64 (co) x 64 (ci) tile per block,
+// 16-byte loads along ci, the copy in 8-byte stores, the transpose through LDS in whole 128-byte rows along co -- a quarter of
+// the blocks of the 32x32 form and whole cache lines on both sides (the re-layout launches are 7 % of the step's kernel time,
+// beside the main chain).
+template <class T>
+__global__ __launch_bounds__(256) void wprep64_kernel(const float* __restrict__ w, T* __restrict__ wc, T* __restrict__ wt, int Co,
+                                                      int taps, int Ci) {
+    __shared__ float tile[64][65];
+    int b = blockIdx.x;
+    const int nci = (Ci + 63) / 64, nco = (Co + 63) / 64;
+    const int ci0 = (b % nci) * 64; b /= nci;
+    const int co0 = (b % nco) * 64;
+    const int tap = b / nco;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int ci = ci0 + tx * 4;
+    float4 P[4];
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = co0 + ty + 16 * i;
+        ok[i] = co < Co && ci < Ci;
+        P[i] = ok[i] ? *(const float4*)(w + ((size_t)co * taps + tap) * Ci + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = ty + 16 * i;
+        if (ok[i] && wc) store4<T>(wc + ((size_t)(co0 + row) * taps + tap) * Ci + ci, P[i].x, P[i].y, P[i].z, P[i].w);
+        tile[row][tx * 4 + 0] = P[i].x; tile[row][tx * 4 + 1] = P[i].y; tile[row][tx * 4 + 2] = P[i].z; tile[row][tx * 4 + 3] = P[i].w;
+    }
+    if (!wt) return;   // uniform
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cil = ty + 16 * i, co = co0 + tx * 4;
+        if (ci0 + cil < Ci && co < Co)
+            store4<T>(wt + ((size_t)(ci0 + cil) * taps + tap) * Co + co, tile[tx * 4 + 0][cil], tile[tx * 4 + 1][cil], tile[tx * 4 + 2][cil],
+                      tile[tx * 4 + 3][cil]);
+    }
+}
+
 struct WprepTable {
     const float* w[16]; void* wc[16]; void* wt[16];
     int Co[16], taps[16], Ci[16], start[17];
@@ -2062,6 +2102,16 @@ extern "C" int favae_adam_wprep(float* p, float* g, float* m, float* v, long lon
 extern "C" int favae_weight_prep(const float* w, void* w_copy, void* w_transposed, int Co, int taps, int Ci, int dtype,
                                  void* stream) {
     FAVAE_CHECK_ARG(w && Co > 0 && taps > 0 && Ci > 0 && (w_copy || w_transposed), "favae_weight_prep: bad argument");
+    static const bool tile32 = getenv("FAVAE_WPREP64") && getenv("FAVAE_WPREP64")[0] == '0';   // (A/B: the 32x32 form everywhere)
+    if (Ci % 4 == 0 && Co % 4 == 0 && !tile32 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)w_copy % 8) == 0 && ((uintptr_t)w_transposed % 8) == 0) {
+        const unsigned nb = (unsigned)(cdiv(Ci, 64) * cdiv(Co, 64) * taps);
+        if (dtype == FAVAE_F32)
+            hipLaunchKernelGGL(wprep64_kernel<float>, dim3(nb), dim3(256), 0, ST, w, (float*)w_copy, (float*)w_transposed, Co, taps, Ci);
+        else
+            hipLaunchKernelGGL(wprep64_kernel<bf16_t>, dim3(nb), dim3(256), 0, ST, w, (bf16_t*)w_copy, (bf16_t*)w_transposed, Co, taps, Ci);
+        FAVAE_LAUNCH_CHECK();
+        return FAVAE_OK;
+    }
     dim3 grid(cdiv(Ci, 32), cdiv(Co, 32), taps);
     if (dtype == FAVAE_F32)
         hipLaunchKernelGGL(wprep_kernel<float>, grid, dim3(256), 0, ST, w, (float*)w_copy, (float*)w_transposed, Co, taps, Ci);

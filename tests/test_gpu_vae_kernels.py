@@ -250,7 +250,7 @@ def test_adam_matches_torch_optim():
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("Co,taps,Ci", [(128, 9, 64), (3, 9, 64), (40, 1, 4096), (4096, 1, 20), (64, 9, 3)])
+@pytest.mark.parametrize("Co,taps,Ci", [(128, 9, 64), (3, 9, 64), (40, 1, 4096), (4096, 1, 20), (64, 9, 3), (100, 9, 36), (512, 9, 256)])
 def test_weight_prep(dt, Co, taps, Ci):
     L = _L()
     raw_ = L.raw()
