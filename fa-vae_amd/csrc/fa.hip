@@ -22,19 +22,19 @@ __device__ __forceinline__ f64x4 mfma_f64(double a, double b, f64x4 c) {
 
 // ---------------------------------------------------------------------------------------------------------
 // C[da][dbp] = A^T [B | 1]   (dbp = db + ones)
-// One block = 4 waves per (row slab, tile group).  Every wave accumulates TI x TJ tiles of 16x16 over its share of the
+// One block = 8 waves per (row slab, tile group).  Every wave accumulates TI x TJ tiles of 16x16 over its share of the
 // slab's rows (groups of 4 rows, interleaved between the waves), 4 rows per MFMA: lane l supplies row l>>4, column l&15
 // of both operands straight from global memory (128-B row segments; the operands are read exactly once, so there is
-// nothing to stage).  The four waves are added through LDS in wave order, the slabs in slab order by atb_finish =>
+// nothing to stage).  The eight waves are added through LDS in wave order, the slabs in slab order by atb_finish =>
 // bitwise reproducible.  HBM-bound: 8 B * N * (da + db) read, 8 B * nslab * da * dbp of partials written and re-read.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int TI = 4, TJ = 4;
-constexpr int ATB_WAVES = 4;
+constexpr int ATB_WAVES = 8;   // 8: two waves per SIMD at one block per CU (see atb_geom)
 
 __global__ __launch_bounds__(64 * ATB_WAVES) void atb_kernel(const double* __restrict__ A, int lda, int da,
                                                              const double* __restrict__ B, int ldb, int db, int ones, long long N,
                                                              int rps, int gj, double* __restrict__ partial) {
-    __shared__ double red[ATB_WAVES][TJ * 4][64];   // 32 KB: one row of tiles (TJ x 4 registers) of every wave
+    __shared__ double red[ATB_WAVES][TJ * 4][64];   // 64 KB: one row of tiles (TJ x 4 registers) of every wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane >> 4, lc = lane & 15;
     const int dbp = db + ones;
     const int i0 = (blockIdx.y / gj) * (TI * 16), j0 = (blockIdx.y % gj) * (TJ * 16);
@@ -44,10 +44,12 @@ __global__ __launch_bounds__(64 * ATB_WAVES) void atb_kernel(const double* __res
     for (int a = 0; a < TI; ++a)
 #pragma unroll
         for (int b = 0; b < TJ; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-    // two 4-row steps per iteration: 16 independent 8-byte loads per lane in flight before the first MFMA (the kernel is a
-    // stream over A and B; what it needs is bytes in flight, not MFMA issue)
-    for (long long n = n0 + 8 * wave; n < n1; n += 8 * ATB_WAVES) {
-        double av[2][TI], bv[2][TJ];
+    // tiles of this group that exist (block-uniform): a 20 x 21 statistic is 2 x 2 tiles, not the 4 x 4 of the group
+    const int ti = min(TI, (da - i0 + 15) / 16), tj = min(TJ, (dbp - j0 + 15) / 16);
+    // Two 4-row steps per iteration: up to 16 independent 8-byte loads per lane in flight.  The loads of the NEXT iteration are
+    // issued before the MFMAs of this one (two register sets, the loop unrolled by two): the kernel is a stream over A and B, and
+    // with ~3 waves per SIMD a wave that waits for its loads before every batch of MFMAs left the matrix pipe idle two thirds of the time.
+    auto load = [&](long long n, double (&av)[2][TI], double (&bv)[2][TJ]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const long long r = n + 4 * u + lr;
@@ -55,25 +57,42 @@ __global__ __launch_bounds__(64 * ATB_WAVES) void atb_kernel(const double* __res
 #pragma unroll
             for (int a = 0; a < TI; ++a) {
                 const int i = i0 + a * 16 + lc;
-                av[u][a] = (ok && i < da) ? A[r * lda + i] : 0.0;
+                av[u][a] = (a < ti && ok && i < da) ? A[r * lda + i] : 0.0;
             }
 #pragma unroll
             for (int b = 0; b < TJ; ++b) {
                 const int j = j0 + b * 16 + lc;
-                bv[u][b] = !ok ? 0.0 : (j < db ? B[r * ldb + j] : (j == db && ones ? 1.0 : 0.0));
+                bv[u][b] = (b >= tj || !ok) ? 0.0 : (j < db ? B[r * ldb + j] : (j == db && ones ? 1.0 : 0.0));
             }
         }
+    };
+    auto mma = [&](const double (&av)[2][TI], const double (&bv)[2][TJ]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int a = 0; a < TI; ++a)
 #pragma unroll
-                for (int b = 0; b < TJ; ++b) acc[a][b] = mfma_f64(av[u][a], bv[u][b], acc[a][b]);
+                for (int b = 0; b < TJ; ++b)
+                    if (a < ti && b < tj) acc[a][b] = mfma_f64(av[u][a], bv[u][b], acc[a][b]);   // uniform
+    };
+    constexpr long long STEP = 8 * ATB_WAVES;
+    double av0[2][TI], bv0[2][TJ], av1[2][TI], bv1[2][TJ];
+    long long n = n0 + 8 * wave;
+    if (n < n1) load(n, av0, bv0);
+    while (n < n1) {
+        if (n + STEP < n1) load(n + STEP, av1, bv1);
+        mma(av0, bv0);
+        n += STEP;
+        if (n >= n1) break;
+        if (n + STEP < n1) load(n + STEP, av0, bv0);
+        mma(av1, bv1);
+        n += STEP;
     }
     // C/D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
     double* out = partial + (size_t)blockIdx.x * da * dbp;
 #pragma unroll
     for (int a = 0; a < TI; ++a) {
+        if (a >= ti) break;   // block-uniform
 #pragma unroll
         for (int b = 0; b < TJ; ++b)
 #pragma unroll
@@ -82,7 +101,8 @@ __global__ __launch_bounds__(64 * ATB_WAVES) void atb_kernel(const double* __res
 #pragma unroll
         for (int k = 0; k < TJ * 4 / ATB_WAVES; ++k) {
             const int bg = wave + ATB_WAVES * k, b = bg >> 2, g = bg & 3;
-            const double t = (red[0][bg][lane] + red[1][bg][lane]) + (red[2][bg][lane] + red[3][bg][lane]);
+            double t = (red[0][bg][lane] + red[1][bg][lane]) + (red[2][bg][lane] + red[3][bg][lane]);
+            if constexpr (ATB_WAVES == 8) t += (red[4][bg][lane] + red[5][bg][lane]) + (red[6][bg][lane] + red[7][bg][lane]);
             const int i = i0 + a * 16 + lr + 4 * g, j = j0 + b * 16 + lc;
             if (i < da && j < dbp) out[(size_t)i * dbp + j] = t;
         }
@@ -443,12 +463,16 @@ inline int ew_grid(size_t n) { return (int)std::min<size_t>(2048, std::max<size_
 
 #define ST ((hipStream_t)stream)
 
-// slabs of rows: ~1024 blocks of 4 waves over the (tile group, slab) grid fill the chip; at least 256 rows per slab
+// slabs of rows: ONE block of 8 waves per CU over the (tile group, slab) grid.  The kernel needs ~235 registers, i.e. two waves
+// per SIMD: with 792 four-wave blocks a CU held two and the grid ran in 1.5 rounds of short blocks (Z^T [Z | 1] at N = 202 599:
+// 88 us); 256 eight-wave blocks run in one round, with 3x fewer partials to write and add (47 us; 128: 75 us, 512: 55 us).
+// At least 256 rows per slab.
 static void atb_geom(long long N, int da, int dbp, int* nslab, int* rps, int* gi, int* gj) {
     *gi = cdiv(cdiv(da, 16), TI);
     *gj = cdiv(cdiv(dbp, 16), TJ);
     const int groups = (*gi) * (*gj);
-    long long ns = std::max(1LL, std::min<long long>(cdivll(N, 256), std::max(1, 1024 / groups)));
+    static const int blocks = getenv("FAVAE_ATB_BLOCKS") ? atoi(getenv("FAVAE_ATB_BLOCKS")) : 256;
+    long long ns = std::max(1LL, std::min<long long>(cdivll(N, 256), std::max(1, blocks / groups)));
     long long r = cdivll(N, ns);
     r = (r + 15) & ~15LL;
     *rps = (int)r;
