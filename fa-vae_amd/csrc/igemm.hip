@@ -708,6 +708,7 @@ struct PmParams {
     int Rst, Cst;   // rows / columns of dw that exist (<= Rc, Cc: operands padded to whole vectors, see favae_conv_wgrad_folded)
     FlagCarry carry;   // dependency words of the launch stream, stored by the first block (common.h)
     SlabRider rider;   // a small reduction for the first blocks (common.h); partial == NULL: none
+    int xcd_units;     // > 0: XCD-contiguous work units (see the kernel), = blocks / 8
     int hw_shift, ws_shift;   // log2 of Hs*Ws and Ws when both are powers of two (every layer of the model), else -1
 };
 
@@ -758,11 +759,23 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
         }
     }
     const int wm = wave / WN, wn = wave % WN;
-    const int r0 = (blockIdx.x / p.ntn) * BM, c0 = (blockIdx.x % p.ntn) * BN;
-    const int tap = blockIdx.z, kh = tap / p.ks, kw = tap % p.ks;
+    // Blocks are dealt to the 8 XCDs round-robin in launch order.  With xcd_units > 0 block b takes work unit
+    // (b % 8) * xcd_units + b / 8, and the units are ordered tap-fastest: the nine taps of one (tile, slice) read the same pixels of
+    // both operands, shifted, and now meet in one L2 instead of up to eight.
+    unsigned bxx = blockIdx.x, byy = blockIdx.y, bzz = blockIdx.z;
+    if (p.xcd_units) {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned w = (lin & 7u) * (unsigned)p.xcd_units + (lin >> 3);
+        bzz = w % gridDim.z;
+        const unsigned t = w / gridDim.z;
+        bxx = t % gridDim.x;
+        byy = t / gridDim.x;
+    }
+    const int r0 = (bxx / p.ntn) * BM, c0 = (bxx % p.ntn) * BN;
+    const int tap = bzz, kh = tap / p.ks, kw = tap % p.ks;
     const int nchunk = (p.K + BK - 1) / BK;
     const int per = (nchunk + p.splitk - 1) / p.splitk;
-    const int c_begin = blockIdx.y * per, c_end = min(nchunk, c_begin + per);
+    const int c_begin = byy * per, c_end = min(nchunk, c_begin + per);
     if (c_begin >= c_end) return;
 
     // branch-free for whole-vector channel counts: clamped address, validity returned separately and applied when the
@@ -1037,6 +1050,11 @@ int dispatch_pm(PmParams p, hipStream_t st) {
         const int rc = favae_bn_dbias_finish(p.rider.partial, p.rider.nslab, p.rider.C, p.rider.out, st);
         if (rc != FAVAE_OK) return rc;
         p.rider.partial = nullptr;
+    }
+    {
+        static const bool xcd_off = getenv("FAVAE_PM_XCD") && getenv("FAVAE_PM_XCD")[0] == '0';
+        const unsigned total = grid.x * grid.y * grid.z;
+        p.xcd_units = (!xcd_off && grid.z > 1 && total % 8 == 0 && total >= 64) ? (int)(total / 8) : 0;
     }
     ProfScope prof(10 + tile, 2.0 * p.Rc * (double)p.Cc * p.K * p.ks * p.ks, st);
     constexpr int VE = 16 / (int)sizeof(T);
