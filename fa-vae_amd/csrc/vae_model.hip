@@ -912,6 +912,7 @@ extern "C" int favae_vae_set_data_u8(favae_vae* h, int on) {
 extern "C" int favae_vae_destroy(favae_vae* h) {
     if (!h) return FAVAE_OK;
     Vae& v = h->v;
+    favae_slab_rider().partial = nullptr;   // (may point into this executor's workspace)
     auto kill = [](hipEvent_t& e) { if (e) { (void)hipEventDestroy(e); e = nullptr; } };   // handles are value-initialised to null
     if (v.ev_fence_ok) { kill(v.ev_fence[0]); kill(v.ev_fence[1]); }
     for (hipStream_t q : {v.side, v.side2, v.side3})
@@ -962,6 +963,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
                  float beta, float var_x, double* metrics2_out, int stage_lo, int stage_hi, void* st) {
     const bool epoch = (v.overlap && v.ada.on && v.ada.epoch) || v.dp_epoch;
     if (v.overlap) RC(ensure_streams(v, (hipStream_t)st));
+    favae_slab_rider().partial = nullptr;   // (a rider that an aborted call on this thread left behind must not reach another launch)
     if (stage_lo == 0) {
         const bool can_fold = v.overlap && (v.fuse & 64u) && !(v.fuse & 0x200u) && v.ch <= 3;
         // Single-device epochs: encoder.0's weight gradient and update, the last links of a step, stay on the caller's
