@@ -663,6 +663,62 @@ int dbias_finish(Vae& v, int l, int slabs, void* st) {
 }
 int take_dbias_slabs(Vae& v, int l) { const int s = v.dbias_slabs[l]; v.dbias_slabs[l] = 0; return s; }
 
+// Small layers that are neighbours in the parameter arena and in the backward pass share ONE update: decoder.2 .. final_layer.3
+// (0.41 M parameters), fc | decoder_input (0.25 M) and encoder.1 .. encoder.3 (1.55 M).  Their per-layer Adam and re-layout
+// launches were ~4.5 us each for a few hundred KB: launch floors, beside the main chain, where a microsecond of kernel time costs
+// the step as much as on it (step 0.878 -> 0.862 ms; with the 4.7 M-parameter layers in a group it is slower: 0.871 - 0.877).
+// group_of: index of the layer's group or -1; a group is updated behind the weight gradient of its member that comes LAST in the
+// backward pass (= its first layer).
+struct UpdGroup { int l0, l1; };
+struct UpdGroups { UpdGroup g[6]; int n; };
+const UpdGroups& upd_groups() {
+    static const UpdGroups G = [] {
+        UpdGroups r{{{9, L_OUT}, {L_FC, L_DI}, {1, 3}}, 3};
+        const char* e = getenv("FAVAE_UPD_GROUPS");   // e.g. "8-12,4-7": ranges of layer indices (1 .. 12, encoder.0 stays on its own)
+        if (e) {
+            r.n = 0;
+            int a = 0, b = 0, used = 0;
+            while (r.n < 6 && sscanf(e, "%d-%d%n", &a, &b, &used) == 2 && a >= 1 && b >= a && b < NL) {
+                r.g[r.n++] = UpdGroup{a, b};
+                e += used;
+                if (*e == ',') ++e; else break;
+            }
+        }
+        return r;
+    }();
+    return G;
+}
+#define UPD_GROUPS (upd_groups().g)
+inline int group_of(const Vae& v, int l) {
+    if (v.fuse & 0x1000000u) return -1;   // (bit 0x1000000: every layer on its own, as before)
+    for (int g = 0; g < upd_groups().n; ++g)
+        if (l >= UPD_GROUPS[g].l0 && l <= UPD_GROUPS[g].l1) return g;
+    return -1;
+}
+int adam_group(Vae& v, int g, void* st, const Ada& a, int half) {
+    const int l0 = UPD_GROUPS[g].l0, l1 = UPD_GROUPS[g].l1;
+    const long long lo = v.L[l0].w_off, hi = l1 + 1 < NL ? v.L[l1 + 1].w_off : v.nparam;
+    if (a.epoch) RC(favae_adam_step_clear(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, a.lr, a.b1, a.b2, a.eps, a.step, st));
+    else RC(favae_adam_step(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, a.lr, a.b1, a.b2, a.eps, a.step, st));
+    const float* w[16]; void* wc[16]; void* wt[16]; int Co[16], taps[16], Ci[16];
+    int k = 0;
+    for (int l = l0; l <= l1; ++l) {
+        const Layer& L = v.L[l];
+        void* cc = L.wc_off >= 0 ? v.shp(half) + L.wc_off * v.esz : nullptr;
+        void* tt = L.wt_off >= 0 ? v.shp(half) + L.wt_off * v.esz : nullptr;
+        if (!cc && !tt) continue;
+        w[k] = v.P + L.w_off; wc[k] = cc; wt[k] = tt; Co[k] = L.Cout; taps[k] = L.taps; Ci[k] = L.Cin;
+        ++k;
+    }
+    if (k) RC(favae_weight_prep_batch(k, w, wc, wt, Co, taps, Ci, v.dtype, st));
+    if (l1 == L_OUT) {
+        const Layer& L = v.L[L_OUT];
+        void* cc = L.wc_off >= 0 ? v.shp(half) + L.wc_off * v.esz : nullptr;
+        RC(favae_conv_out_wprep(cc ? (const void*)cc : (const void*)(v.P + L.w_off), v.wk_out, v.ch, v.dtype, st));
+    }
+    return FAVAE_OK;
+}
+
 int wgrad(Vae& v, int l, const void* in, int B, void* st) {
     const int slabs = take_dbias_slabs(v, l);   // (by value into the job: the caller's thread may be a step ahead of the worker)
     if (!v.overlap) { RC(dbias_finish(v, l, slabs, st)); return wgrad_launch(v, l, in, B, st); }
@@ -676,10 +732,12 @@ int wgrad(Vae& v, int l, const void* in, int B, void* st) {
         RC(wgrad_launch(v, l, in, B, (void*)v.side));
         if (!ada.on) return FAVAE_OK;
         if (merged && (v.fuse & 0x20000u)) return adam_layer(v, l, (void*)v.side, ada, half);   // same stream: no further event
+        const int grp = merged ? group_of(v, l) : -1;
+        if (grp >= 0 && l != UPD_GROUPS[grp].l0) return FAVAE_OK;   // updated with its group (the weight-gradient stream runs in order)
         RC(sp_record(v, SP_WG + l, v.side, seq));
         if (merged) {   // optimiser stream, one wait: the update writes the shadow half no queued GEMM reads
             RC(sp_wait(v, SP_WG + l, v.side2, seq));
-            return adam_layer(v, l, (void*)v.side2, ada, half);
+            return grp >= 0 ? adam_group(v, grp, (void*)v.side2, ada, half) : adam_layer(v, l, (void*)v.side2, ada, half);
         }
         // Layer-wise optimiser step on the third stream.  The layer whose weight gradient was queued before this one may be
         // updated once that gradient is complete (ev_wg) and its input-gradient GEMM, the last reader of its weight shadows,
