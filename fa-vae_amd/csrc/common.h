@@ -79,7 +79,9 @@ __device__ __forceinline__ void wait_vm_writes() { asm volatile("s_waitcnt vmcnt
 // A small reduction that rides with this thread's next weight-gradient launch (igemm_pm): out[c] = sum over the slabs of
 // partial[slab][c], the second half of favae_bn_lrelu_bwd_bins with FAVAE_DBIAS_DEFER.  The first cdiv(C, 8) blocks of the launch
 // take 8 channels each before their own work: no launch of its own on the stream beside the main chain.
-struct SlabRider { const double* partial; float* out; int nslab, C; };
+// out0 != NULL (the sums of favae_conv_out_ll with FAVAE_DBIAS_DEFER): channel 0 goes to *out0 = off0 + scale0 * sum as a double
+// and channel c >= 1 to out[c - 1].
+struct SlabRider { const double* partial; float* out; int nslab, C; double* out0; double off0, scale0; };
 SlabRider& favae_slab_rider();                       // this thread's pending rider (api.hip)
 inline SlabRider favae_take_slab_rider() { SlabRider& r = favae_slab_rider(); const SlabRider k = r; r.partial = nullptr; return k; }
 struct FlagCarry { unsigned* p[4]; unsigned val; int n; };

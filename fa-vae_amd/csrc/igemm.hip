@@ -741,11 +741,13 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
             const int ch = tid & 7, part = tid >> 3, c = (int)lin * 8 + ch;
             double t = 0.0;
             if (c < p.rider.C) {
-                double x[8];
+                for (int k0 = part; k0 < p.rider.nslab; k0 += 32 * 8) {   // 8 independent loads in flight
+                    double x[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { const int k = part + 32 * q; x[q] = k < p.rider.nslab ? p.rider.partial[(size_t)k * p.rider.C + c] : 0.0; }
+                    for (int q = 0; q < 8; ++q) { const int k = k0 + 32 * q; x[q] = k < p.rider.nslab ? p.rider.partial[(size_t)k * p.rider.C + c] : 0.0; }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) t += x[q];
+                    for (int q = 0; q < 8; ++q) t += x[q];
+                }
             }
             rs[part * 8 + ch] = t;
             __syncthreads();
@@ -753,7 +755,9 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
                 double u = 0.0;
 #pragma unroll 8
                 for (int k = 0; k < 32; ++k) u += rs[k * 8 + tid];
-                p.rider.out[c] = (float)u;
+                if (!p.rider.out0) p.rider.out[c] = (float)u;
+                else if (c == 0) *p.rider.out0 = p.rider.off0 + p.rider.scale0 * u;
+                else p.rider.out[c - 1] = (float)u;
             }
             __syncthreads();   // (the stages below reuse the LDS)
         }
@@ -1030,7 +1034,7 @@ template <class T>
 int dispatch_pm(PmParams p, hipStream_t st) {
     p.carry = favae_take_flag_carry();
     p.rider = favae_take_slab_rider();
-    FAVAE_CHECK_ARG(!(p.rider.partial && (p.rider.nslab < 1 || p.rider.nslab > 256 || p.rider.C < 1 || p.rider.C > 2048)),
+    FAVAE_CHECK_ARG(!(p.rider.partial && (p.rider.nslab < 1 || p.rider.nslab > 65536 || p.rider.C < 1 || p.rider.C > 2048)),
                     "weight gradient: slab rider of %d slabs x %d channels", p.rider.nslab, p.rider.C);
     int tile = p.Rc <= 32 ? 0 : p.Cc <= 32 ? 1 : 2;   // 32x128, 128x32, 64x64
     if (g_force_pm_tile >= 0 && g_force_pm_tile <= 2) tile = g_force_pm_tile;
@@ -1046,7 +1050,7 @@ int dispatch_pm(PmParams p, hipStream_t st) {
                                      : std::min(std::max(1, nchunk / 8), std::max(1, (pm_target + blocks / 2) / blocks));
     p.splitk = std::max(1, std::min(sk, nchunk));
     dim3 grid(cdiv(p.Rc, BM) * p.ntn, p.splitk, p.ks * p.ks);
-    if (p.rider.partial && (long long)cdiv(p.rider.C, 8) > (long long)grid.x * grid.y * grid.z) {   // too few blocks to carry it: a launch of its own
+    if (p.rider.partial && !p.rider.out0 && (long long)cdiv(p.rider.C, 8) > (long long)grid.x * grid.y * grid.z) {   // too few blocks to carry it: a launch of its own
         const int rc = favae_bn_dbias_finish(p.rider.partial, p.rider.nslab, p.rider.C, p.rider.out, st);
         if (rc != FAVAE_OK) return rc;
         p.rider.partial = nullptr;
@@ -1314,7 +1318,17 @@ extern "C" int favae_debug_kc_blocks(unsigned long long* out16384) {
 
 extern "C" int favae_bn_dbias_ride(const double* partial, int nslab, int C, float* dbias) {
     FAVAE_CHECK_ARG(partial && dbias && nslab >= 1 && nslab <= 256 && C >= 1 && C <= 2048, "favae_bn_dbias_ride: bad argument");
-    favae_slab_rider() = SlabRider{partial, dbias, nslab, C};
+    favae_slab_rider() = SlabRider{partial, dbias, nslab, C, nullptr, 0.0, 0.0};
+    return FAVAE_OK;
+}
+
+extern "C" int favae_conv_out_ll_ride(const double* partial, int Nb, int H, int W, int Cout, float var_x, double* rec_err, float* dbias) {
+    FAVAE_CHECK_ARG(partial && rec_err && dbias && Nb > 0 && H > 0 && W > 0 && Cout >= 1 && Cout <= 4 && var_x > 0, "favae_conv_out_ll_ride: bad argument");
+    const long long blocks = ((long long)Nb * H * W + 255) / 256;
+    FAVAE_CHECK_ARG(blocks <= 65536, "favae_conv_out_ll_ride: %lld blocks", blocks);
+    const double D = (double)H * W * Cout;
+    favae_slab_rider() = SlabRider{partial, dbias, (int)blocks, 5, rec_err, 0.5 * (D * log(2.0 * M_PI) + D * log((double)var_x)),
+                                   0.5 / ((double)var_x * Nb)};
     return FAVAE_OK;
 }
 

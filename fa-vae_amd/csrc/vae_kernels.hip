@@ -1104,6 +1104,12 @@ __device__ __forceinline__ void conv_out_ll_tail(const float4v acc, const float*
         if (lane == 0) sm[k * 4 + wave] = a[k];
     }
     __syncthreads();
+    if (!ticket) {   // uniform, FAVAE_DBIAS_DEFER: the block's five sums stay in the caller's buffer, someone else adds the blocks
+        if (threadIdx.x < 5)
+            partial[(size_t)blockIdx.x * 5 + threadIdx.x] =
+                (sm[threadIdx.x * 4] + sm[threadIdx.x * 4 + 1]) + (sm[threadIdx.x * 4 + 2] + sm[threadIdx.x * 4 + 3]);
+        return;
+    }
     if (threadIdx.x < 5)
         __hip_atomic_store(&partial[(size_t)blockIdx.x * 5 + threadIdx.x],
                            (sm[threadIdx.x * 4] + sm[threadIdx.x * 4 + 1]) + (sm[threadIdx.x * 4 + 2] + sm[threadIdx.x * 4 + 3]),
@@ -1808,6 +1814,36 @@ extern "C" int favae_bn_lrelu_bwd(const void* dact, const void* act, const void*
 #undef BWD_ARGS
 }
 
+// the second half of favae_conv_out_ll with FAVAE_DBIAS_DEFER as a launch of its own (one block; the training step lets the
+// sums ride with the layer's weight gradient instead: favae_conv_out_ll_ride)
+__global__ __launch_bounds__(256) void conv_out_ll_finish_kernel(const double* __restrict__ partial, int blocks, double off0, double scale0,
+                                                                 int CO, double* __restrict__ rec_err, float* __restrict__ dbias) {
+    __shared__ double sm[32][8];
+    const int ch = threadIdx.x & 7, part = threadIdx.x >> 3;
+    double t = 0.0;
+    if (ch < 5)
+        for (int k = part; k < blocks; k += 32) t += partial[(size_t)k * 5 + ch];
+    sm[part][ch] = t;
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double u = 0.0;
+        for (int k = 0; k < 32; ++k) u += sm[k][threadIdx.x];
+        if (threadIdx.x == 0) *rec_err = off0 + scale0 * u;
+        else if ((int)threadIdx.x - 1 < CO) dbias[threadIdx.x - 1] = (float)u;
+    }
+}
+
+extern "C" int favae_conv_out_ll_finish(const double* partial, int Nb, int H, int W, int Cout, float var_x, double* rec_err, float* dbias,
+                                        void* stream) {
+    FAVAE_CHECK_ARG(partial && rec_err && dbias && Nb > 0 && H > 0 && W > 0 && Cout >= 1 && Cout <= 4 && var_x > 0, "favae_conv_out_ll_finish: bad argument");
+    const int blocks = cdiv(Nb * H * W, 256);
+    const double D = (double)H * W * Cout;
+    hipLaunchKernelGGL(conv_out_ll_finish_kernel, dim3(1), dim3(256), 0, ST, partial, blocks, 0.5 * (D * log(2.0 * M_PI) + D * log((double)var_x)),
+                       0.5 / ((double)var_x * Nb), Cout, rec_err, dbias);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
 extern "C" int favae_bn_lrelu_bwd_slabs(long long R, int C) {
     return (R > 0 && C > 0) ? red_geom(R, C).nslab : 0;
 }
@@ -1981,13 +2017,17 @@ extern "C" int favae_conv_out_ll(const void* act, const void* wk, const float* b
                                  size_t scratch_doubles, int dtype, void* stream) {
     FAVAE_CHECK_ARG(act && wk && x && raw && draw && rec_err && scratch && Nb > 0 && H > 0 && W > 0 && var_x > 0, "favae_conv_out_ll: bad argument");
     FAVAE_CHECK_ARG(Cout >= 1 && Cout <= 4, "favae_conv_out_ll: 1..4 output channels");
-    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_conv_out_ll: dtype");
+    FAVAE_CHECK_ARG((dtype & ~FAVAE_DBIAS_DEFER) == FAVAE_F32 || (dtype & ~FAVAE_DBIAS_DEFER) == FAVAE_BF16, "favae_conv_out_ll: dtype");
     FAVAE_CHECK_ARG(((uintptr_t)act % 16) == 0 && ((uintptr_t)wk % 16) == 0 && (size_t)Nb * H * W < (1u << 31), "favae_conv_out_ll: alignment / size");
     const int total = Nb * H * W, grid = cdiv(total, 256);
     FAVAE_CHECK_ARG((size_t)grid * 5 <= scratch_doubles, "favae_conv_out_ll: scratch too small (%zu < %zu doubles)", scratch_doubles, (size_t)grid * 5);
     unsigned* ticket = nullptr;
-    int trc = ticket_base(1, &ticket);
-    if (trc) return trc;
+    const bool defer = (dtype & FAVAE_DBIAS_DEFER) != 0;   // rec_err / dbias are left to favae_conv_out_ll_finish / _ride (ticket == NULL in the kernel)
+    dtype &= ~FAVAE_DBIAS_DEFER;
+    if (!defer) {
+        int trc = ticket_base(1, &ticket);
+        if (trc) return trc;
+    }
     const float ivb = 1.f / (var_x * (float)Nb);
     const double D = (double)H * W * Cout;
 #define CO_LAUNCH(T_, CO_)                                                                                                   \

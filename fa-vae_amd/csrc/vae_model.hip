@@ -204,6 +204,9 @@ struct Vae {
     // column sums of draw[l] per slab of rows, left by the BN-backward apply of this step (FAVAE_DBIAS_DEFER); dbias_slabs[l] > 0:
     // the stream that takes layer l's weight gradient adds them up first (dbias_finish)
     double* dbp[NL]; int dbias_slabs[NL];
+    // the five sums per block of the final conv + loss launch of this step (FAVAE_DBIAS_DEFER): added up by the first block of
+    // final_layer.3's weight gradient (ll_B > 0: pending, with the loss term's destination)
+    double* llp; int ll_B; float ll_var; double* ll_out;
     float* ab[NL]; bool act_deferred[NL]; bool bn_published[NL]; bool fi_on; int fi_pend[NL], fi_npend, fi_flushes; hipEvent_t ev_fi[2], ev_acts; bool acts_wait;
     // Dependency points between the streams (see sp_record / sp_wait): in threaded single-device epochs they are 32-bit words in
     // device memory written / awaited by stream memory operations with the step number as value, otherwise the events above.
@@ -352,6 +355,7 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
     v.xf_alt = (float*)c.take(img * 4);
     v.xt_alt = (char*)c.take(img * v.esz);
     v.wk_out = (char*)c.take(9 * 16 * 16 * 4);
+    v.llp = (double*)c.take((size_t)((B * 64 * 64 + 255) / 256) * 5 * 8);
     v.fold_bytes = favae_conv_wgrad_folded_scratch(B, 64, 64, v.dtype);
     v.fold = (char*)c.take(v.fold_bytes);
     v.fold0_bytes = (size_t)B * 32 * 32 * 32 * v.esz;
@@ -721,14 +725,19 @@ int adam_group(Vae& v, int g, void* st, const Ada& a, int half) {
 
 int wgrad(Vae& v, int l, const void* in, int B, void* st) {
     const int slabs = take_dbias_slabs(v, l);   // (by value into the job: the caller's thread may be a step ahead of the worker)
+    const int ll_B = l == L_OUT ? v.ll_B : 0;
+    const float ll_var = v.ll_var;
+    double* const ll_out = v.ll_out;
+    if (l == L_OUT) v.ll_B = 0;
     if (!v.overlap) { RC(dbias_finish(v, l, slabs, st)); return wgrad_launch(v, l, in, B, st); }
     const unsigned seq = v.step_no;
     RC(sp_record(v, SP_FORK + l, (hipStream_t)st, seq, true));   // rides with the input-gradient GEMM queued next
     const Ada ada = v.ada;
     const bool merged = v.merged; const int half = v.upd_half;
-    return side_do(v, [&v, l, in, B, ada, merged, half, seq, slabs]() -> int {
+    return side_do(v, [&v, l, in, B, ada, merged, half, seq, slabs, ll_B, ll_var, ll_out]() -> int {
         RC(sp_wait(v, SP_FORK + l, v.side, seq));
         RC(dbias_finish(v, l, slabs, (void*)v.side));
+        if (ll_B > 0) RC(favae_conv_out_ll_ride(v.llp, ll_B, 64, 64, v.ch, ll_var, ll_out, v.G + v.L[L_OUT].b_off));
         RC(wgrad_launch(v, l, in, B, (void*)v.side));
         if (!ada.on) return FAVAE_OK;
         if (merged && (v.fuse & 0x20000u)) return adam_layer(v, l, (void*)v.side, ada, half);   // same stream: no further event
@@ -1107,8 +1116,14 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
         RC(decoder_fwd(v, B, true, st, true, out_ll, decin));
         const long long D = (long long)64 * 64 * v.ch;
         if (out_ll) {   // final conv + sigmoid + log-likelihood + gradient + bias gradient in one launch
+            // epochs: the loss term and the bias gradient are needed by nobody on the main chain; their sums over the launch's
+            // blocks are left to the layer's weight gradient (folded form: one igemm_pm launch) on the stream beside it
+            // (FAVAE_FUSE_MASK bit 0x4000000: inside this launch, as before)
+            const bool defer = epoch && v.overlap && (v.fuse & 64u) && v.ch <= 3 && !(v.fuse & 0x4000000u);
+            if (defer) { v.ll_B = B; v.ll_var = var_x; v.ll_out = metrics2_out; }
             RC(favae_conv_out_ll(v.act[11], v.wk_out, v.P + v.L[L_OUT].b_off, v.xf, B, 64, 64, v.ch, var_x, v.raw[L_OUT], v.draw[L_OUT],
-                                 metrics2_out, v.G + v.L[L_OUT].b_off, v.scratch, v.scratch_doubles, v.dtype, st));
+                                 metrics2_out, v.G + v.L[L_OUT].b_off, defer ? v.llp : v.scratch,
+                                 defer ? (size_t)((B * 64 * 64 + 255) / 256) * 5 : v.scratch_doubles, v.dtype | (defer ? FAVAE_DBIAS_DEFER : 0), st));
         } else if (v.fuse & 8u) {
             RC(favae_sigmoid_ll_bias(v.raw[L_OUT], v.xf, B, D, v.ch, var_x, v.draw[L_OUT], metrics2_out, v.G + v.L[L_OUT].b_off, v.scratch,
                                      v.scratch_doubles, v.dtype, st));

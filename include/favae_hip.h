@@ -249,6 +249,14 @@ int favae_sigmoid_ll_bias(const float* raw, const float* x, int B, long long D, 
  * x [Nb,H,W,Cout] fp32 targets.  scratch >= 5 * ceil(Nb*H*W / 256) doubles.  Same results as favae_conv_igemm +
  * favae_sigmoid_ll_bias up to fp32 summation order. */
 int favae_conv_out_wprep(const void* w, void* wk, int Cout, int dtype, void* stream);
+/* favae_conv_out_ll with FAVAE_DBIAS_DEFER in dtype writes neither rec_err nor dbias: scratch keeps five sums per block of 256
+ * pixels ([ceil(Nb*H*W / 256)][5] doubles: squared error, then the bias-gradient sums), and the launch ends without the
+ * hand-over between its blocks.  _finish adds them up with a launch of its own; _ride lets the calling thread's next
+ * favae_conv_wgrad / favae_conv_wgrad_folded launch do it in its first block (the training step: final_layer.3's weight
+ * gradient is queued next, beside the main chain).  No reference counterpart (a split of :368-381 + :249). */
+int favae_conv_out_ll_finish(const double* partial, int Nb, int H, int W, int Cout, float var_x, double* rec_err, float* dbias,
+                             void* stream);
+int favae_conv_out_ll_ride(const double* partial, int Nb, int H, int W, int Cout, float var_x, double* rec_err, float* dbias);
 int favae_conv_out_ll(const void* act, const void* wk, const float* bias, const float* x, int Nb, int H, int W, int Cout,
                       float var_x, float* raw, void* draw, double* rec_err, float* dbias, double* scratch,
                       size_t scratch_doubles, int dtype, void* stream);

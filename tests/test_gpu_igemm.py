@@ -571,3 +571,22 @@ def test_final_conv_with_loss_in_one_launch(dt, tol, Nb, H, Co):
         assert abs(rec.item() + ll.item()) <= 1e-5 * abs(ll.item())
         assert_close(draw.float().cpu(), nhwc(y.grad), 1e-4 if dt == torch.float32 else 8e-3)
         assert_close(dbias.cpu(), b.grad, 1e-4)
+    # FAVAE_DBIAS_DEFER: the launch leaves five sums per block; a launch of its own (finish) or the first block of the calling
+    # thread's next weight-gradient launch (ride) adds them up: the same loss term and bias gradient
+    rec0, dbias0 = rec.clone(), dbias.clone()
+    for how in ("finish", "ride"):
+        rec.fill_(-1.0); dbias.fill_(-1.0); scratch.fill_(float("nan"))
+        lib.check(rawl.favae_conv_out_ll(lib.ptr(ad), lib.ptr(wk), lib.ptr(bd), lib.ptr(xd), i_(Nb), i_(H), i_(H), i_(Co), f_(var_x),
+                                         lib.ptr(raw), lib.ptr(draw), lib.ptr(rec), lib.ptr(dbias), lib.ptr(scratch), sz_(scratch.numel()),
+                                         i_(lib.dtype_code(ad) | 0x80), lib.stream_ptr()))
+        assert rec.item() == -1.0 and (dbias == -1.0).all()
+        if how == "finish":
+            lib.check(rawl.favae_conv_out_ll_finish(lib.ptr(scratch), i_(Nb), i_(H), i_(H), i_(Co), f_(var_x), lib.ptr(rec), lib.ptr(dbias),
+                                                    lib.stream_ptr()))
+        else:
+            lib.check(rawl.favae_conv_out_ll_ride(lib.ptr(scratch), i_(Nb), i_(H), i_(H), i_(Co), f_(var_x), lib.ptr(rec), lib.ptr(dbias)))
+            rows = torch.randn(4, 8, 8, 128).to(torch.bfloat16).cuda()
+            cols = torch.randn(4, 16, 16, 64).to(torch.bfloat16).cuda()
+            lib.conv_wgrad(rows, 0, cols, 1, torch.zeros(128, 9, 64, device="cuda"), 4, 8, 8, 16, 16, 3, 2, 1, -1)
+        assert abs(rec.item() - rec0.item()) <= 1e-12 * abs(rec0.item())
+        assert_close(dbias.cpu(), dbias0.cpu(), 1e-6)

@@ -296,7 +296,8 @@ def _same_epochs(a, b, dtype):
     # later steps: Adam's first steps move every entry by +-lr whatever the gradient magnitude, so entries whose gradient
     # is rounding noise (split-K atomics reorder sums) send ANY two runs apart (tools/dbg_epoch_vs_steps.py): the
     # reconstruction term stays within 1e-2, the (small) KL term within a factor
-    assert np.allclose(m1[:, :, 0], m0[:, :, 0], rtol=1e-2 if dtype == "f32" else 5e-2), np.abs(m1[:, :, 0] / m0[:, :, 0] - 1).max()
+    # (bf16: two runs of the SAME configuration differ by up to 0.059 over these 14 steps, tools/dbg_modes.py run 18 times)
+    assert np.allclose(m1[:, :, 0], m0[:, :, 0], rtol=1e-2 if dtype == "f32" else 1e-1), np.abs(m1[:, :, 0] / m0[:, :, 0] - 1).max()
     # (single steps spike: the KL term is chaotic early on -- two runs of the SAME configuration differ by a median |log ratio| of
     # 0.2-0.9 in bf16, tools/dbg_modes.py; a sanity bound, the reconstruction term above is the comparison)
     assert np.median(np.abs(np.log(m1[:, :, 1] / m0[:, :, 1]))) < (0.2 if dtype == "f32" else 1.5)
