@@ -630,8 +630,9 @@ int bn_bwd(Vae& v, int l, int B, void* st) {
         // the bias gradient (column sums of draw: rounding noise in front of a BatchNorm) is finished beside the main chain, by the
         // stream that takes the layer's weight gradient (FAVAE_FUSE_MASK bit 0x400000: inside this launch, as before)
         const int slabs = favae_bn_lrelu_bwd_slabs(v.rows(l, B), L.Cout);
-        // (not for encoder.0 when its weight gradient ends the step on the caller's stream: the finish would sit on the main chain)
-        const bool defer = !(v.fuse & 0x400000u) && v.dbp[l] && slabs >= 1 && slabs <= DBP_SLABS && !(l == 0 && v.inline_tail);
+        // (encoder.0: only when its weight gradient is the GEMM over the folded batch, which can carry the sums; a finishing
+        // launch of its own would sit on the main chain when the tail of the step runs there)
+        const bool defer = !(v.fuse & 0x400000u) && v.dbp[l] && slabs >= 1 && slabs <= DBP_SLABS && !(l == 0 && !v.x_folded);
         v.dbias_slabs[l] = defer ? slabs : 0;
         return favae_bn_lrelu_bwd_bins(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.gbins[l],
                                        bins_for(v.rows(l, B)), v.draw[l], v.G + L.g_off, v.G + L.be_off, v.G + L.b_off,
@@ -660,7 +661,7 @@ int dbias_finish(Vae& v, int l, int slabs, void* st) {
     if (slabs <= 0) return FAVAE_OK;
     // layers whose weight gradient is an igemm_pm launch on this thread, next: the sums ride with that launch (a launch of its own
     // in front of every weight gradient costs the step 1.2 %, as much as the shorter BN-backward launches bring)
-    if (l != 0 && l != L_OUT && v.L[l].kind != LINEAR) {
+    if ((l != 0 || v.x_folded) && l != L_OUT && v.L[l].kind != LINEAR) {
         return favae_bn_dbias_ride(v.dbp[l], slabs, v.L[l].Cout, v.G + v.L[l].b_off);
     }
     return favae_bn_dbias_finish(v.dbp[l], slabs, v.L[l].Cout, v.G + v.L[l].b_off, st);
@@ -1195,7 +1196,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             if (v.inline_tail) {
                 RC(sp_record(v, SP_FORK + 0, (hipStream_t)st, v.step_no, true));   // the next step's memset / gather may start here (rides with the weight-gradient GEMM below)
                 if (!v.fwd_folded) RC(sp_wait(v, SP_FOLD, (hipStream_t)st, v.step_no));
-                RC(dbias_finish(v, 0, take_dbias_slabs(v, 0), st));   // (nothing to do: see bn_bwd)
+                RC(dbias_finish(v, 0, take_dbias_slabs(v, 0), st));   // (rides with the launch below)
                 RC(wgrad_launch(v, 0, v.xt, B, st));
                 RC(sp_flush_carry((hipStream_t)st));
             } else {
