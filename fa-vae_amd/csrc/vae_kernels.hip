@@ -1456,10 +1456,8 @@ __global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w,
 // the blocks of the 32x32 form and whole cache lines on both sides (the re-layout launches are 7 % of the step's kernel time,
 // beside the main chain).
 template <class T>
-__global__ __launch_bounds__(256) void wprep64_kernel(const float* __restrict__ w, T* __restrict__ wc, T* __restrict__ wt, int Co,
-                                                      int taps, int Ci) {
-    __shared__ float tile[64][65];
-    int b = blockIdx.x;
+__device__ __forceinline__ void wprep64_tile(const float* __restrict__ w, T* __restrict__ wc, T* __restrict__ wt, int Co, int taps, int Ci,
+                                             int b, float (*tile)[65]) {
     const int nci = (Ci + 63) / 64, nco = (Co + 63) / 64;
     const int ci0 = (b % nci) * 64; b /= nci;
     const int co0 = (b % nco) * 64;
@@ -1490,14 +1488,22 @@ __global__ __launch_bounds__(256) void wprep64_kernel(const float* __restrict__ 
                       tile[tx * 4 + 3][cil]);
     }
 }
+template <class T>
+__global__ __launch_bounds__(256) void wprep64_kernel(const float* __restrict__ w, T* __restrict__ wc, T* __restrict__ wt, int Co,
+                                                      int taps, int Ci) {
+    __shared__ float tile[64][65];
+    wprep64_tile<T>(w, wc, wt, Co, taps, Ci, (int)blockIdx.x, tile);
+}
 
 struct WprepTable {
     const float* w[16]; void* wc[16]; void* wt[16];
     int Co[16], taps[16], Ci[16], start[17];
+    int t64[16];   // this tensor goes in 64x64 tiles (wprep64_tile: channel counts that are multiples of 4, aligned pointers)
 };
 template <class T>
 __global__ __launch_bounds__(256) void wprep_batch_kernel(const WprepTable tb, int n) {
-    __shared__ float tile[32][33];
+    __shared__ float tile64[64][65];
+    float (*tile)[33] = (float (*)[33])tile64;
     int l = 0;
     while (l + 1 < n && (int)blockIdx.x >= tb.start[l + 1]) ++l;
     const int Co = tb.Co[l], taps = tb.taps[l], Ci = tb.Ci[l];
@@ -1505,6 +1511,10 @@ __global__ __launch_bounds__(256) void wprep_batch_kernel(const WprepTable tb, i
     T* __restrict__ wc = (T*)tb.wc[l];
     T* __restrict__ wt = (T*)tb.wt[l];
     int b = blockIdx.x - tb.start[l];
+    if (tb.t64[l]) {   // block-uniform
+        wprep64_tile<T>(w, wc, wt, Co, taps, Ci, b, tile64);
+        return;
+    }
     const int nci = (Ci + 31) / 32, nco = (Co + 31) / 32;
     const int ci0 = (b % nci) * 32; b /= nci;
     const int co0 = (b % nco) * 32;
@@ -2171,7 +2181,10 @@ extern "C" int favae_weight_prep_batch(int n, const float* const* w, void* const
         tb.w[i] = w[i]; tb.wc[i] = w_copy[i]; tb.wt[i] = w_transposed[i];
         tb.Co[i] = Co[i]; tb.taps[i] = taps[i]; tb.Ci[i] = Ci[i];
         tb.start[i] = total;
-        total += cdiv(Ci[i], 32) * cdiv(Co[i], 32) * taps[i];
+        static const bool tile32 = getenv("FAVAE_WPREP64") && getenv("FAVAE_WPREP64")[0] == '0';   // (A/B: the 32x32 form everywhere)
+        tb.t64[i] = !tile32 && Ci[i] % 4 == 0 && Co[i] % 4 == 0 && ((uintptr_t)w[i] % 16) == 0 && ((uintptr_t)w_copy[i] % 8) == 0 &&
+                    ((uintptr_t)w_transposed[i] % 8) == 0;
+        total += tb.t64[i] ? cdiv(Ci[i], 64) * cdiv(Co[i], 64) * taps[i] : cdiv(Ci[i], 32) * cdiv(Co[i], 32) * taps[i];
     }
     tb.start[n] = total;
     if (dtype == FAVAE_F32)
