@@ -1264,7 +1264,28 @@ extern "C" int favae_conv_folded_fwd(const void* fold, const void* w, const floa
     FAVAE_CHECK_ARG(dtype == FAVAE_BF16 && Cout == 64 && K >= 1 && K <= 32, "favae_conv_folded_fwd: bf16, 64 outputs, K <= 32");
     FAVAE_CHECK_ARG(!bins || nbins >= 1, "favae_conv_folded_fwd: nbins");
     FAVAE_CHECK_ARG(((uintptr_t)fold % 16) == 0 && ((uintptr_t)out % 16) == 0, "favae_conv_folded_fwd: 16-byte alignment");
-    return folded_fwd_launch(fold, w, K, bias, out, P, bins, nbins, (hipStream_t)stream);
+    return folded_fwd_launch(fold, w, K, bias, out, P, bins, nbins, 0, (hipStream_t)stream);
+}
+
+extern "C" int favae_conv_fold_taps_split(const float* src, void* dst, size_t dst_bytes, int Nb, int Hs, int Ws, int Hl, int Wl, int C,
+                                          int stride, void* stream) {
+    FAVAE_CHECK_ARG(src && dst, "favae_conv_fold_taps_split: null pointer");
+    FAVAE_CHECK_ARG(Nb > 0 && Hs > 0 && Ws > 0 && C >= 1 && C <= 3, "favae_conv_fold_taps_split: bad shape (1..3 channels)");
+    FAVAE_CHECK_ARG(stride == 1 || stride == 2, "favae_conv_fold_taps_split: stride");
+    FAVAE_CHECK_ARG(Hs == (Hl + 2 - 3) / stride + 1 && Ws == (Wl + 2 - 3) / stride + 1, "favae_conv_fold_taps_split: small/large size mismatch");
+    FAVAE_CHECK_ARG((size_t)Nb * Hl * Wl < (1u << 31), "favae_conv_fold_taps_split: too many pixels");
+    const size_t need = (size_t)Nb * Hs * Ws * 32 * 2 * 2;
+    FAVAE_CHECK_ARG(need <= dst_bytes && ((uintptr_t)dst % 16) == 0, "favae_conv_fold_taps_split: dst holds %zu bytes, %zu needed (16-byte aligned)", dst_bytes, need);
+    return fold_taps_hl_launch(src, dst, Nb, Hs, Ws, Hl, Wl, C, stride, (hipStream_t)stream);
+}
+
+extern "C" int favae_conv_folded_fwd_split(const void* fold_hl, const float* w, const float* bias, float* out, long long P, int K, int Cout,
+                                           double* bins, int nbins, void* stream) {
+    FAVAE_CHECK_ARG(fold_hl && w && out && P > 0 && P < (1ll << 30), "favae_conv_folded_fwd_split: bad argument");
+    FAVAE_CHECK_ARG(Cout == 64 && K >= 1 && K <= 32, "favae_conv_folded_fwd_split: 64 outputs, K <= 32");
+    FAVAE_CHECK_ARG(!bins || nbins >= 1, "favae_conv_folded_fwd_split: nbins");
+    FAVAE_CHECK_ARG(((uintptr_t)fold_hl % 16) == 0 && ((uintptr_t)out % 16) == 0, "favae_conv_folded_fwd_split: 16-byte alignment");
+    return folded_fwd_launch(fold_hl, w, K, bias, out, P, bins, nbins, 1, (hipStream_t)stream);
 }
 
 extern "C" int favae_conv_wgrad_prefolded(const void* rows, int Rc, int Rst, const void* cols, int Cc, int Cst, float* dw,

@@ -21,5 +21,8 @@ int fold_taps_launch(const void* src, void* dst, int Nb, int Hq, int Wq, int Hn,
 
 // out [P][64] fp32 = fold [P][32] (bf16, columns >= K zero) x w [64][K]^T (bf16) + bias; optional BatchNorm sums (sum, sum of
 // squares per channel, fp64) added to bins [nbin][2][64].  See folded_fwd_kernel.
+// split != 0: fold holds the hi and the lo plane of fold_taps_hl_launch ([2][P][32]) and w is the fp32 weight [64][K].
 int folded_fwd_launch(const void* fold, const void* w, int K, const float* bias, float* out, long long P, double* bins, int nbin,
-                      hipStream_t st);
+                      int split, hipStream_t st);
+// fold_taps (shifted = 0) of an fp32 source into two bf16 planes: dst [P][32] = bf16(x), dst + P * 32 = bf16(x - bf16(x))
+int fold_taps_hl_launch(const float* src, void* dst, int Nb, int Hq, int Wq, int Hn, int Wn, int Cs, int stride, hipStream_t st);

@@ -343,15 +343,28 @@ __device__ __forceinline__ f32x16 mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, f32x16 
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256) void folded_fwd_kernel(const bf16_t* __restrict__ fold, const bf16_t* __restrict__ w, int K,
+// SPLIT: the operands carry (almost) fp32 precision as two bf16 terms each.  `fold` holds two planes of P rows -- the bf16
+// rounding of the fp32 pixels and the bf16 rounding of what that rounding dropped (fold_taps_hl) -- and `w` is the fp32 master
+// weight, split the same way into LDS here: out = x_hi w_hi + x_lo w_hi + x_hi w_lo (the dropped x_lo w_lo term is 2^-18 relative).
+// 12 MFMAs per 32 pixels instead of 4; the launch stays bound by its fp32 output.  The rounding of the IMAGE to bf16 was the largest
+// single contribution to the error of the bf16 path's latent means (it passes through all five BatchNorm layers): tools/dbg_parity_r3.py.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void folded_fwd_kernel(const bf16_t* __restrict__ fold, const void* __restrict__ w_, int K,
                                                          const float* __restrict__ bias, float* __restrict__ out, int P,
                                                          double* __restrict__ bins, int nbin, const FlagCarry carry) {
     carry_store(carry);
-    __shared__ __attribute__((aligned(16))) bf16_t wl[64 * 40];   // [cout][32] + 8 columns of padding (80-byte rows: conflict-free 16-B reads)
+    __shared__ __attribute__((aligned(16))) bf16_t wl[(SPLIT ? 2 : 1) * 64 * 40];   // [cout][32] + 8 columns of padding (80-byte rows: conflict-free 16-B reads)
     __shared__ double redsm[4 * 2 * 64];
     for (int i = threadIdx.x; i < 64 * 32; i += 256) {
         const int co = i >> 5, k = i & 31;
-        wl[co * 40 + k] = k < K ? w[co * K + k] : (bf16_t)0;
+        if constexpr (SPLIT) {
+            const float wf = k < K ? ((const float*)w_)[co * K + k] : 0.f;
+            const bf16_t hi = f32_to_bf16(wf);
+            wl[co * 40 + k] = hi;
+            wl[64 * 40 + co * 40 + k] = f32_to_bf16(wf - bf16_to_f32(hi));
+        } else {
+            wl[co * 40 + k] = k < K ? ((const bf16_t*)w_)[co * K + k] : (bf16_t)0;
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -361,6 +374,14 @@ __global__ __launch_bounds__(256) void folded_fwd_kernel(const bf16_t* __restric
     b01.u = *(const uint4*)(wl + r * 40 + 16 + h * 8);
     b10.u = *(const uint4*)(wl + (32 + r) * 40 + h * 8);
     b11.u = *(const uint4*)(wl + (32 + r) * 40 + 16 + h * 8);
+    [[maybe_unused]] U l00, l01, l10, l11;   // the low halves of the weights
+    if constexpr (SPLIT) {
+        const bf16_t* wl2 = wl + 64 * 40;
+        l00.u = *(const uint4*)(wl2 + r * 40 + h * 8);
+        l01.u = *(const uint4*)(wl2 + r * 40 + 16 + h * 8);
+        l10.u = *(const uint4*)(wl2 + (32 + r) * 40 + h * 8);
+        l11.u = *(const uint4*)(wl2 + (32 + r) * 40 + 16 + h * 8);
+    }
     const float bias0 = bias ? bias[r] : 0.f, bias1 = bias ? bias[32 + r] : 0.f;
     double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;   // sums of this lane's two output channels (r, 32 + r) over its pixel rows
     const int ngroup = (P + 31) / 32, nw = gridDim.x * 4;
@@ -372,6 +393,19 @@ __global__ __launch_bounds__(256) void folded_fwd_kernel(const bf16_t* __restric
         f32x16 c0, c1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { c0[i] = bias0; c1[i] = bias1; }
+        if constexpr (SPLIT) {   // smallest terms first
+            U x0, x1;
+            x0.u = *(const uint4*)(fold + ((size_t)P + pa) * 32 + h * 8);
+            x1.u = *(const uint4*)(fold + ((size_t)P + pa) * 32 + 16 + h * 8);
+            c0 = mfma_bf16_32x32x16(x0.b, b00.b, c0);
+            c0 = mfma_bf16_32x32x16(x1.b, b01.b, c0);
+            c1 = mfma_bf16_32x32x16(x0.b, b10.b, c1);
+            c1 = mfma_bf16_32x32x16(x1.b, b11.b, c1);
+            c0 = mfma_bf16_32x32x16(a0.b, l00.b, c0);
+            c0 = mfma_bf16_32x32x16(a1.b, l01.b, c0);
+            c1 = mfma_bf16_32x32x16(a0.b, l10.b, c1);
+            c1 = mfma_bf16_32x32x16(a1.b, l11.b, c1);
+        }
         c0 = mfma_bf16_32x32x16(a0.b, b00.b, c0);
         c0 = mfma_bf16_32x32x16(a1.b, b01.b, c0);
         c1 = mfma_bf16_32x32x16(a0.b, b10.b, c1);
@@ -407,12 +441,16 @@ __global__ __launch_bounds__(256) void folded_fwd_kernel(const bf16_t* __restric
 }  // namespace
 
 int folded_fwd_launch(const void* fold, const void* w, int K, const float* bias, float* out, long long P, double* bins, int nbin,
-                      hipStream_t st) {
+                      int split, hipStream_t st) {
     const FlagCarry carry = favae_take_flag_carry();
     const int ngroup = (int)((P + 31) / 32);
     const int grid = std::max(1, std::min(512, (ngroup + 3) / 4));
-    hipLaunchKernelGGL(folded_fwd_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)fold, (const bf16_t*)w, K, bias, out, (int)P, bins,
-                       std::max(1, nbin), carry);
+    if (split)
+        hipLaunchKernelGGL(folded_fwd_kernel<true>, dim3(grid), dim3(256), 0, st, (const bf16_t*)fold, w, K, bias, out, (int)P, bins,
+                           std::max(1, nbin), carry);
+    else
+        hipLaunchKernelGGL(folded_fwd_kernel<false>, dim3(grid), dim3(256), 0, st, (const bf16_t*)fold, w, K, bias, out, (int)P, bins,
+                           std::max(1, nbin), carry);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }
@@ -451,6 +489,51 @@ __global__ __launch_bounds__(256) void fold_taps(const T* __restrict__ src, T* _
     for (int i = 0; i < (int)(32 * sizeof(T) / 16); ++i) out[i] = vv[i];
 }
 }  // namespace
+
+// The same gather (shifted = 0) from an fp32 source into TWO bf16 planes of [pixels][32]: hi = bf16(x) at dst, lo = bf16(x - hi) at
+// dst + pixels * 32.  The weight gradient reads the hi plane (what fold_taps<bf16_t> writes); the SPLIT forward reads both.
+namespace {
+template <int CS>
+__global__ __launch_bounds__(256) void fold_taps_hl(const float* __restrict__ src, bf16_t* __restrict__ dst, int Hq, int Wq, int Hn, int Wn,
+                                                    int stride, int total) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= total) return;
+    const int n = pix / (Hq * Wq), rem = pix - n * Hq * Wq, y = rem / Wq, x = rem - y * Wq;
+    bf16_t hi[32], lo[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) hi[i] = lo[i] = (bf16_t)0;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int sy = y * stride - 1 + kh, sx = x * stride - 1 + kw;
+            if (sy < 0 || sy >= Hn || sx < 0 || sx >= Wn) continue;
+            const float* s = src + ((size_t)(n * Hn + sy) * Wn + sx) * CS;
+#pragma unroll
+            for (int c = 0; c < CS; ++c) {
+                const float f = s[c];
+                const bf16_t h = f32_to_bf16(f);
+                hi[(kh * 3 + kw) * CS + c] = h;
+                lo[(kh * 3 + kw) * CS + c] = f32_to_bf16(f - bf16_to_f32(h));
+            }
+        }
+    uint4* oh = (uint4*)(dst + (size_t)pix * 32);
+    uint4* ol = (uint4*)(dst + ((size_t)total + pix) * 32);
+    const uint4 *vh = (const uint4*)hi, *vl = (const uint4*)lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { oh[i] = vh[i]; ol[i] = vl[i]; }
+}
+}  // namespace
+
+int fold_taps_hl_launch(const float* src, void* dst, int Nb, int Hq, int Wq, int Hn, int Wn, int Cs, int stride, hipStream_t st) {
+    FAVAE_CHECK_ARG(Cs >= 1 && Cs <= 3, "fold_taps_hl: 1..3 channels");
+    const int total = Nb * Hq * Wq;
+#define FH_CASE(CS_) hipLaunchKernelGGL((fold_taps_hl<CS_>), dim3(cdiv(total, 256)), dim3(256), 0, st, src, (bf16_t*)dst, Hq, Wq, Hn, Wn, stride, total)
+    switch (Cs) { case 1: FH_CASE(1); break; case 2: FH_CASE(2); break; default: FH_CASE(3); }
+#undef FH_CASE
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
 
 int fold_taps_launch(const void* src, void* dst, int Nb, int Hq, int Wq, int Hn, int Wn, int Cs, int stride, int shifted,
                      int dtype, hipStream_t st) {

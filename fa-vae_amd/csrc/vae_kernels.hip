@@ -552,7 +552,7 @@ __global__ __launch_bounds__(OWN_THREADS) void bn_fwd_owner(const float* __restr
                                                             const float* __restrict__ beta, T* __restrict__ act,
                                                             float* __restrict__ mean, float* __restrict__ invstd,
                                                             float* __restrict__ run_mean, float* __restrict__ run_var, int R,
-                                                            int C, float eps, float mom) {
+                                                            int C, float eps, float mom, float* __restrict__ act32 = nullptr) {
     __shared__ double sm[2 * OWN_WAVES * OWN_CT], tot[2 * OWN_CT];
     __shared__ float ab[2 * OWN_CT];
     const int tid = threadIdx.x, tl = tid % OWN_TPR, rg = tid / OWN_TPR;
@@ -598,6 +598,7 @@ __global__ __launch_bounds__(OWN_THREADS) void bn_fwd_owner(const float* __restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = lrelu(x[p][j] * a[j] + b[j]);
             VecLoad<T, 4>::st(act + (size_t)r * C + c0, y);
+            if (act32) VecLoad<float, 4>::st(act32 + (size_t)r * C + c0, y);   // uniform
         }
     }
 }
@@ -1720,6 +1721,21 @@ extern "C" int favae_bn_train_fwd(const void* raw, const float* gamma, const flo
     if (rc) return rc;
     return favae_bn_lrelu_fwd(raw, mean, invstd, gamma, beta, act, R, C, 1, dtype, stream);
 }
+
+/* favae_bn_train_fwd for the small feature maps (one channel-owner launch) that also keeps the activation unrounded: act (dtype)
+ * for the backward pass and act_f32 for a consumer that wants fp32 (fc_mu | fc_var of the bf16 step). */
+extern "C" int favae_bn_train_fwd_keep32(const float* raw, const float* gamma, const float* beta, void* act, float* act_f32, float* mean,
+                                         float* invstd, float* run_mean, float* run_var, long long R, int C, float eps, float momentum,
+                                         int dtype, void* stream) {
+    FAVAE_CHECK_ARG(raw && gamma && beta && act && act_f32 && mean && invstd && R > 0 && C > 0, "favae_bn_train_fwd_keep32: bad argument");
+    FAVAE_CHECK_ARG(dtype == FAVAE_BF16 && owner_applicable(R, C), "favae_bn_train_fwd_keep32: bf16, at most %d rows, C a multiple of %d",
+                    OWN_RG * OWN_MAXP, OWN_CT);
+    hipLaunchKernelGGL(bn_fwd_owner<bf16_t>, dim3(C / OWN_CT), dim3(OWN_THREADS), 0, ST, raw, gamma, beta, (bf16_t*)act, mean, invstd,
+                       run_mean, run_var, (int)R, C, eps, momentum, act_f32);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+extern "C" int favae_bn_train_fwd_keep32_ok(long long R, int C) { return owner_applicable(R, C) ? 1 : 0; }
 
 extern "C" int favae_bn_train_fwd_bins(const void* raw, const double* bins, int nbins, const float* gamma, const float* beta,
                                        void* act, float* mean, float* invstd, float* run_mean, float* run_var, long long R,

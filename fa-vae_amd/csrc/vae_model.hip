@@ -191,6 +191,12 @@ struct Vae {
     char* fold0_buf[2]; int fold_sel; hipEvent_t ev_batch, ev_fold; bool inline_tail;   // see train_stages
     bool fwd_folded;   // this step's encoder.0 forward reads the folded batch (the caller's stream has waited for the fold)
     char* fold0; size_t fold0_bytes; hipEvent_t ev_x; bool x_folded;   // encoder.0's folded input batch, gathered on the side stream while the forward pass runs
+    // bf16 executor: the two ends of the encoder keep fp32 precision in the training step (FAVAE_BF16_EXACT_ENDS=0: plain bf16, as
+    // before).  encoder.0 reads the image as two bf16 terms (hi + lo planes of the folded batch, fp32 master weights split in the
+    // kernel), fc_mu | fc_var read encoder.4's activation unrounded with the fp32 master weights.  The image's rounding passes
+    // through all five BatchNorm layers and was the largest single term of the error of the latent means at initialisation
+    // (1.2e-2 of scale -> 0.75e-2; tools/dbg_parity_r3.py); both launches are bound by latency / their fp32 output, not by MFMA.
+    bool hp; float* act4_f32; bool act4_ready;
     char* fold; size_t fold_bytes;   // [pixels][32] tap-folded operand of the two image-side weight gradients (side stream only)   // second batch buffer: the next gather must not overwrite what wgrad(encoder.0) still reads
     // The dtype copies / transposes of the weights exist twice.  In single-device epochs the optimiser step of a layer follows
     // its weight gradient on the same stream and writes the re-laid weights into the half the running step does not read
@@ -358,7 +364,8 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
     v.llp = (double*)c.take((size_t)((B * 64 * 64 + 255) / 256) * 5 * 8);
     v.fold_bytes = favae_conv_wgrad_folded_scratch(B, 64, 64, v.dtype);
     v.fold = (char*)c.take(v.fold_bytes);
-    v.fold0_bytes = (size_t)B * 32 * 32 * 32 * v.esz;
+    v.fold0_bytes = (size_t)B * 32 * 32 * 32 * v.esz * (v.dtype == FAVAE_BF16 ? 2 : 1);   // bf16: hi and lo plane
+    v.act4_f32 = v.dtype == FAVAE_BF16 ? (float*)c.take((size_t)B * 4096 * 4) : nullptr;
     v.fold0_buf[0] = (char*)c.take(v.fold0_bytes);
     v.fold0_buf[1] = (char*)c.take(v.fold0_bytes);
     v.fold0 = v.fold0_buf[0];
@@ -481,9 +488,20 @@ int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false
     v.bn_published[l] = false;
     if (l == 0 && v.fwd_folded && pooled && fi < 0 && (v.fuse & 1u) && v.sbins[0] && !v.raw_bf[0]) {
         // encoder.0 of the training step as a K = 32 GEMM over the tap-folded batch (smallconv.hip, folded_fwd_kernel)
-        RC(folded_fwd_launch(v.fold0, v.Wf(0), 9 * v.ch, bias, v.raw[0], v.rows(0, B), v.sbins[0], bins_for(v.rows(0, B)), (hipStream_t)st));
+        RC(folded_fwd_launch(v.fold0, v.hp ? (const void*)(v.P + L.w_off) : v.Wf(0), 9 * v.ch, bias, v.raw[0], v.rows(0, B), v.sbins[0],
+                             bins_for(v.rows(0, B)), v.hp ? 1 : 0, (hipStream_t)st));
         v.stats_fused[0] = true;
         return FAVAE_OK;
+    }
+    if (l == 0 && v.hp && pooled && fi < 0 && thin_in_applicable(v.ch, L.Cout, 3, 2, 0)) {
+        // no folded batch (four channels, one stream): the thin-input convolution on the fp32 batch with the fp32 master weights
+        const ThinRed none{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+        return thin_in_launch(v.xf, v.P + L.w_off, bias, v.raw[0], B, L.Hin, L.Hin, v.ch, L.Hout, L.Hout, L.Cout, 2, 0, FAVAE_F32, 0, none,
+                              (hipStream_t)st);
+    }
+    if (l == L_FC && v.hp && pooled && v.act4_ready) {   // fc_mu | fc_var from the unrounded activation, fp32 matrix cores
+        v.act4_ready = false;
+        return favae_conv_igemm(v.act4_f32, v.P + L.w_off, bias, v.raw[l], B, 1, 1, L.Cin, 1, 1, L.Cout, 1, 1, 0, 0, sk, FAVAE_F32, st);
     }
     const bool publish = pooled && v.fi_on && (v.fuse & 1u) && v.sbins[l] && L.kind != LINEAR && L.bn && !v.raw_bf[l];
     if (fi >= 0 || publish) {
@@ -535,6 +553,11 @@ int bn_fwd(Vae& v, int l, int B, bool train, void* st) {
         v.stats_fused[l] = false;
         return favae_bn_train_fwd_bins(v.raw[l], v.sbins[l], bins_for(R), v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l],
                                        v.invstd[l], v.BUF + L.rm_off, v.BUF + L.rv_off, R, L.Cout, 1e-5f, 0.1f, dt, st);
+    }
+    if (train && l == 4 && v.hp && v.act4_f32 && !v.raw_bf[l] && favae_bn_train_fwd_keep32_ok(R, L.Cout)) {
+        v.act4_ready = true;
+        return favae_bn_train_fwd_keep32(v.raw[l], v.P + L.g_off, v.P + L.be_off, v.act[l], v.act4_f32, v.mean[l], v.invstd[l],
+                                         v.BUF + L.rm_off, v.BUF + L.rv_off, R, L.Cout, 1e-5f, 0.1f, v.dtype, st);
     }
     if (train)
         return favae_bn_train_fwd(v.raw[l], v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l], v.invstd[l], v.BUF + L.rm_off,
@@ -928,6 +951,11 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.eval_fused = batch_max >= 256 && !(getenv("FAVAE_EVAL_FUSED") && getenv("FAVAE_EVAL_FUSED")[0] == '0');
     v.eval_ab_ready = false;
     v.fwd_folded = false;
+    {
+        const char* hpe = getenv("FAVAE_BF16_EXACT_ENDS");
+        v.hp = dtype == FAVAE_BF16 && !(hpe && hpe[0] == '0');
+        v.act4_ready = false;
+    }
     v.step_no = 0; v.join_seq = 0; v.vals = false; v.vals_ok = -1; v.mark_prev = v.mark_cur = 0;
     v.data_u8 = false;
     v.fi_on = false; v.fi_npend = 0; v.fi_flushes = 0; v.acts_wait = false;
@@ -1072,7 +1100,8 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
                 FAVAE_HIP(hipMemsetAsync(v.zero_lo, 0, v.zero_bytes, v.side));
                 RC(gather(v, data_nhwc, idx, B, xf, xt, (void*)v.side));
                 RC(sp_record(v, SP_BATCH, v.side, seq));
-                RC(favae_conv_fold_taps(xt, fold0, v.fold0_bytes, B, 32, 32, 64, 64, v.ch, 2, 0, v.dtype, (void*)v.side));
+                if (v.hp) RC(favae_conv_fold_taps_split(xf, fold0, v.fold0_bytes, B, 32, 32, 64, 64, v.ch, 2, (void*)v.side));
+                else RC(favae_conv_fold_taps(xt, fold0, v.fold0_bytes, B, 32, 32, 64, 64, v.ch, 2, 0, v.dtype, (void*)v.side));
                 return sp_record(v, SP_FOLD, v.side, seq);
             }));
             v.x_folded = true;
@@ -1092,13 +1121,22 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             if (can_fold) {
                 // encoder.0's weight gradient ends the step: its tap gather needs the batch only, so it runs now, on the
                 // weight-gradient stream (idle during the forward pass; in order behind the previous step's last reader of fold0)
-                RC(sp_record(v, SP_X, (hipStream_t)st, seq, true));   // (rides with encoder.0's forward GEMM)
-                char* xt = v.xt; char* fold0 = v.fold0;
-                RC(side_do(v, [&v, xt, fold0, B, seq]() -> int {
+                // bf16 with exact ends: encoder.0's forward pass reads the (split) folded batch, so the caller's stream waits for it
+                const bool need_now = v.hp && v.L[0].Cout == 64 && !(v.fuse & 0x100000u) && !v.fi_on && (v.fuse & 1u) && v.sbins[0] && !v.raw_bf[0];
+                RC(sp_record(v, SP_X, (hipStream_t)st, seq, !need_now));   // (rides with encoder.0's forward GEMM unless that waits for the fold)
+                char* xt = v.xt; float* xf = v.xf; char* fold0 = v.fold0;
+                RC(side_do(v, [&v, xt, xf, fold0, B, seq, need_now]() -> int {
                     RC(sp_wait(v, SP_X, v.side, seq));
-                    return favae_conv_fold_taps(xt, fold0, v.fold0_bytes, B, 32, 32, 64, 64, v.ch, 2, 0, v.dtype, (void*)v.side);
+                    if (v.hp) RC(favae_conv_fold_taps_split(xf, fold0, v.fold0_bytes, B, 32, 32, 64, 64, v.ch, 2, (void*)v.side));
+                    else RC(favae_conv_fold_taps(xt, fold0, v.fold0_bytes, B, 32, 32, 64, 64, v.ch, 2, 0, v.dtype, (void*)v.side));
+                    return need_now ? sp_record(v, SP_FOLD, v.side, seq) : FAVAE_OK;
                 }));
                 v.x_folded = true;
+                if (need_now) {
+                    if (v.wk && !v.vals) RC(v.wk->drain());
+                    RC(sp_wait(v, SP_FOLD, (hipStream_t)st, seq));
+                    v.fwd_folded = true;
+                }
             }
             if (v.wk && !v.vals) RC(v.wk->drain());
         }

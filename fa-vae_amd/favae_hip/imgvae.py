@@ -175,8 +175,19 @@ class ImgVAE(VAE):
         return self
 
     # ---- data residency ---------------------------------------------------------------------------------------
+    def _source(self):
+        """The training images as the caller handed them in: the array / tensor of the last trainloop / update_x call, or --
+        on a model that came out of a pickle (cA/condition_a_pretrainedvae.py:87-94 un-pickles a trained ImgVAE and calls
+        update_x() with no argument) -- `self.img`, the tensor the reference keeps (:187) and pickles with the model."""
+        src = getattr(self, "_img_src", None)
+        if src is None:
+            src = self._img_src = self.img
+        if src is None:
+            raise ValueError("ImgVAE: no images yet (call trainloop(img=...) or update_x(img) first)")
+        return src
+
     def _resident(self, img):
-        """fp32 NHWC device copy of an image array; cached on the identity of the caller's array."""
+        """NHWC device copy of an image array / tensor; cached on the identity of the caller's object."""
         key = (id(img), tuple(img.shape))
         if key != self._img_key or self._data_dev is None:
             self._data_dev = self._engine().upload_images(img)
@@ -260,7 +271,7 @@ class ImgVAE(VAE):
             self._img_src = img
             self.img = torch.from_numpy(img) if isinstance(img, np.ndarray) else torch.as_tensor(img)
         e = self._engine()
-        data = self._resident(self._img_src)
+        data = self._resident(self._source())
         self.loss_during_training, self.elbo_training = [], []
         self.reconstruc_during_training, self.KL_during_training, self.KL_QandP = [], [], []
         if favae or self.ALWAYS_FA_PRIOR:
@@ -394,15 +405,15 @@ class ImgVAE(VAE):
     def update_x(self, img=None):
         e = self._engine()
         torch.empty((), dtype=torch.int64).random_()        # the sequential DataLoader still draws its base seed
-        if img is not None and getattr(self, "_img_src", None) is None:
+        if img is not None and getattr(self, "_img_src", None) is None and self.img is None:
             self._img_src = img
             self.img = torch.from_numpy(img) if isinstance(img, np.ndarray) else torch.as_tensor(img)
         if img is None or self.UPDATE_X_USES_SELF_IMG:
-            data = self._resident(self._img_src)
+            data = self._resident(self._source())
         elif img is getattr(self, "_img_src", None):
             data = self._resident(img)
         else:
-            data = e.upload_images(np.ascontiguousarray(img, dtype=np.float32))
+            data = self._images_to_dev(img)
         n = data.shape[0]
         self.x_mean_dev = torch.empty(n, self.dimx, dtype=torch.float64, device=self.device)
         self.x_cov_dev = torch.empty_like(self.x_mean_dev)
@@ -437,7 +448,7 @@ class ImgVAE(VAE):
         sample = self._latent_sample(mean, var).to(self.device).contiguous()
         torch.empty((), dtype=torch.int64).random_()
         acc = torch.zeros(3, dtype=torch.float64, device=self.device)
-        e.reconstruct_stats(sample, self._resident(self._img_src), acc, self.BATCH)
+        e.reconstruct_stats(sample, self._resident(self._source()), acc, self.BATCH)
         dist.sum_(acc)
         sse, sy, syy = acc.cpu().numpy()
         cnt = dist.sum_scalar(float(sample.shape[0]), self.device) * 64 * 64 * self.channels

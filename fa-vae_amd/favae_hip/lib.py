@@ -132,6 +132,25 @@ def conv_folded_fwd(folded, w, bias, out, bins=None):
     return out
 
 
+def conv_fold_taps_split(src_f32, Nb, Hs, Ws, Hl, Wl, stride):
+    """favae_conv_fold_taps_split: fp32 src -> [2, Nb*Hs*Ws, 32] bf16 (plane 0 = bf16(x), plane 1 = bf16(x - bf16(x)))."""
+    C = src_f32.shape[-1]
+    assert src_f32.dtype == torch.float32
+    dst = torch.empty(2, Nb * Hs * Ws, 32, dtype=torch.bfloat16, device=src_f32.device)
+    check(_lib.favae_conv_fold_taps_split(ptr(src_f32), ptr(dst), ctypes.c_size_t(dst.numel() * 2), _i(Nb), _i(Hs), _i(Ws), _i(Hl), _i(Wl),
+                                          _i(C), _i(stride), stream_ptr()))
+    return dst
+
+
+def conv_folded_fwd_split(folded_hl, w_f32, bias, out, bins=None):
+    """favae_conv_folded_fwd_split: out [P, 64] f32 = x w^T + bias with x as hi + lo bf16 planes and w (fp32) split in the kernel."""
+    P, Cout, K = folded_hl.shape[1], w_f32.shape[0], w_f32.numel() // w_f32.shape[0]
+    assert folded_hl.dtype == torch.bfloat16 and w_f32.dtype == torch.float32 and out.dtype == torch.float32 and out.shape == (P, Cout)
+    check(_lib.favae_conv_folded_fwd_split(ptr(folded_hl), ptr(w_f32), ptr(bias), ptr(out), ctypes.c_longlong(P), _i(K), _i(Cout), ptr(bins),
+                                           _i(0 if bins is None else bins.shape[0]), stream_ptr()))
+    return out
+
+
 def conv_wgrad_prefolded(rows, cols, dw, Rst, Cst, splitk=0):
     """favae_conv_wgrad_prefolded: dw [Rst][Cst] += rows^T cols over the K rows of two plain matrices."""
     assert rows.dtype == cols.dtype and dw.dtype == torch.float32 and rows.shape[0] == cols.shape[0]

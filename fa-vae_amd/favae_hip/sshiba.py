@@ -49,6 +49,7 @@ class LazyDict(dict):
 
     def __setitem__(self, key, value):
         self._dev.pop(key, None)
+        self._touched = True          # a caller assigned an entry by hand (cA/condition_a_pretrainedvae.py:94-95)
         dict.__setitem__(self, key, value)
 
     def __getstate__(self):
@@ -127,6 +128,40 @@ class SSHIBA(object):
                     center=center, deg=deg, latent_dim=latent_dim, lr=lr, epochs=epochs, dataset=dataset)
 
     # ---- device helpers ------------------------------------------------------------------------------------------
+    def _device_state(self):
+        """Device handle + scratch buffers; built by fit, and again on first use by a model that came out of a pickle (the
+        result scripts un-pickle a fitted model and call predict, DA/results_celeba2cartoon.py:25-34)."""
+        import os
+        if not torch.cuda.is_available():
+            raise L.FavaeHipError("SSHIBA needs a GPU: the HIP path has no CPU fallback")
+        self.dev = torch.device("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(self.dev)
+        self.sc = fa.Scratch(self.dev)
+        self.scal = torch.zeros(4, dtype=F64, device=self.dev)
+
+    def __getattr__(self, name):          # only reached when the attribute is missing: device state dropped by pickling
+        if name in ("dev", "sc", "scal") and "q_dist" in self.__dict__:
+            self._device_state()
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+    def _resume_device_stats(self):
+        """After un-pickling: the reduced statistics the updates read (column sums, traces, Z^T [Z | 1]) and the device copies
+        of xi / the semi-supervised masks are rebuilt from the pickled state, so fit_iterate can go on where it stopped."""
+        q = self.q_dist
+        q.xi = [torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(self.dev) if isinstance(x, np.ndarray) else x
+                for x in q.xi]
+        if any(self.SS):
+            self._ss_mask_dev = {m: torch.from_numpy(self.SS_mask[m] if self.method[m] == "reg" else self.SS_mask[m].astype(np.uint8)).to(self.dev)
+                                 for m in range(self.m) if self.SS[m]}
+        self._xsum = {}
+        for m in range(self.m):
+            prod = dict.__getitem__(self.X[m], "prodT")
+            self._refresh_xstats(m)
+            dict.__setitem__(self.X[m], "prodT", prod)
+            self.X[m]._touched = False
+        self._refresh_zstats()
+
     def _up(self, a):
         return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64))).to(self.dev)
 
@@ -165,11 +200,7 @@ class SSHIBA(object):
     def fit(self, *args, **kwargs):
         if not torch.cuda.is_available():
             raise L.FavaeHipError("SSHIBA.fit needs a GPU: the HIP path has no CPU fallback")
-        import os
-        self.dev = torch.device("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")))
-        torch.cuda.set_device(self.dev)
-        self.sc = fa.Scratch(self.dev)
-        self.scal = torch.zeros(4, dtype=F64, device=self.dev)
+        self._device_state()
         n = [int(a["data"].shape[0]) for a in args]
         self.n_loc = int(np.max(n))                       # rows held by this rank (the views passed in are this rank's shard)
         self.n_max = int(round(dist.sum_scalar(self.n_loc, self.dev)))      # global N of the formulas
@@ -312,6 +343,8 @@ class SSHIBA(object):
             W["prodT"] = np.dot(W["mean"].T, W["mean"]) + self.Kc * W["cov"]
             self._refresh_xstats(m)
             self.update_b(m, n=self.n[m] if self.n[m] != self.n_loc else None)                       # :1986-1988 (n[m], not n_max)
+        for X in self.X:
+            X._touched = False
         if self.VARIANT == "A":
             if not kwargs["pretrained"]:                                                             # :378 (KeyError if absent)
                 self.fit_iterate(**kwargs)
@@ -331,6 +364,9 @@ class SSHIBA(object):
                      X_tst=[None], X_tr=[None], HL=0, AUC=0, ACC=0, mse=0, R2=0, m_in=[0], m_out=1, steps=50, nnd=None,
                      pretrained=0, mc_it=1, Y_ss=None, store=False, xga=None, tgx=None, lr=None):
         q = self.q_dist
+        for vae in self.img_vae:           # also a model injected after fit(pretrained=1): one sync when fit_iterate returns
+            if vae is not None:
+                vae.defer_pull = True
         for i in range(max_iter):
             self.update(iter_count=i)
             if self.prune:
@@ -355,6 +391,12 @@ class SSHIBA(object):
     # ---- update (:743-902) ---------------------------------------------------------------------------------------
     def update(self, Y_tst=[None], X_tst=[None], X_tr=[None], Y_ss=None, HL=0, AUC=0, ACC=0, mse=0, R2=0, m_in=[0], m_out=1,
                steps=100, mc_it=1, store=True, iter_count=0):
+        if "_xsum" not in self.__dict__:
+            self._resume_device_stats()
+        for m in range(self.m):
+            if getattr(self.X[m], "_touched", False):      # X[m]['mean'] / ['cov'] were assigned from outside: the column sums
+                self._refresh_xstats(m)                    # and traces the tau / b updates read follow them
+                self.X[m]._touched = False
         # X_m^T [Z | 1] of every view in one all-reduce (Z does not change between the W updates)
         Zd = self.q_dist.Z.dev("mean", self.dev)
         xtz = dist.sum_many_([fa.atb(self.X[m].dev("mean", self.dev), Zd, True, self.sc) for m in range(self.m)])

@@ -139,6 +139,18 @@ int favae_conv_fold_taps(const void* src, void* dst, size_t dst_bytes, int Nb, i
 int favae_conv_wgrad_prefolded(const void* rows, int Rc, int Rst, const void* cols, int Cc, int Cst, float* dw, long long K,
                                int splitk, int dtype, void* stream);
 
+/* The same pair with (almost) fp32 operands on bf16 matrix cores, for encoder.0 of the bf16 training step (the image is the one
+ * operand whose bf16 rounding passes through every BatchNorm of the encoder; celeba_deepvanilla_vae.py:31-33, 80-87):
+ *   fold_taps_split: fp32 src [Nb,Hl,Wl,C] -> two bf16 planes of [Nb*Hs*Ws][32]: dst = bf16(x) (exactly what
+ *     favae_conv_fold_taps(shifted = 0, bf16) writes: the weight gradient keeps reading it), dst + Nb*Hs*Ws*32 = bf16(x - bf16(x));
+ *     dst_bytes >= Nb*Hs*Ws*128.
+ *   folded_fwd_split: out = x_hi w_hi + x_lo w_hi + x_hi w_lo + bias with w the fp32 master weights [Cout][K], split in the
+ *     kernel; fold_hl the two planes above; bins as in favae_conv_folded_fwd. */
+int favae_conv_fold_taps_split(const float* src, void* dst, size_t dst_bytes, int Nb, int Hs, int Ws, int Hl, int Wl, int C,
+                               int stride, void* stream);
+int favae_conv_folded_fwd_split(const void* fold_hl, const float* w, const float* bias, float* out, long long P, int K, int Cout,
+                                double* bins, int nbins, void* stream);
+
 /* Live HIP-event timing of selected launches (measurement only; no reference counterpart). Every stride-th launch of each
  * kernel class is timed on its launch stream; collect() synchronises and returns [16][3] = launches, seconds, algorithmic
  * work per class: flops for the GEMM classes, bytes for the HBM-bound ones (7 BatchNorm-backward apply, 13 Adam); classes
@@ -163,6 +175,13 @@ int favae_bn_eval_prep(const float* run_mean, const float* run_var, int C, float
 /* act = LeakyReLU_0.01((raw-mean)*invstd*gamma+beta) stored as dtype (:34-35); apply_act=0 skips the LeakyReLU. */
 int favae_bn_lrelu_fwd(const void* raw, const float* mean, const float* invstd, const float* gamma, const float* beta,
                        void* act, long long R, int C, int apply_act, int dtype, void* stream);
+/* BatchNorm2d (training) + LeakyReLU of a small feature map (R <= 1024 rows; encoder.4, :34-35) in one channel-owner launch that
+ * writes the activation twice: act (bf16, what the backward pass and the weight gradient read) and act_f32 (unrounded), which
+ * fc_mu | fc_var of the bf16 step read (:82-85), so the last rounding in front of the latent means is fp32's.  _ok: shape test. */
+int favae_bn_train_fwd_keep32(const float* raw, const float* gamma, const float* beta, void* act, float* act_f32, float* mean,
+                              float* invstd, float* run_mean, float* run_var, long long R, int C, float eps, float momentum,
+                              int dtype, void* stream);
+int favae_bn_train_fwd_keep32_ok(long long R, int C);
 /* act = LeakyReLU_0.01(raw * a[c] + b[c]) with ab [2*C] = (a | b) as published by favae_conv_igemm_bn: the activation that a consuming
  * favae_conv_igemm_bn forms on the fly, materialised (bit-identical) for the backward pass (:34-35 under loss.backward(), :249). */
 int favae_bn_lrelu_fwd_ab(const float* raw, const float* ab, void* act, long long R, int C, int dtype, void* stream);

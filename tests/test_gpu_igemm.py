@@ -515,6 +515,39 @@ def test_forward_convolution_over_the_folded_batch(Nb, H, Cs):
     assert_close(out2.cpu().double(), ref - b.double(), 1e-5)
 
 
+@pytest.mark.parametrize("Nb,H,Cs", [(64, 64, 3), (5, 32, 3), (3, 18, 1), (7, 10, 2)])
+def test_forward_convolution_over_the_folded_batch_in_two_bf16_terms(Nb, H, Cs):
+    """favae_conv_fold_taps_split + favae_conv_folded_fwd_split: encoder.0 of the bf16 step with fp32 image and fp32 weights, each
+    carried as two bf16 terms on the bf16 matrix cores (x_hi w_hi + x_lo w_hi + x_hi w_lo): against F.conv2d in float64 on the
+    UNROUNDED operands at 2e-5 of scale (the plain bf16 form is 4e-3 away on these inputs); the hi plane is bit-identical to
+    favae_conv_fold_taps of the bf16 batch (the weight gradient reads it)."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(71 + H)
+    Cout = 64
+    x = torch.rand(Nb, Cs, H, H, generator=g)
+    w = torch.randn(Cout, Cs, 3, 3, generator=g) * 0.3
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    xd = nhwc(x).cuda()
+    hl = lib.conv_fold_taps_split(xd, Nb, H // 2, H // 2, H, H, 2)
+    plain = lib.conv_fold_taps(xd.to(torch.bfloat16), Nb, H // 2, H // 2, H, H, 2)
+    assert torch.equal(hl[0], plain)
+    want = F.unfold(x, 3, padding=1, stride=2).reshape(Nb, Cs, 9, -1).permute(0, 3, 2, 1).reshape(-1, 9 * Cs)
+    both = hl[0].float() + hl[1].float()
+    assert (both[:, :9 * Cs].cpu() - want).abs().max() <= 2.0 ** -16 and not both[:, 9 * Cs:].any()
+    wd = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cs).contiguous().cuda()
+    out = torch.full((ref.shape[0], Cout), float("nan"), device="cuda")
+    bins = torch.zeros(8, 2, Cout, dtype=torch.float64, device="cuda")
+    lib.conv_folded_fwd_split(hl, wd, b.cuda(), out, bins)
+    assert_close(out.cpu().double(), ref, 2e-5)
+    tot = bins.sum(0).cpu()
+    assert_close(tot[0], out.double().sum(0).cpu(), 1e-10)
+    assert_close(tot[1], (out.double() ** 2).sum(0).cpu(), 1e-10)
+    rounded = torch.empty_like(out)
+    lib.conv_folded_fwd(hl[0], wd.to(torch.bfloat16), b.cuda(), rounded)
+    assert (rounded.cpu().double() - ref).abs().max() > 20 * (out.cpu().double() - ref).abs().max()
+
+
 @pytest.mark.parametrize("dt,tol", DT)
 @pytest.mark.parametrize("Nb,H,Co", [(2, 64, 3), (3, 18, 2), (64, 64, 3)])
 def test_folded_weight_gradient_final_conv(dt, tol, Nb, H, Co):

@@ -78,7 +78,12 @@ def test_training_steps_match_oracle(dtype, tol_loss, tol_bulk, min_cos):
         assert abs(m[0] - rec_err.item()) <= tol_loss * abs(rec_err.item()), (step, m, rec_err.item())
         assert abs(m[1] - kl.item()) <= tol_loss * abs(kl.item()) + 1e-6, (step, m, kl.item())
         fc = eng.debug(0, 5, (Bn, 2 * z), torch.float32).cpu().numpy()
-        assert _rel(fc[:, :z], mu.detach().numpy()) <= tol_loss * 10
+        # latent means / log-variances of the training-mode forward pass at the north_star tolerance (bf16 measured 7.8e-3 at the
+        # fresh initialisation -- step 0, where BatchNorm amplifies rounding most -- and 3-7e-4 afterwards; 1.2e-2 before encoder.0
+        # and the heads kept fp32 precision, tools/dbg_parity_r3.py)
+        assert _rel(fc[:, :z], mu.detach().numpy()) <= tol_loss, (step, _rel(fc[:, :z], mu.detach().numpy()))
+        logvar = 2 * np.log(std.detach().numpy())
+        assert _rel(fc[:, z:] + 1e-6, logvar) <= tol_loss, (step, _rel(fc[:, z:] + 1e-6, logvar))
         g = eng.unpack(eng.G)
         for k in names:
             if k in NOISE_ONLY:
@@ -410,7 +415,7 @@ def test_data_parallel_epoch_over_rccl_one_rank():
     assert len(diffs) == 2 and max(diffs) < 1e-3, out.stdout[-2000:]
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("bf16", 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("bf16", 1e-2)])   # bf16 measured: mu 2.9e-3, var 3e-4, decoder 2.5e-4
 def test_eval_encoder_and_decoder_match_oracle(dtype, tol):
     z, Bn = 8, 24
     torch.manual_seed(3)
@@ -441,7 +446,7 @@ def test_eval_encoder_and_decoder_match_oracle(dtype, tol):
     assert _rel(out.cpu().permute(0, 3, 1, 2).numpy(), rec.numpy()) <= tol
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("bf16", 1e-2)])
 def test_whole_dataset_eval_passes_equal_the_batch_64_passes(dtype, tol):
     """update_x / reconstruction over a resident data set run through the large-batch eval executor (engine.eval_batch);
     eval mode is independent per sample, so they must reproduce the batch-64 calls (the reference's loader size).
