@@ -8,7 +8,7 @@
 
 static thread_local char g_err[512] = "";
 SlabRider& favae_slab_rider() {
-    static thread_local SlabRider r = {nullptr, nullptr, 0, 0, nullptr, 0.0, 0.0};
+    static thread_local SlabRider r = {nullptr, nullptr, 0, 0, nullptr, 0.0, 0.0, 0};
     return r;
 }
 

@@ -81,7 +81,8 @@ __device__ __forceinline__ void wait_vm_writes() { asm volatile("s_waitcnt vmcnt
 // take 8 channels each before their own work: no launch of its own on the stream beside the main chain.
 // out0 != NULL (the sums of favae_conv_out_ll with FAVAE_DBIAS_DEFER): channel 0 goes to *out0 = off0 + scale0 * sum as a double
 // and channel c >= 1 to out[c - 1].
-struct SlabRider { const double* partial; float* out; int nslab, C; double* out0; double off0, scale0; };
+// nout: entries of `out` that exist (out0 form: Cout of the convolution, 1..4; the launch holds five sums per block whatever Cout is).
+struct SlabRider { const double* partial; float* out; int nslab, C; double* out0; double off0, scale0; int nout; };
 SlabRider& favae_slab_rider();                       // this thread's pending rider (api.hip)
 inline SlabRider favae_take_slab_rider() { SlabRider& r = favae_slab_rider(); const SlabRider k = r; r.partial = nullptr; return k; }
 struct FlagCarry { unsigned* p[4]; unsigned val; int n; };

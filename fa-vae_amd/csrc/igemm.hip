@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
                 for (int k = 0; k < 32; ++k) u += rs[k * 8 + tid];
                 if (!p.rider.out0) p.rider.out[c] = (float)u;
                 else if (c == 0) *p.rider.out0 = p.rider.off0 + p.rider.scale0 * u;
-                else p.rider.out[c - 1] = (float)u;
+                else if (c - 1 < p.rider.nout) p.rider.out[c - 1] = (float)u;
             }
             __syncthreads();   // (the stages below reuse the LDS)
         }
@@ -1339,7 +1339,7 @@ extern "C" int favae_debug_kc_blocks(unsigned long long* out16384) {
 
 extern "C" int favae_bn_dbias_ride(const double* partial, int nslab, int C, float* dbias) {
     FAVAE_CHECK_ARG(partial && dbias && nslab >= 1 && nslab <= 256 && C >= 1 && C <= 2048, "favae_bn_dbias_ride: bad argument");
-    favae_slab_rider() = SlabRider{partial, dbias, nslab, C, nullptr, 0.0, 0.0};
+    favae_slab_rider() = SlabRider{partial, dbias, nslab, C, nullptr, 0.0, 0.0, C};
     return FAVAE_OK;
 }
 
@@ -1349,7 +1349,7 @@ extern "C" int favae_conv_out_ll_ride(const double* partial, int Nb, int H, int 
     FAVAE_CHECK_ARG(blocks <= 65536, "favae_conv_out_ll_ride: %lld blocks", blocks);
     const double D = (double)H * W * Cout;
     favae_slab_rider() = SlabRider{partial, dbias, (int)blocks, 5, rec_err, 0.5 * (D * log(2.0 * M_PI) + D * log((double)var_x)),
-                                   0.5 / ((double)var_x * Nb)};
+                                   0.5 / ((double)var_x * Nb), Cout};
     return FAVAE_OK;
 }
 

@@ -12,6 +12,8 @@ struct ThinRed { double* bins; int nbin; const void* act; const float *raw, *mea
 int thin_in_launch(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cs, int Ho, int Wo,
                    int Co, int stride, int scatter, int dtype, int out_bf16, const ThinRed& red, hipStream_t st);
 
+void thin_in_release_stream(hipStream_t st);   // st is going away: free its slot of re-laid-out weights
+
 // Gather of the 3x3 neighbourhood of a <= 3-channel NHWC tensor into rows of 32 values (zero padded), one row per
 // pixel of the (Hq x Wq) grid the caller's reduction runs over.
 //   shifted = 0: dst[pix][tap*Cs + c] = src[n][s*y - 1 + kh][s*x - 1 + kw][c]      (src on the Hn x Wn grid, stride s)

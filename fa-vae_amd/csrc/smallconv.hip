@@ -284,8 +284,12 @@ int g_wk_owners = 0;
 int wk_slot(int dev, hipStream_t st, bool* shared) {
     std::lock_guard<std::mutex> lk(g_wk_mu);
     *shared = false;
-    for (int i = 0; i < g_wk_owners; ++i)
+    int free_slot = -1;
+    for (int i = 0; i < g_wk_owners; ++i) {
         if (g_wk_owner[i].dev == dev && g_wk_owner[i].st == st) return i;
+        if (g_wk_owner[i].dev < 0 && free_slot < 0) free_slot = i;
+    }
+    if (free_slot >= 0) { g_wk_owner[free_slot] = WkOwner{dev, st}; return free_slot; }
     if (g_wk_owners < WK_SLOTS - 1) {
         g_wk_owner[g_wk_owners] = WkOwner{dev, st};
         return g_wk_owners++;
@@ -294,6 +298,16 @@ int wk_slot(int dev, hipStream_t st, bool* shared) {
     return WK_SLOTS - 1;
 }
 }  // namespace
+
+// The stream is about to be destroyed (its work has completed): its slot may serve another stream.  Without this a process that
+// creates executors over and over ran out of slots, and every further launch of the kernel synchronised the device.
+void thin_in_release_stream(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_wk_mu);
+    for (int i = 0; i < g_wk_owners; ++i)
+        if (g_wk_owner[i].dev == dev && g_wk_owner[i].st == st) g_wk_owner[i] = WkOwner{-1, nullptr};
+}
 
 int thin_in_launch(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cs, int Ho, int Wo,
                    int Co, int stride, int scatter, int dtype, int out_bf16, const ThinRed& red, hipStream_t st) {
@@ -496,32 +510,50 @@ namespace {
 template <int CS>
 __global__ __launch_bounds__(256) void fold_taps_hl(const float* __restrict__ src, bf16_t* __restrict__ dst, int Hq, int Wq, int Hn, int Wn,
                                                     int stride, int total) {
+    // a thread gathers the 27 values of its pixel; the rows leave through LDS so that every store instruction of a wave writes 1 KB of
+    // consecutive bytes (a thread storing its own 64-byte row in 16-byte pieces writes every line four times: 10.1 -> 4 us)
+    __shared__ __attribute__((aligned(16))) bf16_t sh[2][256 * 32];
     const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= total) return;
-    const int n = pix / (Hq * Wq), rem = pix - n * Hq * Wq, y = rem / Wq, x = rem - y * Wq;
     bf16_t hi[32], lo[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) hi[i] = lo[i] = (bf16_t)0;
+    if (pix < total) {
+        const int n = pix / (Hq * Wq), rem = pix - n * Hq * Wq, y = rem / Wq, x = rem - y * Wq;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int sy = y * stride - 1 + kh, sx = x * stride - 1 + kw;
-            if (sy < 0 || sy >= Hn || sx < 0 || sx >= Wn) continue;
-            const float* s = src + ((size_t)(n * Hn + sy) * Wn + sx) * CS;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int sy = y * stride - 1 + kh, sx = x * stride - 1 + kw;
+                if (sy < 0 || sy >= Hn || sx < 0 || sx >= Wn) continue;
+                const float* s = src + ((size_t)(n * Hn + sy) * Wn + sx) * CS;
 #pragma unroll
-            for (int c = 0; c < CS; ++c) {
-                const float f = s[c];
-                const bf16_t h = f32_to_bf16(f);
-                hi[(kh * 3 + kw) * CS + c] = h;
-                lo[(kh * 3 + kw) * CS + c] = f32_to_bf16(f - bf16_to_f32(h));
+                for (int c = 0; c < CS; ++c) {
+                    const float f = s[c];
+                    const bf16_t h = f32_to_bf16(f);
+                    hi[(kh * 3 + kw) * CS + c] = h;
+                    lo[(kh * 3 + kw) * CS + c] = f32_to_bf16(f - bf16_to_f32(h));
+                }
             }
-        }
-    uint4* oh = (uint4*)(dst + (size_t)pix * 32);
-    uint4* ol = (uint4*)(dst + ((size_t)total + pix) * 32);
+    }
+    // the 16-byte pieces of an LDS row are rotated by (row / 4) so that the 64 lanes of a wave, each writing piece i of its own
+    // 64-byte row, spread evenly over the 16 bank groups (4 lanes each: the minimum)
+    const int t = threadIdx.x;
     const uint4 *vh = (const uint4*)hi, *vl = (const uint4*)lo;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { oh[i] = vh[i]; ol[i] = vl[i]; }
+    for (int i = 0; i < 4; ++i) {
+        *(uint4*)(sh[0] + t * 32 + ((i + (t >> 2)) & 3) * 8) = vh[i];
+        *(uint4*)(sh[1] + t * 32 + ((i + (t >> 2)) & 3) * 8) = vl[i];
+    }
+    __syncthreads();
+    const int p0 = blockIdx.x * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = i * 256 + t, row = v >> 2, piece = v & 3;   // 16-byte piece v of the block's 16 KB plane slice
+        if (p0 + row < total) {
+            *(uint4*)(dst + (size_t)(p0 + row) * 32 + piece * 8) = *(const uint4*)(sh[0] + row * 32 + ((piece + (row >> 2)) & 3) * 8);
+            *(uint4*)(dst + ((size_t)total + p0 + row) * 32 + piece * 8) = *(const uint4*)(sh[1] + row * 32 + ((piece + (row >> 2)) & 3) * 8);
+        }
+    }
 }
 }  // namespace
 

@@ -106,7 +106,11 @@ struct Worker {
             std::function<int()>& f = q[h % CAP];
             if (rc.load(std::memory_order_relaxed) == 0) {   // after a failure the remaining jobs are dropped
                 const double t0 = now();
-                const int r = f();
+                // FAVAE_DEBUG_FAIL_JOB=n (tests only): the n-th job of every worker fails without issuing its calls
+                static const long long fail_at = getenv("FAVAE_DEBUG_FAIL_JOB") ? atoll(getenv("FAVAE_DEBUG_FAIL_JOB")) : -1;
+                int r;
+                if (fail_at >= 0 && jobs == fail_at) { favae_set_error("favae: injected failure of worker job %lld", jobs); r = FAVAE_ERR_HIP; }
+                else r = f();
                 busy += now() - t0; ++jobs;
                 if (r != FAVAE_OK) { strncpy(err, favae_last_error(), sizeof(err) - 1); rc.store(r, std::memory_order_release); }
             }
@@ -177,6 +181,7 @@ struct Vae {
     Ada ada;
     int pending;   // layer whose optimiser step waits for the next fork event (-1: none); touched by side-stream jobs only
     Worker* wk;    // non-null while an epoch hands its side-stream calls to the enqueue worker
+    hipStream_t probed_main;   // the caller's stream the probe of ensure_streams ran against
     unsigned beside;    // ensure_streams: pairs of streams measured to run on hardware queues of their own (bits: see there)
     int stream_score;   // ensure_streams: 21 = all three side streams run beside the main stream and each other
     bool join_pending; bool dg_all;
@@ -216,6 +221,7 @@ struct Vae {
     float* ab[NL]; bool act_deferred[NL]; bool bn_published[NL]; bool fi_on; int fi_pend[NL], fi_npend, fi_flushes; hipEvent_t ev_fi[2], ev_acts; bool acts_wait;
     // Dependency points between the streams (see sp_record / sp_wait): in threaded single-device epochs they are 32-bit words in
     // device memory written / awaited by stream memory operations with the step number as value, otherwise the events above.
+    unsigned* host_words;   // pinned host memory the device can read: [0] abort (set by the host to end every pending wait), [1] a wait gave up
     unsigned* flags; unsigned step_no, join_seq; bool vals; int vals_ok;   // vals_ok: -1 not probed, 0 unsupported, 1 usable
     unsigned mark_prev, mark_cur;   // worker queue positions at the start of the previous / this step (bounded run-ahead)
     char* shp(int half) const { return SH + (size_t)half * sh_half; }
@@ -283,11 +289,35 @@ int sp_flush_carry(hipStream_t s) {
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }
+// The wait of values mode: ONE wave that polls the word until it has reached `seq`.  Every such wave reaches an exit: when the word
+// arrives; when the host raises the abort word (pinned host memory: the host needs no queue, no copy engine and no stream to write
+// it, so a failed enqueue can always end the waits it left behind -- a release written by a copy or a kernel may be queued on a
+// hardware queue that one of these waves occupies); or when `max_ticks` have passed, in which case it reports through host_words[1]
+// and the next call on the executor fails instead of the process hanging.  (hipStreamWaitValue32, used until round 3, is a polling
+// wave too, with neither exit.)
+__global__ void wait_word_kernel(const unsigned* word, unsigned seq, unsigned* host_words, unsigned long long max_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    unsigned it = 0;
+    while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++it & 255u) == 0u) {
+            if (__hip_atomic_load(host_words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
+            if (wall_clock64() - t0 > max_ticks) { __hip_atomic_store(host_words + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        }
+    }
+}
+constexpr unsigned long long WAIT_MAX_TICKS = 400000000ULL;   // 4 s of the 100 MHz wall clock: a step is < 1 ms
+
 int sp_wait(Vae& v, int sp, hipStream_t s, unsigned seq) {
     static const int dbg_skip = getenv("FAVAE_DEBUG_SKIP_WAIT") ? atoi(getenv("FAVAE_DEBUG_SKIP_WAIT")) : -1;   // timing experiments only
     if (dbg_skip >= 0 && (sp == dbg_skip || (dbg_skip == 99 && (sp == SP_JOIN || sp == SP_BATCH)))) return FAVAE_OK;
-    if (v.vals) { FAVAE_HIP(hipStreamWaitValue32(s, v.flags + sp, seq, hipStreamWaitValueGte, 0xFFFFFFFFu)); }
-    else { FAVAE_HIP(hipStreamWaitEvent(s, sp_event(v, sp), 0)); }
+    if (v.vals) {
+        hipLaunchKernelGGL(wait_word_kernel, dim3(1), dim3(64), 0, s, (const unsigned*)(v.flags + sp), seq, v.host_words, WAIT_MAX_TICKS);
+        FAVAE_HIP(hipGetLastError());
+    } else {
+        FAVAE_HIP(hipStreamWaitEvent(s, sp_event(v, sp), 0));
+    }
     return FAVAE_OK;
 }
 
@@ -409,16 +439,10 @@ int ensure_streams(Vae& v, hipStream_t main) {
     if (v.side) return FAVAE_OK;
     constexpr int NC = 4, NS = NC + 1;
     hipStream_t s[NS] = {main, nullptr, nullptr, nullptr, nullptr};
-    // FAVAE_SIDE_PRIO=1 (experiment, off by default): side streams at the lowest priority the device offers.  Priorities have
-    // hardware-queue pools of their own, so with ONE executor in the process the four candidates share no queue with the caller's
-    // stream or each other (probe score 21 of 21 where it was 20) and the step is 0.6 % faster; with a second executor (two image
-    // views) the first epoch of the second one never finished on the GPU (event mode, one step per epoch; tests/test_gpu_sshiba.py
-    // variant B).  Not understood, so not used.
-    int prio_lo = 0, prio_hi = 0;
-    const char* pe = getenv("FAVAE_SIDE_PRIO");
-    const bool low = pe && pe[0] == '1' && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_lo != prio_hi;
+    // (Side streams at the lowest stream priority were tried in round 2 and removed in round 3: -0.6 % with one executor, and a
+    // run that never finished with two -- DESIGN.md section 4, "the two hangs".  All streams of an executor share one priority.)
     for (int i = 1; i < NS; ++i)
-        if ((low ? hipStreamCreateWithPriority(&s[i], hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking)) != hipSuccess) {
+        if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) {
             for (int j = 1; j < i; ++j) (void)hipStreamDestroy(s[j]);
             favae_set_error("favae: could not create the side streams");
             return FAVAE_ERR_HIP;
@@ -461,6 +485,7 @@ int ensure_streams(Vae& v, hipStream_t main) {
     for (int i = 1; i < NS; ++i)
         if (i != pick[0] && i != pick[1] && i != pick[2]) (void)hipStreamDestroy(s[i]);
     v.stream_score = best;
+    v.probed_main = main;
     // which pairs run side by side: bit 0 main-side, 1 main-side2, 2 main-side3, 3 side-side2, 4 side-side3, 5 side2-side3
     v.beside = (ok2(0, pick[0]) ? 1u : 0u) | (ok2(0, pick[1]) ? 2u : 0u) | (ok2(0, pick[2]) ? 4u : 0u) | (ok2(pick[0], pick[1]) ? 8u : 0u) |
                (ok2(pick[0], pick[2]) ? 16u : 0u) | (ok2(pick[1], pick[2]) ? 32u : 0u);
@@ -935,7 +960,15 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
         favae_set_error("favae_vae_create: workspace %zu < %zu or shadow %zu < %zu", workspace_bytes, need, shadow_bytes, 2 * v.sh_half);
         return FAVAE_ERR_ARG;
     }
+    v.host_words = nullptr;
+    if (hipHostMalloc((void**)&v.host_words, 2 * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && v.host_words) {
+        v.host_words[0] = v.host_words[1] = 0u;
+    } else {
+        (void)hipGetLastError();
+        v.host_words = nullptr;   // no stream words then: events
+    }
     if (hipMemset(v.flags, 0, (SP_COUNT + 1) * sizeof(unsigned)) != hipSuccess) {
+        if (v.host_words) (void)hipHostFree(v.host_words);
         delete h;
         favae_set_error("favae_vae_create: could not clear the dependency words");
         return FAVAE_ERR_HIP;
@@ -1009,13 +1042,15 @@ extern "C" int favae_vae_destroy(favae_vae* h) {
     if (!h) return FAVAE_OK;
     Vae& v = h->v;
     favae_slab_rider().partial = nullptr;   // (may point into this executor's workspace)
+    favae_flag_carry().n = 0;
     auto kill = [](hipEvent_t& e) { if (e) { (void)hipEventDestroy(e); e = nullptr; } };   // handles are value-initialised to null
     if (v.ev_fence_ok) { kill(v.ev_fence[0]); kill(v.ev_fence[1]); }
     for (hipStream_t q : {v.side, v.side2, v.side3})
-        if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+        if (q) { (void)hipStreamSynchronize(q); thin_in_release_stream(q); (void)hipStreamDestroy(q); }
     kill(v.ev_comm); kill(v.ev_x); kill(v.ev_batch); kill(v.ev_fold); kill(v.ev_fi[0]); kill(v.ev_fi[1]); kill(v.ev_acts);
     for (int l = 0; l < NL; ++l) { kill(v.ev_fork[l]); kill(v.ev_dg[l]); kill(v.ev_wg[l]); }
     kill(v.ev_join); kill(v.ev_join2);
+    if (v.host_words) (void)hipHostFree(v.host_words);
     delete h;
     return FAVAE_OK;
 }
@@ -1061,6 +1096,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
     if (v.overlap) RC(ensure_streams(v, (hipStream_t)st));
     favae_slab_rider().partial = nullptr;   // (a rider that an aborted call on this thread left behind must not reach another launch)
     if (stage_lo == 0) {
+        favae_flag_carry().n = 0;           // (the same for dependency words: they may point into a workspace that is gone)
         const bool can_fold = v.overlap && (v.fuse & 64u) && !(v.fuse & 0x200u) && v.ch <= 3;
         // Single-device epochs: encoder.0's weight gradient and update, the last links of a step, stay on the caller's
         // stream (no event hop on that chain); what used to hide under them -- the zero-pool memset, the batch gather and
@@ -1381,7 +1417,9 @@ int epoch_worker_start(Vae& v, long long nsteps, hipStream_t st, unsigned need_b
         // A wait may be queued before the write it waits for, so the streams of this epoch must sit on hardware queues of their own:
         // a polling wait ahead of its writer in ONE queue would never end.  The probe of ensure_streams has measured exactly that,
         // pair by pair; if a pair this epoch uses shares a queue, the events stay.
-        v.vals = v.vals_ok == 1 && (v.beside & need_beside) == need_beside;
+        // ... and `beside` was measured against the caller's stream of the FIRST training step: a caller that comes back on
+        // another stream (another hardware queue, possibly one of the side streams') gets events.
+        v.vals = v.vals_ok == 1 && v.host_words && (v.beside & need_beside) == need_beside && st == v.probed_main;
         if (getenv("FAVAE_VERBOSE") && v.vals_ok == 1 && !v.vals)
             fprintf(stderr, "favae: stream words not used: streams of this epoch share a hardware queue (pairs 0x%x of 0x%x)\n", v.beside & need_beside, need_beside);
         v.mark_prev = v.mark_cur = wk->mark();
@@ -1402,14 +1440,37 @@ int epoch_worker_stop(Vae& v, long long nsteps) {
     return wrc;
 }
 // a failed step may have left waits whose writes were never issued: satisfy every point, let the queues run dry, start over
+// The release must not be ordered behind any stream of the executor, nor need a hardware queue at all: every stream may hold a
+// wait that will never be satisfied (in data-parallel epochs side3 is the communication stream and waits on SP_FENCE_*; the
+// caller's stream waits on SP_BATCH / SP_FOLD / SP_JOIN), a polling wave occupies its hardware queue, and the process has four of
+// them: a memset on side3 (round 2) and a small copy on a fresh stream (first try of round 3: small copies are blit KERNELS) both
+// ended behind such a wave -- tools/fail_inject.py hung in the hipDeviceSynchronize below.  So the host raises the abort word in
+// pinned host memory, which every wait polls (wait_word_kernel), and only then synchronises.
 void epoch_values_end(Vae& v, int rc) {
-    if (v.vals && rc != FAVAE_OK) {
-        (void)hipMemsetD32Async((hipDeviceptr_t)v.flags, 0x7FFFFFFF, SP_COUNT, v.side3);
+    favae_flag_carry().n = 0;   // words of an aborted step must not ride with a later launch of this thread
+    if (v.vals && rc != FAVAE_OK && v.host_words) {
+        __atomic_store_n(&v.host_words[0], 1u, __ATOMIC_SEQ_CST);
         (void)hipDeviceSynchronize();
+        __atomic_store_n(&v.host_words[0], 0u, __ATOMIC_SEQ_CST);
         (void)hipMemset(v.flags, 0, SP_COUNT * sizeof(unsigned));
+        (void)hipGetLastError();
         v.step_no = 0;
     }
     v.vals = false;
+}
+// a wait of an earlier call gave up (WAIT_MAX_TICKS): what ran behind it ran out of order.  Reported once; events from then on.
+int check_wait_timeout(Vae& v) {
+    if (v.host_words && __atomic_load_n(&v.host_words[1], __ATOMIC_SEQ_CST) != 0u) {
+        (void)hipDeviceSynchronize();
+        __atomic_store_n(&v.host_words[1], 0u, __ATOMIC_SEQ_CST);
+        (void)hipMemset(v.flags, 0, SP_COUNT * sizeof(unsigned));
+        v.step_no = 0;
+        v.vals_ok = 0;
+        favae_set_error("favae: a stream-word wait of a training epoch timed out (its writer never ran: streams sharing a hardware queue?); "
+                        "the epoch's results are invalid; later epochs use events");
+        return FAVAE_ERR_HIP;
+    }
+    return FAVAE_OK;
 }
 }  // namespace
 
@@ -1421,6 +1482,7 @@ extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const
     FAVAE_CHECK_ARG(h && perm && metrics && n >= 1 && batch >= 1, "favae_vae_train_epoch: bad argument");
     Vae& v = h->v;
     long long s = 0;
+    RC(check_wait_timeout(v));
     if (v.overlap) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));   // the steps keep it cleared
     RC(epoch_worker_start(v, (n + batch - 1) / batch, (hipStream_t)st, 1u | 2u | 8u));   // main, weight-gradient and optimiser stream
     int rc = FAVAE_OK;
@@ -1462,6 +1524,7 @@ extern "C" int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float
     FAVAE_CHECK_ARG(h && c && perm && metrics && n >= 1 && batch >= 1, "favae_vae_train_epoch_dp: bad argument");
     Vae& v = h->v;
     FAVAE_CHECK_ARG(v.overlap, "favae_vae_train_epoch_dp needs the weight-gradient stream (FAVAE_SINGLE_STREAM is set)");
+    RC(check_wait_timeout(v));
     RC(ensure_streams(v, (hipStream_t)st));
     hipStream_t cs = v.side3;          // collectives + the bucket-wise optimiser step behind them
     hipEvent_t done = v.ev_comm;
@@ -1542,6 +1605,13 @@ extern "C" int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float
     v.ev_join_ext = nullptr;
     epoch_values_end(v, rc);
     return rc;
+}
+
+/* Non-zero (with favae_last_error set) if a dependency wait of an earlier epoch on this executor gave up; call after the epoch's
+ * results have been synchronised (the host mirror calls it when it reads the epoch metrics). */
+extern "C" int favae_vae_poll_error(favae_vae* h) {
+    FAVAE_CHECK_ARG(h, "favae_vae_poll_error: null handle");
+    return check_wait_timeout(h->v);
 }
 
 /* Encoder over B samples (update_x, :331-358 when train=0; the encoder half of forward() when train=1):

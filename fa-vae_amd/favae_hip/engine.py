@@ -278,6 +278,10 @@ class VaeEngine:
                                               L.stream_ptr()))
         self.step += (n + batch - 1) // batch
 
+    def poll_error(self):
+        """Raise if a dependency wait of an earlier epoch gave up (favae_vae_poll_error); call after a synchronisation."""
+        L.check(_raw.favae_vae_poll_error(self.h))
+
     def encode(self, data, idx, B, xmean, xcov, train=False):
         self._fmt(data)
         L.check(_raw.favae_vae_encode(self.h, L.ptr(data), L.ptr(idx), _i(B), ctypes.c_void_p(xmean.data_ptr()),

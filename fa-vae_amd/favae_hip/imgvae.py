@@ -334,6 +334,7 @@ class ImgVAE(VAE):
                 dist.mean_(metrics)
                 dist.mean_(e.BUF)
             m = metrics.cpu().numpy()
+            e.poll_error()
             rec, kl = m[:, 0], m[:, 1]
             loss = rec + beta * kl
             self.loss_during_training.append(np.float64(loss.sum() / nb))

@@ -360,6 +360,10 @@ int favae_vae_train_stages(favae_vae* h, const float* data_nhwc, const int* idx,
 /* Orders stream `waiting` behind everything queued so far on `stream` and on the handle's weight-gradient stream (the
  * gradients of the stages issued so far are complete for work enqueued on `waiting` afterwards).  Blocks nothing. */
 int favae_vae_fence(favae_vae* h, void* stream, void* waiting);
+/* No reference counterpart (error plumbing of the threaded epochs): a stream-word wait that never got its write gives up after
+ * ~4 s instead of hanging the process and leaves a mark; this returns FAVAE_ERR_HIP once if there is one (the results of that
+ * epoch are invalid), 0 otherwise.  Call it after the epoch's outputs have been synchronised. */
+int favae_vae_poll_error(favae_vae* h);
 
 /* ---- data-parallel epoch over RCCL (xGMI) ---------------------------------------------------------------------- */
 /* No reference counterpart (the reference is single-device).  One process per GPU; rank 0 calls favae_comm_unique_id, the

@@ -415,6 +415,22 @@ def test_data_parallel_epoch_over_rccl_one_rank():
     assert len(diffs) == 2 and max(diffs) < 1e-3, out.stdout[-2000:]
 
 
+@pytest.mark.parametrize("mode", ["single", "dp"])
+def test_failed_worker_job_returns_an_error_instead_of_hanging(mode):
+    """A job of the enqueue worker fails in the middle of a threaded epoch (FAVAE_DEBUG_FAIL_JOB, tools/fail_inject.py): the
+    stream-word waits of that step never get their writes.  The epoch call must return the error -- the words are released by
+    a copy that is ordered behind none of the executor's streams (csrc/vae_model.hip, epoch_values_end) -- and the executor
+    must run a later epoch.  Own process: the hook is read once per process; 'dp' is the one-rank RCCL rehearsal, where the
+    communication stream holds the waits on the bucket fences."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT="29549")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fail_inject.py"), mode], env=env, capture_output=True, text=True,
+                         timeout=100)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "epoch returned an error" in out.stdout and "recovered" in out.stdout, out.stdout[-1500:]
+
+
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("bf16", 1e-2)])   # bf16 measured: mu 2.9e-3, var 3e-4, decoder 2.5e-4
 def test_eval_encoder_and_decoder_match_oracle(dtype, tol):
     z, Bn = 8, 24
