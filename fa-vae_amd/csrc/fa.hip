@@ -290,6 +290,238 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Batched SPD inverse: ONE launch, one 16-wave workgroup per matrix, the matrix resident in LDS as a packed lower triangle
+// (K (K + 1) / 2 doubles: K <= 201 fits the 160 KB of a CU), every O(K^3) part on v_mfma_f64_16x16x4_f64 over 16 x 16 tiles:
+//   A'  = (s s^T) o (sum_t coef_t A_t) + diag_add I            the combination of update_Z (:970-980) is formed while loading
+//   L   = chol(A')        right-looking, panels of 16 columns: diagonal block by one wave (wave-synchronous, no block barrier),
+//                         panel solve one row per lane, trailing update as MFMA tiles          3 barriers per panel
+//   X   = L^-1            block columns right to left: diagonal block by one wave, T = L21 X_pp one row per lane,
+//                         X21 = -X22 T as MFMA tile rows held in registers across the barrier  (in place, no second buffer)
+//   out = out_scale (s s^T) o (X^T X), log det A', log det out; a pivot <= 0 gives NaN and info = 1 (myInverse :917-922)
+// Nothing is read back: the caller looks at info[] when it needs to (once per iteration).  myInverse (:904-922), the W
+// covariance (:1062-1065) and the M + 1 (variant A: 2M + 1) inverses of update_Z (:970-980) of one iteration are two launches.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int CB_MAXB = 12, CB_MAXT = 8, CB_THREADS = 1024, CB_KMAX_LDS = 201;
+struct CholOne {
+    const double* a[CB_MAXT]; double coef[CB_MAXT]; int nterm;
+    const double* s; double s_mul; int s_sqrt;   // s_i = s ? (s_sqrt ? sqrt(s[i] * s_mul) : s[i]) : 1
+    double diag_add, out_scale;
+    double* out;
+};
+struct CholBatchArgs { CholOne m[CB_MAXB]; int nb, K, lda, ldo; double* logdet; int* info; };
+
+__device__ __forceinline__ int pk(int i, int j) { return ((i * (i + 1)) >> 1) + j; }   // j <= i
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(CB_THREADS) void chol_inv_batched_kernel(const CholBatchArgs args_by_value) {
+    // (the per-matrix record is picked by blockIdx: read it through the kernel-argument segment, a by-value struct indexed at run
+    // time would be copied to scratch memory first)
+    typedef const __attribute__((address_space(4))) CholBatchArgs* KArgs;
+    KArgs ap = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)args_by_value;
+    const int b = blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int& bad = *(int*)smem;
+    double* W = smem + 2;
+    const int K = ap->K, lda = ap->lda, ldo = ap->ldo;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = CB_THREADS / 64, lr = lane >> 4, lc = lane & 15;
+    const int nt = (K + 15) >> 4;
+    const double* sp = ap->m[b].s;
+    const double s_mul = ap->m[b].s_mul, diag_add = ap->m[b].diag_add, out_scale = ap->m[b].out_scale;
+    const int s_sqrt = ap->m[b].s_sqrt, nterm = ap->m[b].nterm;
+    double* const outp = ap->m[b].out;
+    double* const logdet = ap->logdet;
+    int* const info = ap->info;
+    auto sval = [&](int i) -> double { return sp ? (s_sqrt ? sqrt(sp[i] * s_mul) : sp[i]) : 1.0; };
+    if (tid == 0) bad = 0;
+    for (int e = tid; e < K * K; e += CB_THREADS) {
+        const int i = e / K, j = e - i * K;
+        if (j > i) continue;
+        double v = 0.0;
+        for (int t = 0; t < nterm; ++t) v += ap->m[b].coef[t] * ap->m[b].a[t][(size_t)i * lda + j];
+        W[pk(i, j)] = sval(i) * sval(j) * v + (i == j ? diag_add : 0.0);
+    }
+    __syncthreads();
+    // ---- Cholesky -------------------------------------------------------------------------------------------
+    for (int p = 0; p < nt; ++p) {
+        const int j0 = p << 4, w = min(16, K - j0);
+        if (wave == 0) {
+            for (int jj = 0; jj < w; ++jj) {
+                const int j = j0 + jj;
+                const double piv = W[pk(j, j)];
+                if (!(piv > 0.0)) { if (lane == 0) bad = 1; break; }   // wave-uniform
+                const double d = sqrt(piv);
+                if (lane < w - jj) { const int r = j + lane; W[pk(r, j)] = lane == 0 ? d : W[pk(r, j)] / d; }
+                wave_sync_lds();
+#pragma unroll
+                for (int e0 = 0; e0 < 256; e0 += 64) {
+                    const int e = e0 + lane, r = j0 + (e >> 4), c = j0 + (e & 15);
+                    if (c > j && c <= r && r < j0 + w) W[pk(r, c)] -= W[pk(r, j)] * W[pk(c, j)];
+                }
+                wave_sync_lds();
+            }
+        }
+        __syncthreads();
+        if (bad) break;
+        {   // panel solve: row i of the panel times the inverse transpose of the diagonal block, one row per lane
+            const int i = j0 + w + tid;
+            if (i < K) {
+                double a[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) a[c] = c < w ? W[pk(i, j0 + c)] : 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    if (c < w) {
+                        a[c] /= W[pk(j0 + c, j0 + c)];
+#pragma unroll
+                        for (int q = c + 1; q < 16; ++q)
+                            if (q < w) a[q] -= a[c] * W[pk(j0 + q, j0 + c)];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c < w) W[pk(i, j0 + c)] = a[c];
+            }
+        }
+        __syncthreads();
+        {   // trailing update: tile (I, J) -= L[I, panel] L[J, panel]^T, p < J <= I
+            int t = 0;
+            for (int I = p + 1; I < nt; ++I)
+                for (int J = p + 1; J <= I; ++J, ++t) {
+                    if (t % nw != wave) continue;
+                    f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+                    const int ra = (I << 4) + lc, rb = (J << 4) + lc;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int col = j0 + 4 * q + lr;
+                        const bool ck = col < j0 + w;
+                        const double av = (ck && ra < K) ? W[pk(ra, col)] : 0.0;
+                        const double bv = (ck && rb < K) ? W[pk(rb, col)] : 0.0;
+                        acc = mfma_f64(av, bv, acc);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int r = (I << 4) + lr + 4 * g, c = (J << 4) + lc;
+                        if (r < K && c <= r) W[pk(r, c)] -= acc[g];
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    if (bad) {
+        const double nan = __longlong_as_double(0x7ff8000000000000LL);
+        for (int e = tid; e < K * K; e += CB_THREADS) outp[(size_t)(e / K) * ldo + (e % K)] = nan;
+        if (tid == 0) { info[b] = 1; logdet[2 * b] = nan; logdet[2 * b + 1] = nan; }
+        return;
+    }
+    if (wave == nw - 1) {   // log-determinants from the factor's diagonal (one wave, fixed order), beside the first inverse panel
+        double ld = 0.0, ls = 0.0;
+        for (int j = lane; j < K; j += 64) { ld += log(W[pk(j, j)]); if (sp) ls += log(sval(j)); }
+        ld = wave_sum(ld); ls = wave_sum(ls);
+        if (lane == 0) {
+            logdet[2 * b] = 2.0 * ld;
+            logdet[2 * b + 1] = K * log(out_scale) + 2.0 * ls - 2.0 * ld;
+            info[b] = 0;
+        }
+    }
+    __syncthreads();   // (the diagonal is overwritten below)
+    // ---- X = L^-1, block columns right to left ------------------------------------------------------------------
+    for (int p = nt - 1; p >= 0; --p) {
+        const int j0 = p << 4, w = min(16, K - j0);
+        if (wave == 0) {   // diagonal block: columns right to left; a column is read whole before its entries are replaced
+            for (int jj = w - 1; jj >= 0; --jj) {
+                const int j = j0 + jj, i = j + 1 + lane;
+                const double ljj = W[pk(j, j)];
+                double acc = 0.0;
+                if (lane < w - 1 - jj)
+                    for (int k = j + 1; k <= i; ++k) acc += W[pk(i, k)] * W[pk(k, j)];
+                wave_sync_lds();
+                if (lane < w - 1 - jj) W[pk(i, j)] = -acc / ljj;
+                if (lane == 0) W[pk(j, j)] = 1.0 / ljj;
+                wave_sync_lds();
+            }
+        }
+        __syncthreads();
+        {   // T = L21 X_pp, one row per lane, in place
+            const int i = j0 + w + tid;
+            if (i < K) {
+                double a[16], tt[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) a[c] = c < w ? W[pk(i, j0 + c)] : 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int q = c; q < 16; ++q)
+                        if (q < w && c < w) acc += a[q] * W[pk(j0 + q, j0 + c)];
+                    tt[c] = acc;
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c < w) W[pk(i, j0 + c)] = tt[c];
+            }
+        }
+        __syncthreads();
+        // X[I, p] = -sum_{p < J <= I} X[I, J] T[J]: one tile row per wave, kept in registers until every wave has read T
+        f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+        const int I = p + 1 + wave;
+        if (I < nt) {
+            for (int J = p + 1; J <= I; ++J) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ra = (I << 4) + lc, ca = (J << 4) + 4 * q + lr;     // X22[I][J]: row lc, k = lr
+                    const double av = (ra < K && ca <= ra) ? W[pk(ra, ca)] : 0.0;
+                    const int rb = (J << 4) + 4 * q + lr;                           // T[J]: k = lr, column lc of the panel
+                    const double bv = (rb < K && lc < w) ? W[pk(rb, j0 + lc)] : 0.0;
+                    acc = mfma_f64(av, bv, acc);
+                }
+            }
+        }
+        __syncthreads();
+        if (I < nt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = (I << 4) + lr + 4 * g;
+                if (r < K && lc < w) W[pk(r, j0 + lc)] = -acc[g];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- out = out_scale (s s^T) o (X^T X) ----------------------------------------------------------------------
+    {
+        int t = 0;
+        for (int I = 0; I < nt; ++I)
+            for (int J = 0; J <= I; ++J, ++t) {
+                if (t % nw != wave) continue;
+                f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+                for (int Kt = I; Kt < nt; ++Kt) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = (Kt << 4) + 4 * q + lr, ca = (I << 4) + lc, cb = (J << 4) + lc;
+                        const double av = (r < K && ca <= r) ? W[pk(r, ca)] : 0.0;   // A[m = lc][k = lr] = X[r][I*16 + m]
+                        const double bv = (r < K && cb <= r) ? W[pk(r, cb)] : 0.0;   // B[k = lr][n = lc] = X[r][J*16 + n]
+                        acc = mfma_f64(av, bv, acc);
+                    }
+                }
+                const int j = (J << 4) + lc;
+                const double sj = j < K ? sval(j) : 0.0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int i = (I << 4) + lr + 4 * g;
+                    if (i < K && j < K && j <= i) {
+                        const double v = out_scale * sval(i) * sj * acc[g];
+                        outp[(size_t)i * ldo + j] = v;
+                        outp[(size_t)j * ldo + i] = v;
+                    }
+                }
+            }
+    }
+}
+
 // LU with partial pivoting: sign and log|det| of a general K x K matrix (np.linalg.slogdet)
 __global__ __launch_bounds__(256) void slogdet_kernel(const double* __restrict__ A, int lda, int K, double* __restrict__ gwork,
                                                       int use_lds, double* __restrict__ out2) {
@@ -358,7 +590,9 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(int ta, int tb, int M, 
 __global__ __launch_bounds__(256) void w_update_kernel(const double* __restrict__ xtz1, const double* __restrict__ zsum,
                                                        const double* __restrict__ b, const double* __restrict__ wcov, double tau, int d,
                                                        int K, double* __restrict__ wmean, double* __restrict__ wprodT,
-                                                       double* __restrict__ tmp) {
+                                                       double* __restrict__ tmp, const int* __restrict__ info, double* __restrict__ wcov_out) {
+    // info != NULL: the flag of the inverse that produced wcov (favae_chol_inv_batched); not SPD -> "not updated" (:1073-1075)
+    if (info && *info != 0) return;   // uniform
     // tmp[d][K] = XtZ - b^T colsumZ
     for (int e = threadIdx.x; e < d * K; e += 256) {
         const int i = e / K, k = e - i * K;
@@ -377,6 +611,7 @@ __global__ __launch_bounds__(256) void w_update_kernel(const double* __restrict_
         double acc = 0.0;
         for (int i = 0; i < d; ++i) acc += wmean[(size_t)i * K + k] * wmean[(size_t)i * K + l];
         wprodT[e] = acc + d * wcov[e];
+        if (wcov_out) wcov_out[e] = wcov[e];
     }
 }
 
@@ -406,8 +641,15 @@ __global__ __launch_bounds__(256) void tau_update_kernel(const double* __restric
                                                          const double* __restrict__ xtz1, double trxx, const double* __restrict__ zprodT,
                                                          const double* __restrict__ wprodT, const double* __restrict__ wmean,
                                                          const double* __restrict__ bmean, double bprodT, double a0, double b0, double N,
-                                                         int d, int K, double* __restrict__ scal) {
+                                                         int d, int K, double* __restrict__ scal, const double* __restrict__ bprodT_dev,
+                                                         const double* __restrict__ xtx1_dev, const double* __restrict__ covsum_dev) {
     __shared__ double sm[4];
+    if (bprodT_dev) bprodT = *bprodT_dev;   // <b b^T> as favae_fa_b_update left it on the device
+    if (xtx1_dev) {                         // tr<X^T X> from X^T [X | 1] (d x (d + 1)) and the column sums of X.cov, in a fixed order
+        trxx = 0.0;
+        for (int i = 0; i < d; ++i) trxx += xtx1_dev[(size_t)i * (d + 1) + i];
+        if (covsum_dev) for (int i = 0; i < d; ++i) trxx += covsum_dev[i];
+    }
     double acc = 0.0;
     for (int e = threadIdx.x; e < K * K; e += 256) acc += wprodT[e] * zprodT[(size_t)(e % K) * K + e / K];       // tr(WW ZZ)
     for (int e = threadIdx.x; e < d * K; e += 256) {
@@ -636,18 +878,96 @@ extern "C" int favae_fa_xi_init(const double* mean, const double* cov, double* x
     return FAVAE_OK;
 }
 
-/* Synchronous: returns FAVAE_NOT_SPD (and fills out with NaN) when a pivot is not positive. */
+// combination kernel of the global-memory fallback (K > 201): aux = sum_t coef_t A_t
+__global__ void chol_comb_kernel(CholOne m, int K, int lda, double* __restrict__ aux) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < K * K; e += gridDim.x * 256) {
+        const int i = e / K, j = e - i * K;
+        double v = 0.0;
+#pragma unroll
+        for (int t = 0; t < CB_MAXT; ++t)
+            if (t < m.nterm) v += m.coef[t] * m.a[t][(size_t)i * lda + j];
+        aux[e] = v;
+    }
+}
+__global__ void chol_svec_kernel(const double* __restrict__ s, double s_mul, int K, double* __restrict__ out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < K) out[i] = sqrt(s[i] * s_mul);
+}
+
+/* nb <= 12 SPD inverses of size K in one launch (see chol_inv_batched_kernel).  Matrix b:
+ *   A'_b = (s_b s_b^T) o (sum_{t < nterm[b]} coef[b*8 + t] * A[b*8 + t]) + diag_add[b] I,   out[b] = out_scale[b] (s_b s_b^T) o A'_b^-1
+ * with s_b = NULL (ones), s[b] as given (s_sqrt[b] = 0) or sqrt(s[b][i] * s_mul[b]) (s_sqrt[b] = 1: 1 / sqrt(alpha.mean) from alpha.b).
+ * logdet2 [nb][2] = (log det A'_b, log det out[b]); info [nb] = 0 / 1 (not SPD: out[b] and its log-determinants are NaN).
+ * Asynchronous: nothing is read back.  K <= 201: LDS-resident; larger K (up to 1024) runs matrix by matrix through `work`
+ * (>= 2 K^2 + 2 K doubles) in global memory. */
+extern "C" int favae_chol_inv_batched(int nb, const double* const* A, const double* coef, const int* nterm, int lda, int K,
+                                      const double* const* s, const double* s_mul, const int* s_sqrt, const double* diag_add,
+                                      const double* out_scale, double* const* out, int ldo, double* logdet2, int* info_dev,
+                                      double* work, size_t work_doubles, void* stream) {
+    FAVAE_CHECK_ARG(nb >= 1 && nb <= CB_MAXB && A && coef && nterm && diag_add && out_scale && out && logdet2 && info_dev,
+                    "favae_chol_inv_batched: bad argument (1..%d matrices)", CB_MAXB);
+    FAVAE_CHECK_ARG(K > 0 && K <= 1024 && lda >= K && ldo >= K, "favae_chol_inv_batched: K = %d, lda = %d, ldo = %d", K, lda, ldo);
+    CholBatchArgs a;
+    a.nb = nb; a.K = K; a.lda = lda; a.ldo = ldo; a.logdet = logdet2; a.info = info_dev;
+    for (int b = 0; b < nb; ++b) {
+        CholOne& m = a.m[b];
+        FAVAE_CHECK_ARG(nterm[b] >= 1 && nterm[b] <= CB_MAXT && out[b], "favae_chol_inv_batched: matrix %d: 1..%d terms, non-null out", b, CB_MAXT);
+        m.nterm = nterm[b];
+        for (int t = 0; t < CB_MAXT; ++t) {
+            m.a[t] = t < nterm[b] ? A[b * CB_MAXT + t] : nullptr;
+            m.coef[t] = t < nterm[b] ? coef[b * CB_MAXT + t] : 0.0;
+            FAVAE_CHECK_ARG(t >= nterm[b] || m.a[t], "favae_chol_inv_batched: matrix %d term %d is null", b, t);
+        }
+        m.s = s ? s[b] : nullptr;
+        m.s_mul = s_mul ? s_mul[b] : 1.0;
+        m.s_sqrt = s_sqrt ? s_sqrt[b] : 0;
+        m.diag_add = diag_add[b];
+        m.out_scale = out_scale[b];
+        m.out = out[b];
+    }
+    for (int b = nb; b < CB_MAXB; ++b) a.m[b] = a.m[0];
+    if (K <= CB_KMAX_LDS) {
+        const size_t lds_bytes = (2 + (size_t)K * (K + 1) / 2) * sizeof(double);
+        if (lds_bytes > 64 * 1024)
+            FAVAE_HIP(hipFuncSetAttribute((const void*)chol_inv_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(chol_inv_batched_kernel, dim3(nb), dim3(CB_THREADS), lds_bytes, ST, a);
+        FAVAE_LAUNCH_CHECK();
+        return FAVAE_OK;
+    }
+    // beyond the LDS: the single-workgroup kernel on a global workspace, one matrix after the other (same stream)
+    const size_t KK = (size_t)K * K;
+    FAVAE_CHECK_ARG(work && work_doubles >= 2 * KK + 2 * (size_t)K, "favae_chol_inv_batched: K = %d needs a workspace of %zu doubles", K, 2 * KK + 2 * (size_t)K);
+    for (int b = 0; b < nb; ++b) {
+        const CholOne& m = a.m[b];
+        const double* src = m.a[0];
+        int ld = lda;
+        if (m.nterm > 1 || m.coef[0] != 1.0) {
+            hipLaunchKernelGGL(chol_comb_kernel, dim3(std::min(64, cdiv(K * K, 256))), dim3(256), 0, ST, m, K, lda, work);
+            src = work; ld = K;
+        }
+        const double* sv = m.s;
+        if (m.s && m.s_sqrt) {
+            hipLaunchKernelGGL(chol_svec_kernel, dim3(cdiv(K, 64)), dim3(64), 0, ST, m.s, m.s_mul, K, work + 2 * KK + K);
+            sv = work + 2 * KK + K;
+        }
+        hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), 16, ST, src, ld, K, sv, m.diag_add, m.out_scale, m.out, ldo, work + KK, 0,
+                           logdet2 + 2 * b, info_dev + b);
+        FAVAE_LAUNCH_CHECK();
+    }
+    return FAVAE_OK;
+}
+
+/* One matrix, synchronous: returns FAVAE_NOT_SPD (and fills out with NaN) when a pivot is not positive. */
 extern "C" int favae_chol_inv(const double* A, int lda, int K, const double* s, double diag_add, double out_scale, double* out,
                               int ldo, double* work, double* logdet2, int* info_dev, void* stream) {
     FAVAE_CHECK_ARG(A && out && work && logdet2 && info_dev && K > 0 && K <= 1024, "favae_chol_inv: bad argument");
-    const size_t full = ((size_t)K * K + K + 2) * sizeof(double);
-    const int use_lds = full <= 150 * 1024;
-    const size_t lds_bytes = use_lds ? full : 16;
-    if (lds_bytes > 64 * 1024)
-        FAVAE_HIP(hipFuncSetAttribute((const void*)chol_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), lds_bytes, ST, A, lda, K, s, diag_add, out_scale, out, ldo, work,
-                       use_lds, logdet2, info_dev);
-    FAVAE_LAUNCH_CHECK();
+    const double* Ap[CB_MAXT] = {A};
+    const double coef[CB_MAXT] = {1.0};
+    const int nterm = 1, s_sqrt = 0;
+    const double s_mul = 1.0;
+    int rc = favae_chol_inv_batched(1, Ap, coef, &nterm, lda, K, s ? &s : nullptr, &s_mul, &s_sqrt, &diag_add, &out_scale, &out, ldo, logdet2,
+                                    info_dev, work, (size_t)2 * K * K + 2 * K, stream);
+    if (rc) return rc;
     int info = 0;
     FAVAE_HIP(hipMemcpyAsync(&info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ST));
     FAVAE_HIP(hipStreamSynchronize(ST));
@@ -676,9 +996,9 @@ extern "C" int favae_small_gemm(int transA, int transB, int M, int N, int Kd, do
 }
 
 extern "C" int favae_fa_w_update(const double* xtz1, const double* zsum, const double* b, const double* wcov, double tau, int d, int K,
-                                 double* wmean, double* wprodT, double* tmp, void* stream) {
+                                 double* wmean, double* wprodT, double* tmp, const int* info, double* wcov_out, void* stream) {
     FAVAE_CHECK_ARG(xtz1 && zsum && b && wcov && wmean && wprodT && tmp && d > 0 && K > 0, "favae_fa_w_update: bad argument");
-    hipLaunchKernelGGL(w_update_kernel, dim3(1), dim3(256), 0, ST, xtz1, zsum, b, wcov, tau, d, K, wmean, wprodT, tmp);
+    hipLaunchKernelGGL(w_update_kernel, dim3(1), dim3(256), 0, ST, xtz1, zsum, b, wcov, tau, d, K, wmean, wprodT, tmp, info, wcov_out);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }
@@ -693,10 +1013,11 @@ extern "C" int favae_fa_b_update(const double* xsum, const double* zsum, const d
 
 extern "C" int favae_fa_tau_update(const double* xsum, const double* zsum, const double* xtz1, double trxx, const double* zprodT,
                                    const double* wprodT, const double* wmean, const double* bmean, double bprodT, double a0, double b0,
-                                   double N, int d, int K, double* scal, void* stream) {
+                                   double N, int d, int K, double* scal, const double* bprodT_dev, const double* xtx1_dev,
+                                   const double* covsum_dev, void* stream) {
     FAVAE_CHECK_ARG(xsum && zsum && xtz1 && zprodT && wprodT && wmean && bmean && scal && d > 0 && K > 0, "favae_fa_tau_update: bad argument");
     hipLaunchKernelGGL(tau_update_kernel, dim3(1), dim3(256), 0, ST, xsum, zsum, xtz1, trxx, zprodT, wprodT, wmean, bmean, bprodT, a0, b0, N,
-                       d, K, scal);
+                       d, K, scal, bprodT_dev, xtx1_dev, covsum_dev);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

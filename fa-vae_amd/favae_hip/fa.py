@@ -56,11 +56,13 @@ def rows_gemm(X, P, c, alpha, base, beta, out, accumulate=False):
     return out
 
 
-def mult_update(t, zwb, xi, mean, cov, tau, sc):
+def mult_update(t, zwb, xi, mean, cov, tau, sc, sync=True):
     s = sc.need(4096)
     L.check(_raw.favae_fa_mult_update(L.ptr(t), L.ptr(zwb), L.ptr(xi), L.ptr(mean), L.ptr(cov), _d(tau), _ll(t.numel()),
                                       L.ptr(sc.pair), L.ptr(s), _sz(s.numel()), L.stream_ptr()))
     dist.sum_(sc.pair)                          # the two sums run over all shards
+    if not sync:
+        return sc.pair[:2].clone()              # device: (sum log cov, bound term), read when the bound is assembled
     return sc.pair[:2].cpu().numpy().copy()     # (sum log cov, bound term)
 
 
@@ -82,11 +84,55 @@ def mult_predict(m_x, scale, mean_t, var_t):
     L.check(_raw.favae_fa_mult_predict(L.ptr(m_x), L.ptr(scale), L.ptr(mean_t), L.ptr(var_t), _ll(N), _i(d), L.stream_ptr()))
 
 
+def chol_inv_batched(mats, K, sc, lda=None):
+    """favae_chol_inv_batched: up to 12 SPD inverses of size K in one asynchronous launch.  mats: dicts with
+    terms = [(coef, [K, K] tensor), ...] (the matrix is their sum), optional s (tensor), s_mul, s_sqrt, diag_add, out_scale, out.
+    Returns (outs, logdet [nb, 2], info [nb]) -- device tensors; nothing is synchronised."""
+    nb = len(mats)
+    dev = mats[0]["terms"][0][1].device
+    A = (ctypes.c_void_p * (8 * nb))()
+    coef = (ctypes.c_double * (8 * nb))()
+    nterm = (ctypes.c_int * nb)()
+    sv = (ctypes.c_void_p * nb)()
+    s_mul = (ctypes.c_double * nb)()
+    s_sqrt = (ctypes.c_int * nb)()
+    dadd = (ctypes.c_double * nb)()
+    oscale = (ctypes.c_double * nb)()
+    outp = (ctypes.c_void_p * nb)()
+    outs = []
+    ld = None
+    for b, m in enumerate(mats):
+        nterm[b] = len(m["terms"])
+        for t, (c, a) in enumerate(m["terms"]):
+            assert a.dtype == F64 and a.shape[0] >= K and a.shape[1] >= K
+            ld = a.stride(0) if ld is None else ld
+            assert a.stride(0) == ld, "favae_chol_inv_batched: one leading dimension for all terms"
+            A[8 * b + t] = a.data_ptr()
+            coef[8 * b + t] = float(c)
+        sb = m.get("s")
+        sv[b] = None if sb is None else sb.data_ptr()
+        s_mul[b] = float(m.get("s_mul", 1.0))
+        s_sqrt[b] = 1 if m.get("s_sqrt") else 0
+        dadd[b] = float(m.get("diag_add", 0.0))
+        oscale[b] = float(m.get("out_scale", 1.0))
+        o = m.get("out")
+        if o is None:
+            o = torch.empty(K, K, dtype=F64, device=dev)
+        outs.append(o)
+        outp[b] = o.data_ptr()
+    logdet = torch.empty(nb, 2, dtype=F64, device=dev)
+    info = torch.zeros(nb, dtype=torch.int32, device=dev)
+    w = sc.need_work(2 * K * K + 2 * K) if K > 201 else None
+    L.check(_raw.favae_chol_inv_batched(_i(nb), A, coef, nterm, _i(ld if lda is None else lda), _i(K), sv, s_mul, s_sqrt, dadd, oscale, outp, _i(K),
+                                        L.ptr(logdet), L.ptr(info), L.ptr(w), _sz(0 if w is None else w.numel()), L.stream_ptr()))
+    return outs, logdet, info
+
+
 def chol_inv(A, sc, s=None, diag_add=0.0, out_scale=1.0):
     """(inverse [K,K] device tensor, logdet_factored, logdet_out, ok)."""
     K = A.shape[0]
     out = torch.empty(K, K, dtype=F64, device=A.device)
-    w = sc.need_work(2 * K * K + K)
+    w = sc.need_work(2 * K * K + 2 * K)
     rc = L.check(_raw.favae_chol_inv(L.ptr(A), _i(A.stride(0)), _i(K), L.ptr(s), _d(diag_add), _d(out_scale), L.ptr(out),
                                      _i(K), L.ptr(w), L.ptr(sc.pair), L.ptr(sc.info), L.stream_ptr()), allow_flags=True)
     ld = sc.pair[:2].cpu().numpy()
@@ -101,6 +147,13 @@ def slogdet(A, sc):
     return float(r[0]), float(r[1])
 
 
+def slogdet_into(A, out2):
+    """(sign, log|det|) of A into the device pair out2, asynchronously (several matrices, one read-back by the caller)."""
+    K = A.shape[0]
+    w = torch.empty(K * K, dtype=F64, device=A.device)       # (own workspace: the calls of one bound are in flight together)
+    L.check(_raw.favae_slogdet(L.ptr(A), _i(A.stride(0)), _i(K), L.ptr(w), L.ptr(out2), L.stream_ptr()))
+
+
 def small_gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None):
     M = A.shape[1] if transA else A.shape[0]
     Kd = A.shape[0] if transA else A.shape[1]
@@ -111,12 +164,12 @@ def small_gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None):
     return C
 
 
-def w_update(xtz1, zsum, b, wcov, tau, wmean, wprodT, sc):
+def w_update(xtz1, zsum, b, wcov, tau, wmean, wprodT, sc, info=None, wcov_out=None, tmp=None):
     d, K1 = xtz1.shape
     K = K1 - 1
-    tmp = sc.need_work(d * K)
+    tmp = sc.need_work(d * K) if tmp is None else tmp
     L.check(_raw.favae_fa_w_update(L.ptr(xtz1), L.ptr(zsum), L.ptr(b), L.ptr(wcov), _d(tau), _i(d), _i(K), L.ptr(wmean),
-                                   L.ptr(wprodT), L.ptr(tmp), L.stream_ptr()))
+                                   L.ptr(wprodT), L.ptr(tmp), L.ptr(info), L.ptr(wcov_out), L.stream_ptr()))
 
 
 def b_update(xsum, zsum, wmean, tau, N, bmean, scal):
@@ -125,11 +178,12 @@ def b_update(xsum, zsum, wmean, tau, N, bmean, scal):
                                    L.ptr(scal), L.stream_ptr()))
 
 
-def tau_update(xsum, zsum, xtz1, trxx, zprodT, wprodT, wmean, bmean, bprodT, a0, b0, N, scal):
+def tau_update(xsum, zsum, xtz1, trxx, zprodT, wprodT, wmean, bmean, bprodT, a0, b0, N, scal, bprodT_dev=None, xtx1_dev=None,
+               covsum_dev=None):
     d, K = wmean.shape
     L.check(_raw.favae_fa_tau_update(L.ptr(xsum), L.ptr(zsum), L.ptr(xtz1), _d(trxx), L.ptr(zprodT), L.ptr(wprodT), L.ptr(wmean),
                                      L.ptr(bmean), _d(bprodT), _d(a0), _d(b0), _d(float(N)), _i(d), _i(K), L.ptr(scal),
-                                     L.stream_ptr()))
+                                     L.ptr(bprodT_dev), L.ptr(xtx1_dev), L.ptr(covsum_dev), L.stream_ptr()))
 
 
 def alpha_update(wprodT, b0, d, alpha_b):

@@ -424,6 +424,10 @@ class ImgVAE(VAE):
 
     # ---- reconstruction (:360-385) ----------------------------------------------------------------------------
     def _latent_sample(self, mean, var):
+        """torch.Tensor(mean + np.random.randn() * np.sqrt(var)) of :362 (one scalar draw; float64 arithmetic, float32 result);
+        device tensors stay on the device."""
+        if isinstance(mean, torch.Tensor):
+            return (mean + np.random.randn() * var.sqrt()).float()
         return torch.Tensor(mean + np.random.randn() * np.sqrt(var))
 
     def reconstruction(self, mean, var):

@@ -43,18 +43,25 @@ class LazyDict(dict):
     def __getitem__(self, key):
         v = dict.__getitem__(self, key)
         if v is None and key in self._dev:
-            v = self._dev[key].cpu().numpy()
+            d = self._dev[key]
+            v = [t.cpu().numpy() if t is not None else np.nan for t in d] if isinstance(d, list) else d.cpu().numpy()
+            dict.__setitem__(self, key, v)
+        elif v is None and key in getattr(self, "_lazy", {}):       # assembled from device statistics on first access
+            v = self._lazy[key]()
             dict.__setitem__(self, key, v)
         return v
 
     def __setitem__(self, key, value):
         self._dev.pop(key, None)
+        getattr(self, "_lazy", {}).pop(key, None)
         self._touched = True          # a caller assigned an entry by hand (cA/condition_a_pretrainedvae.py:94-95)
         dict.__setitem__(self, key, value)
 
     def __getstate__(self):
         out = {}
         for k in self.keys():
+            if isinstance(k, str) and k.startswith("_"):      # device-side by-products (log-determinants of the last inverse)
+                continue
             v = self[k]
             out[k] = [v[i] for i in range(len(v))] if isinstance(v, _PredList) else v
         return out
@@ -82,12 +89,12 @@ class Qdistribution(object):
 
     def __init__(self, X, n, n_max, d, Kc, m, hyper):
         self.n, self.n_max, self.d, self.Kc, self.m, self.X = n, n_max, d, Kc, m, X
-        self.alpha = [dict(a=hyper.alpha_a[i], b=hyper.alpha_b[i] * np.ones(Kc), LH=None, ElogpWalp=None) for i in range(m)]
+        self.alpha = [LazyDict(a=hyper.alpha_a[i], b=hyper.alpha_b[i] * np.ones(Kc), LH=None, ElogpWalp=None) for i in range(m)]
         self.tau = [dict(a=hyper.tau_a[i], b=hyper.tau_b[i] * np.ones(1), LH=None, ElogpXtau=None) for i in range(m)]
         self.gamma = [dict(a=hyper.gamma_a[i], b=hyper.gamma_b[i] * np.ones(d[i]), LH=None) for i in range(m)]
         blank = lambda: dict(mean=None, cov=None, prodT=None, LH=0, Elogp=0)
-        self.W = [blank() for _ in range(m)]
-        self.b = [blank() for _ in range(m)]
+        self.W = [LazyDict(blank()) for _ in range(m)]      # K-sized state is device-resident between the updates too;
+        self.b = [LazyDict(blank()) for _ in range(m)]      # the host arrays the result scripts index are made on access
         self.XS, self.tS = [LazyDict(blank()) for _ in range(m)], [blank() for _ in range(m)]
         self.tc = {}
         self.Z = LazyDict(blank())
@@ -143,6 +150,9 @@ class SSHIBA(object):
         if name in ("dev", "sc", "scal") and "q_dist" in self.__dict__:
             self._device_state()
             return self.__dict__[name]
+        if name in ("_pending_scal", "_pending_mult", "_pending_info"):      # nothing is pending on a model that was just un-pickled
+            self.__dict__[name] = [] if name == "_pending_info" else {}
+            return self.__dict__[name]
         raise AttributeError(name)
 
     def _resume_device_stats(self):
@@ -154,7 +164,8 @@ class SSHIBA(object):
         if any(self.SS):
             self._ss_mask_dev = {m: torch.from_numpy(self.SS_mask[m] if self.method[m] == "reg" else self.SS_mask[m].astype(np.uint8)).to(self.dev)
                                  for m in range(self.m) if self.SS[m]}
-        self._xsum = {}
+        self._xsum, self._xtx1, self._covsum = {}, {}, {}
+        self._pending_info, self._pending_scal, self._pending_mult = [], {}, {}
         for m in range(self.m):
             prod = dict.__getitem__(self.X[m], "prodT")
             self._refresh_xstats(m)
@@ -179,12 +190,16 @@ class SSHIBA(object):
             stats.append(fa.atb(X.dev("cov", self.dev), None, True, self.sc))
         dist.sum_many_(stats)                              # one all-reduce for the statistics of this view
         xtx1 = stats[0]
-        prod = xtx1[:, :d].cpu().numpy()
-        if with_cov:
-            prod = prod + np.diag(stats[1].cpu().numpy().ravel())
-        dict.__setitem__(X, "prodT", prod)
         self._xsum[m] = xtx1[:, d].contiguous()
-        self._trxx[m] = float(np.trace(prod))
+        # X.prodT = X^T X + diag(sum cov) and its trace stay on the device (the tau update takes them from there); the host
+        # array is assembled when somebody reads X['prodT']
+        self._xtx1[m] = xtx1
+        self._covsum[m] = stats[1].reshape(-1).contiguous() if with_cov else None
+        dict.__setitem__(X, "prodT", None)
+        X._dev.pop("prodT", None)
+        X._lazy = getattr(X, "_lazy", {})
+        cs = self._covsum[m]
+        X._lazy["prodT"] = lambda xtx1=xtx1, cs=cs, d=d: (xtx1[:, :d].cpu().numpy() + (np.diag(cs.cpu().numpy()) if cs is not None else 0.0))
 
     def _refresh_zstats(self, also=()):
         """Z^T [Z | 1] summed over the shards; `also`: further local statistics of the same phase, reduced in the same
@@ -212,7 +227,8 @@ class SSHIBA(object):
         self.wandb_obj = [None] * len(n)
         self.total_elbo, self.kl_q_p, self.recon_loss, self.kl_q_normal = [], [], [], []
         self.keep_training, self.test_acc = [], []
-        self._xsum, self._trxx = {}, {}
+        self._xsum, self._trxx, self._xtx1, self._covsum = {}, {}, {}, {}
+        self._pending_info, self._pending_scal, self._pending_mult = [], {}, {}
         for m, arg in enumerate(args):
             meth = arg["method"]
             if arg.get("SV") is not None or arg.get("sparse") or meth not in ("reg", "img", "mult"):
@@ -359,6 +375,9 @@ class SSHIBA(object):
             for vae in self.img_vae:
                 if vae is not None:
                     vae.sync()
+            if "q_dist" in self.__dict__ and "_pending_scal" in self.__dict__:
+                self._sync_scalars()
+                self._flush_info()
 
     def _fit_iterate(self, max_iter=int(1e3), pruning_crit=1e-6, tol=1e-5, feat_crit=1e-6, perc=False, verbose=0, Y_tst=[None],
                      X_tst=[None], X_tr=[None], HL=0, AUC=0, ACC=0, mse=0, R2=0, m_in=[0], m_out=1, steps=50, nnd=None,
@@ -400,8 +419,7 @@ class SSHIBA(object):
         # X_m^T [Z | 1] of every view in one all-reduce (Z does not change between the W updates)
         Zd = self.q_dist.Z.dev("mean", self.dev)
         xtz = dist.sum_many_([fa.atb(self.X[m].dev("mean", self.dev), Zd, True, self.sc) for m in range(self.m)])
-        for m in range(self.m):
-            self.update_w(m, xtz[m])
+        self._update_w_views(list(range(self.m)), xtz)      # the M Cholesky inverses: one launch
         self.update_Z()
         for m in range(self.m):
             meth = self.method[m]
@@ -439,11 +457,14 @@ class SSHIBA(object):
 
     def _update_img(self, m, iter_count):
         q, vae = self.q_dist, self.img_vae[m]
+        self._sync_scalars()            # the VAE plugin reads b['cov'] / b['prodT'] on the host when it samples the prior
         epochs, beta = self._schedule(m, iter_count)
         if getattr(self, "epochs_override", None) is not None:
             epochs = self.epochs_override[min(iter_count, len(self.epochs_override) - 1)]
         if self.VARIANT == "A":
-            Z_in = {"mean": q.Z.dev("mean_pred%d" % m, self.dev), "cov": q.Z["covs_pred"][m]}         # :802
+            # :802 (the moment prior of celeba_deepvanilla_vae never looks at the covariance: not fetched for it)
+            Z_in = {"mean": q.Z.dev("mean_pred%d" % m, self.dev),
+                    "cov": q.Z["covs_pred"][m] if getattr(vae, "PRIOR", "moment") != "moment" else None}
         else:
             Z_in = {"mean": q.Z.dev("mean", self.dev), "cov": q.Z["cov"]}
         img = self.t[m]["data"]
@@ -474,7 +495,7 @@ class SSHIBA(object):
         self.update_tau(m)
         self.update_b(m)
         # diagnostics (:839-851): reconstruction R^2 (one np.random.randn draw) and the zero-input prediction R^2
-        r2 = vae.reconstruction_r2(self.X[m]["mean"], self.X[m]["cov"])
+        r2 = vae.reconstruction_r2(self.X[m].dev("mean", self.dev), self.X[m].dev("cov", self.dev))
         self.wandb_metrics[str(vae.dataset) + " R2 reconstruction"] = r2
         if self.VARIANT == "A" and self.m > 1 and self.method[1] == "mult":
             self.wandb_metrics[str(vae.dataset) + " r2_acc in the second view"] = self._zero_input_r2()
@@ -483,18 +504,20 @@ class SSHIBA(object):
         """predict([0],[1], struct_data(X['data'],'vae')) of cA :846-848: a 'vae' view contributes nothing to Z_mean
         (:1402-1414), so the prediction is sigmoid(b (1+pi/8 var)^-1/2) per label (:1469-1477); R^2 from column sums."""
         q = self.q_dist
-        W0 = self._up(q.W[0]["mean"])
-        aux = fa.small_gemm(W0, W0, transA=True, alpha=self._tau(0))
-        aux = fa.axpby(1.0, aux, 1.0, self._up(np.eye(q.Kc)))
-        Zc, _, _, ok = fa.chol_inv(aux, self.sc)
-        W1 = self._up(q.W[1]["mean"])
-        var = fa.small_gemm(fa.small_gemm(W1, Zc), W1, transB=True).cpu().numpy()
-        var_d = 1.0 / self._tau(1) + np.diag(var)
-        b1 = np.ravel(q.b[1]["mean"])
+        W0, W1 = q.W[0].dev("mean", self.dev), q.W[1].dev("mean", self.dev)
+        ww = fa.small_gemm(W0, W0, transA=True)
+        (Zc,), _, _ = fa.chol_inv_batched([dict(terms=[(self._tau(0), ww)], diag_add=1.0)], q.Kc, self.sc)     # :1370-1373
+        var = fa.small_gemm(fa.small_gemm(W1, Zc), W1, transB=True)
+        d = self.d[1]
+        if getattr(self, "_t1_stats", None) is None or self.SS[1]:     # T^T [T | 1]: the labels only change when some are unobserved
+            T = self.t[1].dev("mean", self.dev)
+            self._t1_stats = dist.sum_(fa.atb(T, T, True, self.sc))
+        flat = torch.cat([var.diagonal(), q.b[1].dev("mean", self.dev).reshape(-1), self._t1_stats.reshape(-1)]).cpu().numpy()   # one read-back
+        var_d = 1.0 / self._tau(1) + flat[:d]
+        b1 = flat[d:2 * d]
+        st = flat[2 * d:].reshape(d, d + 1)
         pred = np.exp(-np.log(1 + np.exp(-(b1 * (1 + math.pi / 8 * var_d) ** (-0.5)))))
-        T = self.t[1].dev("mean", self.dev)
-        st = dist.sum_(fa.atb(T, T, True, self.sc)).cpu().numpy()
-        n, d = self.n_max, self.d[1]
+        n = self.n_max
         sy, syy = st[:, d], np.diag(st[:, :d])
         num = syy - 2 * pred * sy + n * pred ** 2
         den = syy - sy ** 2 / n
@@ -516,9 +539,10 @@ class SSHIBA(object):
             if arg.get("SV") is not None:
                 raise NotImplementedError("kernel views are outside the FA-VAE hot path")
         n_pred = int(np.shape(args[0]["data"])[0])
+        self._sync_scalars()
         aux = self._up(np.eye(K))
         for m in m_in:
-            Wm = self._up(q.W[m]["mean"])
+            Wm = q.W[m].dev("mean", self.dev)
             aux = fa.axpby(1.0, aux, 1.0, fa.small_gemm(Wm, Wm, transA=True, alpha=self._tau(m)))
         Zc, _, _, ok = fa.chol_inv(aux, self.sc)
         X_sample = None
@@ -538,8 +562,8 @@ class SSHIBA(object):
             if Xs is None:
                 continue
             # sum_m tau_m (X_m - b_m) W_m Sigma  =  sum_m X_m P_m + c ,  P_m = tau_m W_m Sigma  (row GEMMs over N)
-            P = fa.small_gemm(self._up(q.W[mi]["mean"]), Zc, alpha=self._tau(mi))
-            cvec = fa.small_gemm(self._up(np.asarray(q.b[mi]["mean"]).reshape(1, -1)), P, alpha=-1.0,
+            P = fa.small_gemm(q.W[mi].dev("mean", self.dev), Zc, alpha=self._tau(mi))
+            cvec = fa.small_gemm(q.b[mi].dev("mean", self.dev).reshape(1, -1), P, alpha=-1.0,
                                  beta=0.0 if cvec is None else 1.0, out=cvec)
             terms.append((self._up(Xs), P))
         if not terms:
@@ -609,45 +633,77 @@ class SSHIBA(object):
     # ---- mean-field updates ----------------------------------------------------------------------------------------
     def update_w(self, m, xtz1=None):
         """:1058-1075 (xtz1: X_m^T [Z | 1] already summed over the shards)"""
+        self._update_w_views([m], {m: xtz1})
+
+    def _update_w_views(self, views, xtz):
+        """update_w of several views: their K x K inverses (:1062-1065) are one batched launch; the flags stay on the device --
+        W is replaced by a kernel that looks at its flag, so "not invertible, not updated" (:1073-1075) needs no read-back here --
+        and are reported with those of update_Z."""
         q = self.q_dist
-        tau = self._tau(m)
-        s = self._up(1 / np.sqrt(q.alpha_mean(m)))
-        wcov, _, ld_out, ok = fa.chol_inv(self._up(q.Z["prodT"]), self.sc, s=s, diag_add=1 / tau, out_scale=1 / tau)
-        if not ok:
-            print("Cov W" + str(m) + " is not invertible, not updated")
-            return
-        if xtz1 is None:
-            Xd, Zd = self.X[m].dev("mean", self.dev), q.Z.dev("mean", self.dev)
-            xtz1 = dist.sum_(fa.atb(Xd, Zd, True, self.sc))
-        wmean = torch.empty(self.d[m], q.Kc, dtype=F64, device=self.dev)
-        wprod = torch.empty(q.Kc, q.Kc, dtype=F64, device=self.dev)
-        fa.w_update(xtz1, self._zsum, self._up(np.ravel(q.b[m]["mean"])), wcov, tau, wmean, wprod, self.sc)
-        W = q.W[m]
-        W["cov"], W["mean"], W["prodT"] = wcov.cpu().numpy(), wmean.cpu().numpy(), wprod.cpu().numpy()
-        W["_logdet_cov"] = ld_out
+        K = q.Kc
+        zp = q.Z.dev("prodT", self.dev)
+        taus = {m: self._tau(m) for m in views}
+        mats = [dict(terms=[(1.0, zp)], s=q.alpha[m].dev("b", self.dev), s_mul=1.0 / q.alpha[m]["a"], s_sqrt=True,
+                     diag_add=1 / taus[m], out_scale=1 / taus[m]) for m in views]
+        outs, logdet, info = fa.chol_inv_batched(mats, K, self.sc)
+        for i, m in enumerate(views):
+            x = xtz[m]
+            if x is None:
+                x = dist.sum_(fa.atb(self.X[m].dev("mean", self.dev), q.Z.dev("mean", self.dev), True, self.sc))
+            W = q.W[m]
+            wmean, wprod, wcov = W.dev("mean", self.dev), W.dev("prodT", self.dev), W.dev("cov", self.dev)
+            tmp = torch.empty(self.d[m] * K, dtype=F64, device=self.dev)
+            fa.w_update(x, self._zsum, q.b[m].dev("mean", self.dev), outs[i], taus[m], wmean, wprod, self.sc, info=info[i:i + 1],
+                        wcov_out=wcov, tmp=tmp)
+            for k, t in (("mean", wmean), ("prodT", wprod), ("cov", wcov)):
+                W.set_dev(k, t)
+            W["_logdet_cov"] = logdet[i, 1]
+        self._pending_info.append((info, ["Cov W" + str(m) + " is not invertible, not updated" for m in views]))
+
+    def _flush_info(self, extra=None):
+        """ONE read-back of the flags of the inverses queued since the last one (the W updates of this iteration and, as `extra`,
+        the launch of update_Z); prints the reference's messages; returns the flags of `extra`."""
+        pend = self._pending_info
+        self._pending_info = []
+        ts = [i for i, _ in pend] + ([extra] if extra is not None else [])
+        if not ts:
+            return []
+        flags = torch.cat(ts).cpu().tolist()
+        o = 0
+        for i, msgs in pend:
+            for k, msg in enumerate(msgs):
+                if flags[o + k]:
+                    print(msg)
+            o += i.numel()
+        return flags[o:]
 
     def update_Z(self):
         """cA :961-1000 (variant A) / DA :980-1009 (variants B, C)"""
         q = self.q_dist
         M, K, lr = range(self.m), q.Kc, self.latentspace_lr
         taus = [self._tau(m) for m in M]
-        wp = [self._up(q.W[m]["prodT"]) for m in M]
-        Zcov, _, ld, ok = fa.chol_inv(fa.z_aux(wp, taus, K, self.dev), self.sc)
-        covs_pred = []
+        wp = [q.W[m].dev("prodT", self.dev) for m in M]
+        # Sigma_Z = (I + sum_m tau_m <W^T W>_m)^-1 and, variant A, the predictive covariances whose `aux` is carried over from
+        # view to view (:975-980): M + 1 inverses, one launch, the sums formed while the matrices are loaded
+        mats = [dict(terms=[(taus[m], wp[m]) for m in M], diag_add=1.0)]
         if self.VARIANT == "A":
-            q.Z["covs_pred"] = []
             coef = np.zeros(self.m)
             for m in M:
                 coef += np.array([0.0 if j == m else 1.0 for j in M])              # `aux` is carried over (:979)
-                cp, _, _, okp = fa.chol_inv(fa.z_aux(wp, list(coef * np.array(taus)), K, self.dev), self.sc)
-                covs_pred.append(cp)
-                q.Z["covs_pred"].append(cp.cpu().numpy() if okp else np.nan)
-        if not ok:
+                terms = [(coef[j] * taus[j], wp[j]) for j in M if coef[j] != 0.0] or [(0.0, wp[0])]
+                mats.append(dict(terms=terms, diag_add=1.0))
+        outs, logdet, info = fa.chol_inv_batched(mats, K, self.sc)
+        flags = self._flush_info(info)                    # the one read-back of the iteration's inverses
+        Zcov, covs_pred = outs[0], outs[1:]
+        if self.VARIANT == "A":
+            q.Z.set_dev("covs_pred", [c if not f else None for c, f in zip(covs_pred, flags[1:])])
+        if flags[0]:
             print("Cov Z is not invertible, not updated")
             return
-        q.Z["cov"] = Zcov.cpu().numpy()
-        Wd = [self._up(q.W[m]["mean"]) for m in M]
-        bd = [self._up(np.asarray(q.b[m]["mean"]).reshape(1, -1)) for m in M]
+        q.Z.set_dev("cov", Zcov)
+        q.Z["_logdet_cov"] = logdet[0, 1]
+        Wd = [q.W[m].dev("mean", self.dev) for m in M]
+        bd = [q.b[m].dev("mean", self.dev).reshape(1, -1) for m in M]
         Xd = [self.X[m].dev("mean", self.dev) for m in M]
 
         def combine(views, cov, base, out):
@@ -678,9 +734,9 @@ class SSHIBA(object):
                 q.Z.set_dev("mean_pred%d" % m, zp)
                 zz.append(fa.atb(zp, zp, False, self.sc))
         ztz = self._refresh_zstats(also=zz)               # Z^T Z and the predictive Z^T Z of every view: one all-reduce
-        q.Z["prodT"] = fa.axpby(1.0, ztz, float(self.n_max), Zcov).cpu().numpy()                     # :989
+        q.Z.set_dev("prodT", fa.axpby(1.0, ztz, float(self.n_max), Zcov))                            # :989
         if self.VARIANT == "A":
-            q.Z["prodT_pred"] = [fa.axpby(1.0, zz[m], float(self.n_max), covs_pred[m]).cpu().numpy() for m in M]
+            q.Z.set_dev("prodT_pred", [fa.axpby(1.0, zz[m], float(self.n_max), covs_pred[m]) for m in M])
             q.Z["mean_pred"] = _PredList(q.Z, self.m)
 
     def update_xs(self, m):
@@ -690,7 +746,7 @@ class SSHIBA(object):
         X, XS = self.X[m], q.XS[m]
         tau = self._tau(m)
         xs = torch.empty(self.n_loc, self.d[m], dtype=F64, device=self.dev)
-        fa.rows_gemm(q.Z.dev("mean", self.dev), self._up(q.W[m]["mean"].T), self._up(np.ravel(q.b[m]["mean"])), 1.0, None, 0.0, xs)
+        fa.rows_gemm(q.Z.dev("mean", self.dev), self._wt(m), q.b[m].dev("mean", self.dev), 1.0, None, 0.0, xs)
         XS.set_dev("mean", xs)
         dict.__setitem__(XS, "cov", (1.0 / tau) * np.eye(self.d[m]))
         mask = self._ss_mask_dev[m]
@@ -699,54 +755,85 @@ class SSHIBA(object):
         self._refresh_xstats(m)
         dict.__setitem__(X, "sumlogdet", dist.sum_scalar(self._ss_count[m], self.dev) * math.log(1.0 / tau))   # :781-783
 
+    def _wt(self, m):
+        """W_m.mean^T [K, d] on the device (the row GEMMs take their right operand row-major)."""
+        return self.q_dist.W[m].dev("mean", self.dev).t().contiguous()
+
     def update_b(self, m, n=None):
-        """:1077-1092 (n: the view's own row count for the initial b, :1986)"""
+        """:1077-1092 (n: the view's own row count for the initial b, :1986).  The two scalars (Sigma_b[0, 0], <b b^T>) stay on the
+        device -- update_tau reads <b b^T> from there -- and reach the host with the next _sync_scalars."""
         q = self.q_dist
-        bmean = torch.empty(self.d[m], dtype=F64, device=self.dev)
-        fa.b_update(self._xsum[m], self._zsum, self._up(q.W[m]["mean"]), self._tau(m), self.n_max if n is None else n, bmean, self.scal)
-        sc = self.scal.cpu().numpy()
-        b = q.b[m]
-        b["cov"] = sc[0] * np.eye(self.d[m])
-        b["mean"] = bmean.cpu().numpy()[np.newaxis, :]
-        b["prodT"] = float(sc[1])
+        bmean = torch.empty(1, self.d[m], dtype=F64, device=self.dev)
+        scal = self._scal_of(m)
+        fa.b_update(self._xsum[m], self._zsum, q.W[m].dev("mean", self.dev), self._tau(m), self.n_max if n is None else n, bmean, scal)
+        q.b[m].set_dev("mean", bmean)
+        self._pending_scal[m] = scal
+
+    def _scal_of(self, m):
+        """Device scalars of view m: [Sigma_b[0,0], <b b^T>, tau.a, tau.b]."""
+        if "_scal_m" not in self.__dict__:
+            self._scal_m = {}
+        if m not in self._scal_m:
+            self._scal_m[m] = torch.zeros(4, dtype=F64, device=self.dev)
+        return self._scal_m[m]
+
+    def _sync_scalars(self):
+        """ONE read-back of what the updates left on the device for the host side of the coordinator: the b scalars of every
+        view and the two sums of every multilabel update (entropy and bound term, :1649, :1678)."""
+        ms, ks = sorted(self._pending_scal), sorted(self._pending_mult)
+        if not ms and not ks:
+            return
+        flat = torch.cat([self._pending_scal[m][:2] for m in ms] + [self._pending_mult[k] for k in ks]).cpu().numpy()
+        q = self.q_dist
+        for i, m in enumerate(ms):
+            bc, bp = flat[2 * i], flat[2 * i + 1]
+            dict.__setitem__(q.b[m], "cov", bc * np.eye(self.d[m]))
+            dict.__setitem__(q.b[m], "prodT", float(bp))
+        o = 2 * len(ms)
+        self._mult_elbo = getattr(self, "_mult_elbo", {})
+        for i, k in enumerate(ks):
+            dict.__setitem__(self.X[k], "sumlogdet", float(flat[o + 2 * i]))
+            self._mult_elbo[k] = float(flat[o + 2 * i + 1])
+        self._pending_scal, self._pending_mult = {}, {}
 
     def update_alpha(self, m):
         """:1094-1112"""
         q = self.q_dist
         ab = torch.empty(q.Kc, dtype=F64, device=self.dev)
-        fa.alpha_update(self._up(q.W[m]["prodT"]), self.hyper.alpha_b[m], self.d[m], ab)
-        q.alpha[m]["a"] = (self.hyper.alpha_a[m] + 0.5 * self.d[m]) / (self.d[m])
-        q.alpha[m]["b"] = ab.cpu().numpy()
+        fa.alpha_update(q.W[m].dev("prodT", self.dev), self.hyper.alpha_b[m], self.d[m], ab)
+        dict.__setitem__(q.alpha[m], "a", (self.hyper.alpha_a[m] + 0.5 * self.d[m]) / (self.d[m]))
+        q.alpha[m].set_dev("b", ab)
 
     def update_tau(self, m):
-        """:1121-1139"""
+        """:1121-1139; tr<X^T X> and <b b^T> are read on the device; tau itself comes back (the next kernels take it as an argument)"""
         q = self.q_dist
         xtz1 = dist.sum_(fa.atb(self.X[m].dev("mean", self.dev), q.Z.dev("mean", self.dev), True, self.sc))
-        fa.tau_update(self._xsum[m], self._zsum, xtz1, self._trxx[m], self._up(q.Z["prodT"]), self._up(q.W[m]["prodT"]),
-                      self._up(q.W[m]["mean"]), self._up(np.ravel(q.b[m]["mean"])), float(q.b[m]["prodT"]),
-                      self.hyper.tau_a[m], self.hyper.tau_b[m], self.n_max, self.scal)
-        sc = self.scal.cpu().numpy()
+        scal = self._scal_of(m)
+        pend = m in self._pending_scal
+        fa.tau_update(self._xsum[m], self._zsum, xtz1, 0.0, q.Z.dev("prodT", self.dev), q.W[m].dev("prodT", self.dev),
+                      q.W[m].dev("mean", self.dev), q.b[m].dev("mean", self.dev), 0.0 if pend else float(q.b[m]["prodT"]),
+                      self.hyper.tau_a[m], self.hyper.tau_b[m], self.n_max, scal, bprodT_dev=scal[1:2] if pend else None,
+                      xtx1_dev=self._xtx1[m], covsum_dev=self._covsum[m])
+        sc = scal.cpu().numpy()
         q.tau[m]["a"] = float(sc[2])
         q.tau[m]["b"] = np.array([sc[3]])
 
     def update_x(self, m):
-        """multilabel update_x + update_xi (:1197-1229), one fused pass"""
+        """multilabel update_x + update_xi (:1197-1229), one fused pass; its two sums stay on the device until _sync_scalars"""
         q = self.q_dist
         X = self.X[m]
         n, d = self.n_loc, self.d[m]
         zwb = torch.empty(n, d, dtype=F64, device=self.dev)
-        fa.rows_gemm(q.Z.dev("mean", self.dev), self._up(q.W[m]["mean"].T), self._up(np.ravel(q.b[m]["mean"])), 1.0, None, 0.0, zwb)
+        fa.rows_gemm(q.Z.dev("mean", self.dev), self._wt(m), q.b[m].dev("mean", self.dev), 1.0, None, 0.0, zwb)
         mean = X.dev("mean", self.dev)
         cov = X.dev("cov", self.dev)
-        sums = fa.mult_update(self.t[m].dev("mean", self.dev), zwb, q.xi[m], mean, cov, self._tau(m), self.sc)
+        self._pending_mult[m] = fa.mult_update(self.t[m].dev("mean", self.dev), zwb, q.xi[m], mean, cov, self._tau(m), self.sc, sync=False)
         X.set_dev("mean", mean)
         X.set_dev("cov", cov)
-        dict.__setitem__(X, "sumlogdet", float(sums[0]))
-        self._mult_elbo = getattr(self, "_mult_elbo", {})
-        self._mult_elbo[m] = float(sums[1])
 
     def update_t(self, m):
         """t* of a semi-supervised multilabel view (:1176-1195) and t.mean[mask] = tS.mean[mask] (:861), one pass"""
+        self._sync_scalars()
         t = self.t[m]
         tm = t.dev("mean", self.dev)
         sums = fa.mult_ss_update(self.X[m].dev("mean", self.dev), self._ss_mask_dev[m], tm, self.sc)
@@ -758,17 +845,26 @@ class SSHIBA(object):
         """fused into update_x (the kernel writes xi = sqrt(cov + mean^2) in the same pass, :1229)"""
 
     # ---- lower bound (:1572-1688) --------------------------------------------------------------------------------
-    def _hgauss(self, rows, cov, prev):
-        sgn, lad = fa.slogdet(self._up(cov), self.sc)
-        H = 0.5 * rows * (lad if sgn != 0 else -np.inf)
-        return prev if abs(H) == np.inf else H
-
     def update_bound(self):
         q = self.q_dist
-        q.Z["LH"] = self._hgauss(self.n_max, q.Z["cov"], q.Z["LH"])
+        self._sync_scalars()
+        # slogdet of Sigma_Z and every Sigma_W (de-pruned: padded with 1e-15, :1603 on :518-537): the LU launches are queued
+        # together and read back once
+        covs = [q.Z.dev("cov", self.dev)] + [q.W[m].dev("cov", self.dev) for m in range(self.m)]
+        ld = torch.empty(len(covs), 2, dtype=F64, device=self.dev)
+        for i, c in enumerate(covs):
+            fa.slogdet_into(c, ld[i])
+        ld = ld.cpu().numpy()
+
+        def hgauss(rows, i, prev):
+            sgn, lad = ld[i]
+            H = 0.5 * rows * (lad if sgn != 0 else -np.inf)
+            return prev if abs(H) == np.inf else H
+
+        q.Z["LH"] = hgauss(self.n_max, 0, q.Z["LH"])
         ent = q.Z["LH"]
         for m in range(self.m):
-            q.W[m]["LH"] = self._hgauss(self.d[m], q.W[m]["cov"], q.W[m]["LH"])
+            q.W[m]["LH"] = hgauss(self.d[m], 1 + m, q.W[m]["LH"])
             bc = q.b[m]["cov"][0, 0]
             Hb = 0.5 * 1 * self.d[m] * math.log(bc) if bc > 0 else -np.inf                            # slogdet(bc * I_d)
             q.b[m]["LH"] = q.b[m]["LH"] if abs(Hb) == np.inf else Hb
@@ -806,6 +902,9 @@ class SSHIBA(object):
         for m in range(self.m):
             keep |= np.any(np.abs(q.W[m]["mean"][:, :q.Kc]) > pruning_crit, axis=0)
         sel = np.flatnonzero(keep)
+        if len(sel) == q.Kc and not getattr(self, "_padded", False):
+            return                     # every factor stays and nothing was padded: the device-resident state is left alone
+        self._padded = False
         if len(sel) != q.Z.dev("mean", self.dev).shape[1]:
             if len(sel):
                 Zd = q.Z.dev("mean", self.dev)
@@ -834,6 +933,7 @@ class SSHIBA(object):
         Kp = self.Kc - q.Kc
         if Kp == 0:
             return
+        self._padded = True
 
         def pad2(A):
             top = np.hstack((A, pruning_crit * np.ones((q.Kc, Kp))))
@@ -848,8 +948,12 @@ class SSHIBA(object):
 
     # ---- pickling ----------------------------------------------------------------------------------------------------
     def __getstate__(self):
+        if "_pending_scal" in self.__dict__ and "dev" in self.__dict__:
+            self._sync_scalars()
+            self._flush_info()
         st = self.__dict__.copy()
-        for k in ("sc", "scal", "_zsum", "_xsum", "dev", "_ss_mask_dev"):
+        for k in ("sc", "scal", "_zsum", "_xsum", "dev", "_ss_mask_dev", "_xtx1", "_covsum", "_scal_m", "_pending_info", "_pending_scal",
+                  "_pending_mult", "_t1_stats"):
             st.pop(k, None)
         if "q_dist" in st:
             xi = st["q_dist"].xi

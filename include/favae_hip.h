@@ -438,27 +438,42 @@ int favae_fa_xi_init(const double* mean, const double* cov, double* xi, long lon
  * mean_t = sigmoid(m_x scale), var_t = exp(s) / (1 + exp(s)^2) (as the reference writes it). */
 int favae_fa_mult_predict(const double* m_x, const double* scale, double* mean_t, double* var_t, long long N, int d,
                           void* stream);
-/* out = out_scale (s s^T) o ((s s^T) o A + diag_add I)^-1 through the Cholesky factor, one workgroup, LDS-resident for
- * K <= ~135 (myInverse cA/favae.py:904-922; update_w :1062-1065 with s = alpha^-1/2, diag_add = 1/tau, out_scale = 1/tau).
- * s may be NULL. work: 2*K*K doubles. logdet2[0] = log det of the factored matrix, logdet2[1] = log det out.
- * SYNCHRONOUS; returns FAVAE_NOT_SPD and fills out with NaN when a pivot is not positive (the reference's NaN path). */
-int favae_chol_inv(const double* A, int lda, int K, const double* s, double diag_add, double out_scale, double* out,
-                   int ldo, double* work, double* logdet2, int* info_dev, void* stream);
+/* Batched SPD inverse through the Cholesky factor (myInverse cA/favae.py:904-922; the W covariance :1062-1065 with
+ * s = alpha.mean^-1/2, diag_add = out_scale = 1/tau; the M + 1 -- variant A: 2M + 1 -- inverses of update_Z :970-980): nb <= 12
+ * matrices of size K in ONE launch, one 16-wave workgroup per matrix, the matrix resident in LDS as a packed lower triangle
+ * (K <= 201), Cholesky / triangular inverse / X^T X blocked in 16 x 16 tiles on the fp64 matrix cores.  Matrix b:
+ *   A'_b = (s_b s_b^T) o (sum_{t < nterm[b]} coef[8 b + t] * A[8 b + t]) + diag_add[b] I     (the sums of :971, :979 are formed on load)
+ *   out[b] = out_scale[b] (s_b s_b^T) o A'_b^-1,   logdet2[b] = (log det A'_b, log det out[b]),   info[b] = 0, or 1: not SPD, NaN
+ * s may be NULL, s[b] may be NULL (ones); s_sqrt[b] = 1 takes s_b[i] = sqrt(s[b][i] * s_mul[b]) (alpha.b / alpha.a on the device).
+ * ASYNCHRONOUS: nothing is read back; look at info when the results are used.  K > 201 (<= 1024): matrix by matrix through
+ * `work` (>= 2 K^2 + 2 K doubles) in global memory; work may be NULL otherwise. */
+int favae_chol_inv_batched(int nb, const double* const* A, const double* coef, const int* nterm, int lda, int K,
+                           const double* const* s, const double* s_mul, const int* s_sqrt, const double* diag_add,
+                           const double* out_scale, double* const* out, int ldo, double* logdet2, int* info_dev, double* work,
+                           size_t work_doubles, void* stream);
+/* The same for one matrix with one term; s may be NULL; work: 2*K*K + 2*K doubles.  SYNCHRONOUS (reads info back); returns
+ * FAVAE_NOT_SPD and fills out with NaN when a pivot is not positive (the reference's NaN path). */
 /* out2 = (sign, log|det|) of a general K x K matrix (np.linalg.slogdet in HGauss, cA/favae.py:1603). work: K*K doubles. */
 int favae_slogdet(const double* A, int lda, int K, double* work, double* out2, void* stream);
 /* C[M][N] = alpha op(A) op(B) + beta C for the small (d x K, K x K) products of update_w / update_Z / predict. */
 int favae_small_gemm(int transA, int transB, int M, int N, int Kd, double alpha, const double* A, int lda, const double* B,
                      int ldb, double beta, double* C, int ldc, void* stream);
-/* W.mean = tau (X^T Z - b^T 1^T Z) Sigma_W, W.prodT = W^T W + d Sigma_W (cA/favae.py:1070-1072). xtz1 = X^T [Z|1]. */
+/* W.mean = tau (X^T Z - b^T 1^T Z) Sigma_W, W.prodT = W^T W + d Sigma_W (cA/favae.py:1070-1072). xtz1 = X^T [Z|1].
+ * info (may be NULL): device flag of the inverse that produced wcov (favae_chol_inv_batched); when it is set nothing is written
+ * -- the reference's "not invertible, not updated" (:1073-1075) without a read-back.  wcov_out (may be NULL): receives a copy of
+ * wcov, so that Sigma_W too is only replaced when the inverse exists. */
 int favae_fa_w_update(const double* xtz1, const double* zsum, const double* b, const double* wcov, double tau, int d, int K,
-                      double* wmean, double* wprodT, double* tmp, void* stream);
+                      double* wmean, double* wprodT, double* tmp, const int* info, double* wcov_out, void* stream);
 /* b update (cA/favae.py:1090-1092): bmean[d]; scal[0] = Sigma_b[0,0], scal[1] = <b b^T>. */
 int favae_fa_b_update(const double* xsum, const double* zsum, const double* wmean, double tau, double N, int d, int K,
                       double* bmean, double* scal, void* stream);
-/* tau update (cA/favae.py:1134-1139) from reduced statistics: scal[2] = a, scal[3] = b. trxx = tr<X^T X> incl. sum cov. */
+/* tau update (cA/favae.py:1134-1139) from reduced statistics: scal[2] = a, scal[3] = b. trxx = tr<X^T X> incl. sum cov.
+ * Device-resident forms of two scalars (each may be NULL): bprodT_dev overrides bprodT with the value favae_fa_b_update left
+ * at scal[1]; xtx1_dev (X^T [X | 1], d x (d + 1)) with covsum_dev (column sums of X.cov, or NULL) overrides trxx. */
 int favae_fa_tau_update(const double* xsum, const double* zsum, const double* xtz1, double trxx, const double* zprodT,
                         const double* wprodT, const double* wmean, const double* bmean, double bprodT, double a0, double b0,
-                        double N, int d, int K, double* scal, void* stream);
+                        double N, int d, int K, double* scal, const double* bprodT_dev, const double* xtx1_dev,
+                        const double* covsum_dev, void* stream);
 /* alpha.b = (b0 + diag(W.prodT)/2)/d (cA/favae.py:1107-1112). */
 int favae_fa_alpha_update(const double* wprodT, double b0, int d, int K, double* alpha_b, void* stream);
 /* aux = I + sum_m coef[m] WprodT_m (cA/favae.py:970-971, 976-980). wprodT: HOST array of m device pointers, m <= 8. */

@@ -52,7 +52,7 @@ def test_rows_gemm(N, d, K):
     assert _rel(out.cpu().numpy(), 0.7 * (X @ P + c) + 0.3 * base + 2.0 * X @ P) < 1e-12
 
 
-@pytest.mark.parametrize("K", [1, 4, 10, 50, 100, 130, 200])
+@pytest.mark.parametrize("K", [1, 4, 10, 15, 16, 17, 31, 33, 50, 100, 130, 200, 201, 202, 260])
 def test_chol_inverse_matches_my_inverse(K):
     fa = _fa()
     rs = np.random.RandomState(K)
@@ -70,6 +70,49 @@ def test_chol_inverse_matches_my_inverse(K):
     ref = np.linalg.inv(np.diag(alpha) + tau * A)
     assert ok and _rel(inv2.cpu().numpy(), ref) < 1e-10
     assert abs(ld2 - np.linalg.slogdet(ref)[1]) < 1e-9 * max(1, abs(ld2))
+
+
+@pytest.mark.parametrize("K", [200, 50, 7])
+def test_chol_inverse_batch_of_five_in_one_launch(K):
+    """One update_Z of variant A with two views (cA/favae.py:970-980) at the stress size: Sigma_Z and the two predictive
+    covariances -- whose `aux` is carried over from view to view -- plus the two W covariances of update_w (:1062-1065) with
+    s = alpha.mean^-1/2 taken from alpha.b on the device: five K x K inverses, one launch, the sums formed while loading.
+    One matrix of a second batch is not SPD: its output is NaN and flagged, the others are untouched (asynchronous: the
+    flags are read once, afterwards)."""
+    fa = _fa()
+    rs = np.random.RandomState(K)
+    G0, G1, Gz = rs.randn(K + 9, K), rs.randn(K + 3, K), rs.randn(2 * K, K)
+    WW = [G0.T @ G0 / K, G1.T @ G1 / K]
+    ZZ = Gz.T @ Gz
+    taus = [1.7, 0.6]
+    alpha_a, alpha_b = [0.52, 0.51], [rs.rand(K) + 0.2, rs.rand(K) + 0.3]
+    I = np.eye(K)
+    wwd, zzd, Id = [dev(w) for w in WW], dev(ZZ), dev(I)
+    sc = fa.Scratch("cuda")
+    mats = [dict(terms=[(1.0, Id), (taus[0], wwd[0]), (taus[1], wwd[1])]),                       # :970-972
+            dict(terms=[(1.0, Id), (taus[1], wwd[1])]),                                         # m = 0: aux = I + others
+            dict(terms=[(1.0, Id), (taus[1], wwd[1]), (taus[0], wwd[0])])]                      # m = 1: aux carried over (:979)
+    for m in range(2):                                                                          # :1062-1065
+        mats.append(dict(terms=[(1.0, zzd)], s=dev(alpha_b[m]), s_mul=1.0 / alpha_a[m], s_sqrt=True, diag_add=1 / taus[m], out_scale=1 / taus[m]))
+    outs, logdet, info = fa.chol_inv_batched(mats, K, sc)
+    aux = [I + taus[0] * WW[0] + taus[1] * WW[1], I + taus[1] * WW[1], I + taus[1] * WW[1] + taus[0] * WW[0]]
+    refs = [fo.my_inverse(a) for a in aux]
+    for m in range(2):
+        refs.append(np.linalg.inv(np.diag(alpha_a[m] / alpha_b[m]) + taus[m] * ZZ))
+    assert info.cpu().tolist() == [0] * 5
+    ld = logdet.cpu().numpy()
+    for b in range(5):
+        assert _rel(outs[b].cpu().numpy(), refs[b]) < 1e-10, b
+        assert abs(ld[b, 1] - np.linalg.slogdet(refs[b])[1]) < 1e-9 * max(1, abs(ld[b, 1])), b
+    for b in range(3):
+        assert abs(ld[b, 0] - np.linalg.slogdet(aux[b])[1]) < 1e-9 * max(1, abs(ld[b, 0]))
+    bad = np.array(aux[1])
+    bad[K // 2, K // 2] = -1.0
+    keep = outs[0].clone()
+    outs2, _, info2 = fa.chol_inv_batched([dict(terms=[(1.0, dev(aux[0]))]), dict(terms=[(1.0, dev(bad))]), dict(terms=[(0.5, dev(aux[2])), (0.5, dev(aux[2]))])],
+                                          K, sc)
+    assert info2.cpu().tolist() == [0, 1, 0]
+    assert torch.isnan(outs2[1]).all() and _rel(outs2[0].cpu().numpy(), keep.cpu().numpy()) < 1e-12 and _rel(outs2[2].cpu().numpy(), refs[2]) < 1e-10
 
 
 def test_chol_inverse_flags_non_spd_like_the_reference():

@@ -44,6 +44,13 @@ mean, cov = torch.empty_like(xi), torch.empty_like(xi)
 rec("mult_update (update_x + update_xi fused)", timeit(lambda: fa.mult_update(t, zwb, xi.clone(), mean, cov, 1.3, sc)) - timeit(lambda: xi.clone()),
     8.0 * N * d1 * 6, 0.0)
 
+# the batched SPD inverse (favae_chol_inv_batched): one launch for the inverses of an update_Z / update_w
+for Kc, nb in ((50, 3), (50, 5), (100, 5), (200, 5), (200, 9)):
+    G = torch.randn(nb, 2 * Kc, Kc, dtype=F64, device="cuda", generator=g)
+    mats = [dict(terms=[(1.0, (G[i].t() @ G[i]).contiguous())], diag_add=1.0) for i in range(nb)]
+    tt = timeit(lambda: fa.chol_inv_batched(mats, Kc, sc), reps=20)
+    print("chol_inv_batched  %d x (%d x %d)  one launch %38.1f us   %6.2f GFLOP/s f64 per matrix (K^3 flop each)" % (nb, Kc, Kc, tt * 1e6, Kc ** 3 / tt / 1e9))
+
 # whole FA-only iterations through the drop-in API ('reg' d = 20 + 40 labels), as SURVEY 6 timed the reference (2.8 s / update on 8 cores)
 import favae
 rs = np.random.RandomState(1)
