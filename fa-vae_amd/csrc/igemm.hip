@@ -74,14 +74,29 @@ __device__ __forceinline__ void frag_pm(Frag<float>& f, const char* lds, int RS,
 #pragma unroll
     for (int j = 0; j < 8; ++j) f.v[j] = *(const float*)(p + j * RS);
 }
+// bf16 image: rows of RS = 64, 128 or 256 bytes (32 / 64 / 128 channels), NO padding, the 64-byte pieces of a row permuted by
+// pm_swz(row).  ds_read_b64_tr_b16 banks are (a / 4) % 64 and conflicts count per 32-lane half; a half reads, for each of 4
+// consecutive k-rows, one 64-byte piece (two 16-lane groups side by side).  Conflict-free means the four pieces lie in the four
+// 64-byte quarters of the 256-byte bank row: 64-byte rows do by themselves; 128-byte rows put rows r and r + 2 on one quarter, so
+// the piece index is XORed with bit 1 of the row; 256-byte rows put all four on one quarter, so it is XORed with row & 3.
+// (Round 2 padded the rows by 16 bytes instead: 144-byte rows leave rows 0 / 2 and 1 / 3 of a half overlapping in 8 banks -- the
+// 33 % LDS bank-conflict cycles of profiles/r2_sq_counters_gemm_lean.txt.)
+__device__ __forceinline__ int pm_swz(int row, int RS) { return RS == 128 ? ((row >> 1) & 1) : RS == 256 ? (row & 3) : 0; }
 __device__ __forceinline__ void frag_pm(Frag<bf16_t>& f, const char* lds, int RS, int k0, int cb, int lane) {
     // ds_read_b64_tr_b16: each 16-lane group reads a 4(k) x 16(channel) block and receives it column-major
-    const int i = lane & 15;
-    const char* p = lds + (k0 + 8 * (lane >> 5) + (i >> 2)) * RS + (cb + 16 * ((lane >> 4) & 1) + 4 * (i & 3)) * 2;
+    const int i = lane & 15, q = i >> 2;
+    const int row = k0 + 8 * (lane >> 5) + q;                        // (k0 + 8 h is a multiple of 8: the swizzle of row + 4 is the same)
+    const int piece = (cb >> 5) ^ pm_swz(q, RS);
+    const char* p = lds + row * RS + piece * 64 + 32 * ((lane >> 4) & 1) + 8 * (i & 3);
     union { s16x4 s[2]; bf16x8 b; } c;
     c.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
     c.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * RS));
     f.v = c.b;
+}
+// byte offset of 16-byte chunk `chunk` of k-row `row` in that image (fp32 images: plain padded rows)
+template <class T> __device__ __forceinline__ int pm_off(int row, int chunk, int RS) {
+    if constexpr (sizeof(T) == 2) return row * RS + ((((chunk >> 2) ^ pm_swz(row, RS)) << 2) | (chunk & 3)) * 16;
+    else return row * RS + chunk * 16;
 }
 
 // value select (a ?: on two uint4 lvalues would be an lvalue select and force the register arrays into memory)
@@ -721,7 +736,8 @@ struct PmParams {
 template <class T, int BM, int BN, int WM, int WN, bool LEAN>
 __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
     constexpr int VE = 16 / sizeof(T);
-    constexpr int RSR = BM * sizeof(T) + 16, RSC = BN * sizeof(T) + 16;
+    constexpr int PADB = sizeof(T) == 2 ? 0 : 16;   // bf16: swizzled rows without padding (frag_pm); fp32: 16 bytes of padding
+    constexpr int RSR = BM * sizeof(T) + PADB, RSC = BN * sizeof(T) + PADB;
     constexpr int VPR_R = BM / VE, VPR_C = BN / VE;
     constexpr int NVR = BK * VPR_R, NVC = BK * VPR_C;
     constexpr int VR = (NVR + 255) / 256, VC = (NVC + 255) / 256;
@@ -919,12 +935,12 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
 #pragma unroll
                 for (int i = 0; i < VR; ++i) {
                     const int v = tid + i * 256;
-                    if (NVR % 256 == 0 || v < NVR) *(uint4*)(ldsR + (v / VPR_R) * RSR + (v % VPR_R) * 16) = LEAN ? vr[d][i] : keep_if((vm[d] >> i) & 1u, vr[d][i]);
+                    if (NVR % 256 == 0 || v < NVR) *(uint4*)(ldsR + pm_off<T>(v / VPR_R, v % VPR_R, RSR)) = LEAN ? vr[d][i] : keep_if((vm[d] >> i) & 1u, vr[d][i]);
                 }
 #pragma unroll
                 for (int i = 0; i < VC; ++i) {
                     const int v = tid + i * 256;
-                    if (NVC % 256 == 0 || v < NVC) *(uint4*)(ldsC + (v / VPR_C) * RSC + (v % VPR_C) * 16) = LEAN ? vc[d][i] : keep_if((vm[d] >> (16 + i)) & 1u, vc[d][i]);
+                    if (NVC % 256 == 0 || v < NVC) *(uint4*)(ldsC + pm_off<T>(v / VPR_C, v % VPR_C, RSC)) = LEAN ? vc[d][i] : keep_if((vm[d] >> (16 + i)) & 1u, vc[d][i]);
                 }
                 __syncthreads();
                 if (cc + D < c_end) vm[d] = load_any(cc + D, vr[d], vc[d]);
