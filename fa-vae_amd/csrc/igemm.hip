@@ -134,6 +134,10 @@ struct KcParams {
     // xhat = (raw - mean) * invstd (the two reductions of the BatchNorm backward).
     double* red_bins;
     int red_nbin, red_mode;
+    // grouped-batch mode (BatchNorm groups of red_group_rows consecutive rows of this launch's row space; 0: one group): the tile's
+    // group g = m0 / red_group_rows takes bins + g * nbin * 2 * Cout and, in mode 2, mean / invstd + g * Cout.  Tiles never
+    // straddle groups: a group is 64 images, i.e. a multiple of 64 rows.
+    int red_group_rows;
     const void* red_act;
     const void* red_raw;   // fp32, or bf16 with red_raw_bf16
     const float *red_mean, *red_invstd;
@@ -510,7 +514,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
             const int red = p.red_bins ? p.red_mode : 0;   // block-uniform
             double rs[4] = {0.0, 0.0, 0.0, 0.0}, rq[4] = {0.0, 0.0, 0.0, 0.0};
             float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
-            if (red == 2 && n < p.Cout) { mu = *(const float4*)(p.red_mean + n); is = *(const float4*)(p.red_invstd + n); }
+            const int rgrp = p.red_group_rows ? m0 / p.red_group_rows : 0;   // block-uniform
+            if (red == 2 && n < p.Cout) { mu = *(const float4*)(p.red_mean + (size_t)rgrp * p.Cout + n); is = *(const float4*)(p.red_invstd + (size_t)rgrp * p.Cout + n); }
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) {
                 const int row = (ftid >> 4) + RPP * i, m = m0 + row;
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
                             t += (redsm[(4 * 2 + qq) * 64 + col] + redsm[(5 * 2 + qq) * 64 + col]) +
                                  (redsm[(6 * 2 + qq) * 64 + col] + redsm[(7 * 2 + qq) * 64 + col]);
                         const int bin = (int)((bx / p.ntn + blockIdx.z * 5u) % (unsigned)p.red_nbin);
-                        unsafeAtomicAdd(p.red_bins + ((size_t)bin * 2 + qq) * p.Cout + n0 + col, t);
+                        unsafeAtomicAdd(p.red_bins + (((size_t)rgrp * p.red_nbin + bin) * 2 + qq) * p.Cout + n0 + col, t);
                     }
                 }
                 if (red == 1 && p.fin_ab) {   // block-uniform
@@ -1101,7 +1106,7 @@ int dispatch_pm(PmParams p, hipStream_t st) {
 
 #define RC_(x) do { int rc_ = (x); if (rc_ != FAVAE_OK) return rc_; } while (0)
 namespace {
-struct RedArgs { double* bins; int nbin, mode; const void* act; const void* raw; const float *mean, *invstd; int* fused; int raw_bf16; };
+struct RedArgs { double* bins; int nbin, mode; const void* act; const void* raw; const float *mean, *invstd; int* fused; int raw_bf16; int group_images = 0; };
 struct Fin { const float *gamma, *beta; float *mean, *invstd, *ab, *run_mean, *run_var; float eps, mom; };
 
 // a ticket per launch that finalises BatchNorm statistics: slots of a zero-initialised device array handed out in rotation
@@ -1142,9 +1147,9 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
     // one thread per output pixel pays off once the pixel count fills the chip several times over (the decoder side)
     if (!in_ab && !ep_ab && g_force_kc_tile < 0 && (long long)Nb * Ho * Wo >= 131072 && thin_in_applicable(Cin, Cout, ks, stride, scatter)) {
         ProfScope prof(14, 2.0 * Nb * Ho * Wo * (double)Cout * 9 * Cin, (hipStream_t)stream);
-        ThinRed tr{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+        ThinRed tr{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
         if (red.bins && red.mode == 2 && !out_bf16 && !red.raw_bf16) {   // the statistics form (mode 1) is not needed on this path
-            tr = ThinRed{red.bins, red.nbin, red.act, (const float*)red.raw, red.mean, red.invstd};
+            tr = ThinRed{red.bins, red.nbin, red.act, (const float*)red.raw, red.mean, red.invstd, red.group_images * Ho * Wo};
             if (red.fused) *red.fused = 1;
         }
         return thin_in_launch(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, stride, scatter, dtype, out_bf16, tr, (hipStream_t)stream);
@@ -1175,6 +1180,8 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
     else { p.HoC = Ho; p.WoC = Wo; }
     p.M = Nb * p.HoC * p.WoC;
     p.ntn = 1;
+    p.red_group_rows = red.group_images > 0 ? red.group_images * p.HoC * p.WoC : 0;
+    if (p.red_group_rows) FAVAE_CHECK_ARG(p.red_group_rows % 64 == 0 && !fin, "favae_conv_igemm_red_groups: a group must be a multiple of 64 rows");
     // scatter form: four parity classes of 1 / 2 / 2 / 4 taps.  Up to 512 tiles in all the reduction stays whole (fp32 atomics of a
     // split reduction cost more than they bring: decoder.1 forward 23.5 -> 16.7 us unsplit with two reduction groups per tile,
     // and the BatchNorm sums ride in the epilogue again); below that it is split 4-way
@@ -1202,6 +1209,21 @@ extern "C" int favae_conv_igemm_red(const void* in, const void* w, const float* 
     FAVAE_CHECK_ARG(!(raw_bf16 && (dtype & 0xF) != FAVAE_BF16), "favae_conv_igemm_red: FAVAE_RAW_BF16 needs FAVAE_BF16");
     const RedArgs red{bins, nbins, mode, act, raw, mean, invstd, fused, raw_bf16};
     return conv_igemm_impl(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype & ~FAVAE_RAW_BF16, red, stream);
+}
+
+/* favae_conv_igemm_red for a batch made of BatchNorm groups of `group_images` images (grouped-batch mode): the sums of group g go
+ * to bins + g * nbins * 2 * Cout, and mode 2 reads mean / invstd of group g at + g * Cout.  group_images * Ho * Wo (of a parity
+ * class in the stride-2 scatter form) must be a multiple of 64. */
+extern "C" int favae_conv_igemm_red_groups(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi,
+                                           int Cin, int Ho, int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk,
+                                           int dtype, double* bins, int nbins, int mode, const void* act, const void* raw,
+                                           const float* mean, const float* invstd, int group_images, int* fused, void* stream) {
+    FAVAE_CHECK_ARG(bins && fused && nbins >= 1 && nbins <= 256 && group_images >= 1, "favae_conv_igemm_red_groups: bins / fused / nbins / group_images");
+    FAVAE_CHECK_ARG(mode == 1 || (mode == 2 && act && raw && mean && invstd), "favae_conv_igemm_red_groups: mode 1, or mode 2 with act/raw/mean/invstd");
+    FAVAE_CHECK_ARG(!(dtype & FAVAE_RAW_BF16), "favae_conv_igemm_red_groups: fp32 conv outputs only");
+    RedArgs red{bins, nbins, mode, act, raw, mean, invstd, fused, 0};
+    red.group_images = group_images;
+    return conv_igemm_impl(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype, red, stream);
 }
 
 extern "C" int favae_conv_igemm_bn(const void* in, const float* in_ab, const void* w, const float* bias, float* out, int Nb, int Hi,

@@ -8,7 +8,9 @@ int wgrad_nw_launch(const void* wide, const void* narrow, float* dw, int Nb, int
                     int stride, int narrow_is_large, int s_ch, int s_tap, int s_c, int dtype, hipStream_t st);
 bool thin_in_applicable(int Cs, int Co, int ks, int stride, int scatter);
 // optional BatchNorm-backward sums taken while the result is stored (bins == nullptr: none); see favae_conv_igemm_red mode 2
-struct ThinRed { double* bins; int nbin; const void* act; const float *raw, *mean, *invstd; };
+// group_pixels > 0 (grouped-batch mode): output pixels per BatchNorm group (a multiple of 256); group g = pixel / group_pixels takes
+// bins + g * nbin * 2 * Co and mean / invstd + g * Co
+struct ThinRed { double* bins; int nbin; const void* act; const float *raw, *mean, *invstd; int group_pixels; };
 int thin_in_launch(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cs, int Ho, int Wo,
                    int Co, int stride, int scatter, int dtype, int out_bf16, const ThinRed& red, hipStream_t st);
 
@@ -24,7 +26,8 @@ int fold_taps_launch(const void* src, void* dst, int Nb, int Hq, int Wq, int Hn,
 // out [P][64] fp32 = fold [P][32] (bf16, columns >= K zero) x w [64][K]^T (bf16) + bias; optional BatchNorm sums (sum, sum of
 // squares per channel, fp64) added to bins [nbin][2][64].  See folded_fwd_kernel.
 // split != 0: fold holds the hi and the lo plane of fold_taps_hl_launch ([2][P][32]) and w is the fp32 weight [64][K].
+// groups > 1 (grouped-batch mode): P / groups pixels per BatchNorm group (a multiple of 32), bins [groups][nbin][2][64]
 int folded_fwd_launch(const void* fold, const void* w, int K, const float* bias, float* out, long long P, double* bins, int nbin,
-                      int split, hipStream_t st);
+                      int split, hipStream_t st, int groups = 1);
 // fold_taps (shifted = 0) of an fp32 source into two bf16 planes: dst [P][32] = bf16(x), dst + P * 32 = bf16(x - bf16(x))
 int fold_taps_hl_launch(const float* src, void* dst, int Nb, int Hq, int Wq, int Hn, int Wn, int Cs, int stride, hipStream_t st);

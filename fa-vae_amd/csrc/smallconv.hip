@@ -174,9 +174,10 @@ __global__ __launch_bounds__(256) void conv_thin_in(const T* __restrict__ in, co
         ActVec pa[64 / PPI];
         float4 px[64 / PPI];
         float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
+        const int rgrp = (RED && red.group_pixels) ? (int)(blockIdx.x * 256u) / red.group_pixels : 0;   // block-uniform
         if (RED) {
-            mu = *(const float4*)(red.mean + hb + (lane % LPR) * 4);
-            is = *(const float4*)(red.invstd + hb + (lane % LPR) * 4);
+            mu = *(const float4*)(red.mean + rgrp * CO + hb + (lane % LPR) * 4);
+            is = *(const float4*)(red.invstd + rgrp * CO + hb + (lane % LPR) * 4);
 #pragma unroll
             for (int i = 0; i < 64 / PPI; ++i) {
                 const int prow = min(pix_w0 + i * PPI + lane / LPR, total - 1);
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_thin_in(const T* __restrict__ in, co
                 const int qq = threadIdx.x / HC, col = threadIdx.x % HC;
                 const double t = (redsm[(0 * 2 + qq) * HC + col] + redsm[(1 * 2 + qq) * HC + col]) +
                                  (redsm[(2 * 2 + qq) * HC + col] + redsm[(3 * 2 + qq) * HC + col]);
-                unsafeAtomicAdd(red.bins + ((size_t)(blockIdx.x % (unsigned)red.nbin) * 2 + qq) * CO + hb + col, t);
+                unsafeAtomicAdd(red.bins + (((size_t)rgrp * red.nbin + blockIdx.x % (unsigned)red.nbin) * 2 + qq) * CO + hb + col, t);
             }
             __syncthreads();
         }
@@ -365,8 +366,12 @@ __device__ __forceinline__ f32x16 mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, f32x16 
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void folded_fwd_kernel(const bf16_t* __restrict__ fold, const void* __restrict__ w_, int K,
                                                          const float* __restrict__ bias, float* __restrict__ out, int P,
-                                                         double* __restrict__ bins, int nbin, const FlagCarry carry) {
+                                                         double* __restrict__ bins, int nbin, const FlagCarry carry, int plane) {
     carry_store(carry);
+    // blockIdx.y = BatchNorm group (grouped-batch mode): P pixels of the `plane` pixels of the launch, bins of its own
+    fold += (size_t)blockIdx.y * P * 32;
+    out += (size_t)blockIdx.y * P * 64;
+    if (bins) bins += (size_t)blockIdx.y * nbin * 2 * 64;
     __shared__ __attribute__((aligned(16))) bf16_t wl[(SPLIT ? 2 : 1) * 64 * 40];   // [cout][32] + 8 columns of padding (80-byte rows: conflict-free 16-B reads)
     __shared__ double redsm[4 * 2 * 64];
     for (int i = threadIdx.x; i < 64 * 32; i += 256) {
@@ -409,8 +414,8 @@ __global__ __launch_bounds__(256) void folded_fwd_kernel(const bf16_t* __restric
         for (int i = 0; i < 16; ++i) { c0[i] = bias0; c1[i] = bias1; }
         if constexpr (SPLIT) {   // smallest terms first
             U x0, x1;
-            x0.u = *(const uint4*)(fold + ((size_t)P + pa) * 32 + h * 8);
-            x1.u = *(const uint4*)(fold + ((size_t)P + pa) * 32 + 16 + h * 8);
+            x0.u = *(const uint4*)(fold + ((size_t)plane + pa) * 32 + h * 8);
+            x1.u = *(const uint4*)(fold + ((size_t)plane + pa) * 32 + 16 + h * 8);
             c0 = mfma_bf16_32x32x16(x0.b, b00.b, c0);
             c0 = mfma_bf16_32x32x16(x1.b, b01.b, c0);
             c1 = mfma_bf16_32x32x16(x0.b, b10.b, c1);
@@ -455,16 +460,18 @@ __global__ __launch_bounds__(256) void folded_fwd_kernel(const bf16_t* __restric
 }  // namespace
 
 int folded_fwd_launch(const void* fold, const void* w, int K, const float* bias, float* out, long long P, double* bins, int nbin,
-                      int split, hipStream_t st) {
+                      int split, hipStream_t st, int groups) {
     const FlagCarry carry = favae_take_flag_carry();
-    const int ngroup = (int)((P + 31) / 32);
-    const int grid = std::max(1, std::min(512, (ngroup + 3) / 4));
+    FAVAE_CHECK_ARG(groups >= 1 && P % groups == 0 && (groups == 1 || (P / groups) % 32 == 0), "folded forward: %lld pixels in %d groups", P, groups);
+    const int Pg = (int)(P / groups);
+    const int ngroup = (Pg + 31) / 32;
+    const int grid = std::max(1, std::min(std::max(64, 512 / groups), (ngroup + 3) / 4));
     if (split)
-        hipLaunchKernelGGL(folded_fwd_kernel<true>, dim3(grid), dim3(256), 0, st, (const bf16_t*)fold, w, K, bias, out, (int)P, bins,
-                           std::max(1, nbin), carry);
+        hipLaunchKernelGGL(folded_fwd_kernel<true>, dim3(grid, groups), dim3(256), 0, st, (const bf16_t*)fold, w, K, bias, out, Pg, bins,
+                           std::max(1, nbin), carry, (int)P);
     else
-        hipLaunchKernelGGL(folded_fwd_kernel<false>, dim3(grid), dim3(256), 0, st, (const bf16_t*)fold, w, K, bias, out, (int)P, bins,
-                           std::max(1, nbin), carry);
+        hipLaunchKernelGGL(folded_fwd_kernel<false>, dim3(grid, groups), dim3(256), 0, st, (const bf16_t*)fold, w, K, bias, out, Pg, bins,
+                           std::max(1, nbin), carry, (int)P);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

@@ -345,6 +345,8 @@ void choose_storage(Vae& v) {
     }
 }
 
+int bins_for(long long rows);
+
 void carve(Vae& v, char* base, size_t cap, size_t* need) {
     choose_storage(v);
     Carver c{base, 0, cap};
@@ -362,10 +364,13 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
         }
     }
     v.dz = (float*)c.take((size_t)B * v.z * 4);
+    // grouped-batch mode (Bmax > 64: up to Bmax / 64 BatchNorm groups per step): every BatchNorm layer has bins, per group
+    const int Gmax = std::max(1, B / 64);
     for (int l = 0; l < NL; ++l) {
-        const bool use = v.L[l].bn && v.L[l].Cout <= 256;
-        v.sbins[l] = use ? (double*)c.take((size_t)MAX_BINS * 2 * v.L[l].Cout * 8) : nullptr;
-        v.gbins[l] = use ? (double*)c.take((size_t)MAX_BINS * 2 * v.L[l].Cout * 8) : nullptr;
+        const bool use = v.L[l].bn && (v.L[l].Cout <= 256 || Gmax > 1);
+        const size_t nb = Gmax > 1 ? (size_t)Gmax * bins_for(v.rows(l, 64)) : (size_t)MAX_BINS;   // (a step of <= 64 images never needs more)
+        v.sbins[l] = use ? (double*)c.take(nb * 2 * v.L[l].Cout * 8) : nullptr;
+        v.gbins[l] = use ? (double*)c.take(nb * 2 * v.L[l].Cout * 8) : nullptr;
         v.stats_fused[l] = v.grad_fused[l] = false;
     }
     {
@@ -380,8 +385,8 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
         }
         v.act[l] = (char*)c.take(n * v.esz);
         v.draw[l] = (char*)c.take(n * v.esz);
-        v.mean[l] = (float*)c.take((size_t)v.L[l].Cout * 4);
-        v.invstd[l] = (float*)c.take((size_t)v.L[l].Cout * 4);
+        v.mean[l] = (float*)c.take((size_t)Gmax * v.L[l].Cout * 4);
+        v.invstd[l] = (float*)c.take((size_t)Gmax * v.L[l].Cout * 4);
         v.ab[l] = (float*)c.take((size_t)v.L[l].Cout * 8);
         v.dbp[l] = v.L[l].bn ? (double*)c.take((size_t)DBP_SLABS * v.L[l].Cout * 8) : nullptr;
     }
@@ -511,6 +516,24 @@ int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false
     const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_OUT_BF16 : 0);
     v.stats_fused[l] = false;
     v.bn_published[l] = false;
+    if (pooled && B > 64 && L.bn) {
+        // grouped-batch mode: B / 64 BatchNorm groups in one launch; the statistics of every group come from the GEMM epilogue
+        // (bins per group) or, where the launch split its reduction, from a pass over the output
+        const int G = B / 64, nb = bins_for(v.rows(l, 64));
+        int fused = 0;
+        if (l == 0 && v.fwd_folded && L.Cout == 64) {
+            RC(folded_fwd_launch(v.fold0, v.hp ? (const void*)(v.P + L.w_off) : v.Wf(0), 9 * v.ch, bias, v.raw[0], v.rows(0, B), v.sbins[0], nb,
+                                 v.hp ? 1 : 0, (hipStream_t)st, G));
+            fused = 1;
+        } else {
+            const int scatter = L.kind == CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
+            RC(favae_conv_igemm_red_groups(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, stride, 1, scatter, sk,
+                                           v.dtype, v.sbins[l], nb, 1, nullptr, nullptr, nullptr, nullptr, 64, &fused, st));
+        }
+        if (!fused) RC(favae_gbn_sums(v.raw[l], nullptr, nullptr, nullptr, nullptr, v.sbins[l], nb, G, v.rows(l, 64), L.Cout, 1, v.dtype, st));
+        v.stats_fused[l] = true;
+        return FAVAE_OK;
+    }
     if (l == 0 && v.fwd_folded && pooled && fi < 0 && (v.fuse & 1u) && v.sbins[0] && !v.raw_bf[0]) {
         // encoder.0 of the training step as a K = 32 GEMM over the tap-folded batch (smallconv.hip, folded_fwd_kernel)
         RC(folded_fwd_launch(v.fold0, v.hp ? (const void*)(v.P + L.w_off) : v.Wf(0), 9 * v.ch, bias, v.raw[0], v.rows(0, B), v.sbins[0],
@@ -570,6 +593,11 @@ int bn_fwd(Vae& v, int l, int B, bool train, void* st) {
     const Layer& L = v.L[l];
     const long long R = v.rows(l, B);
     const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0);
+    if (train && B > 64 && v.stats_fused[l]) {   // grouped-batch mode
+        v.stats_fused[l] = false;
+        return favae_gbn_fwd(v.raw[l], v.sbins[l], bins_for(v.rows(l, 64)), v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l], v.invstd[l],
+                             v.BUF + L.rm_off, v.BUF + L.rv_off, B / 64, v.rows(l, 64), L.Cout, 1e-5f, 0.1f, v.dtype, st);
+    }
     if (train && v.bn_published[l]) {   // the producing GEMM finished the statistics (mean, invstd, running stats, a | b)
         v.bn_published[l] = v.stats_fused[l] = false;
         return favae_bn_lrelu_fwd_ab(v.raw[l], v.ab[l], v.act[l], R, L.Cout, v.dtype, st);
@@ -673,6 +701,15 @@ int decoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false, bool s
 
 int bn_bwd(Vae& v, int l, int B, void* st) {
     const Layer& L = v.L[l];
+    if (B > 64) {   // grouped-batch mode: the two sums per group from the epilogue of the GEMM that produced dact[l], else from a pass
+        const int G = B / 64, nb = bins_for(v.rows(l, 64));
+        if (!v.grad_fused[l])
+            RC(favae_gbn_sums(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.gbins[l], nb, G, v.rows(l, 64), L.Cout, 2, v.dtype, st));
+        v.grad_fused[l] = false;
+        v.dbias_slabs[l] = 0;
+        return favae_gbn_bwd(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.gbins[l], nb, v.draw[l], v.G + L.g_off,
+                             v.G + L.be_off, v.G + L.b_off, G, v.rows(l, 64), L.Cout, v.dtype, st);
+    }
     if (v.grad_fused[l]) {   // the GEMM that produced dact[l] summed the two reductions in its epilogue
         v.grad_fused[l] = false;
         // the bias gradient (column sums of draw: rounding noise in front of a BatchNorm) is finished beside the main chain, by the
@@ -875,6 +912,14 @@ int dgrad(Vae& v, int l, float* out, int B, void* st, bool out_zeroed, bool out_
     const Layer& L = v.L[l];
     const int sk = out_zeroed ? -1 : 0;
     const int dt = v.dtype | (out_bf ? FAVAE_OUT_BF16 : 0);
+    if (o >= 0 && B > 64 && v.gbins[o] && L.kind != LINEAR && !out_bf) {   // grouped-batch mode: sums per BatchNorm group of layer o
+        const int scatter = L.kind != CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
+        int fused = 0;
+        RC(favae_conv_igemm_red_groups(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, stride, 1, scatter, sk,
+                                       v.dtype, v.gbins[o], bins_for(v.rows(o, 64)), 2, v.act[o], v.raw[o], v.mean[o], v.invstd[o], 64, &fused, st));
+        v.grad_fused[o] = fused != 0;
+        return FAVAE_OK;
+    }
     if (o >= 0 && (v.fuse & (l == L_OUT ? 4u : 2u)) && v.gbins[o] && L.kind != LINEAR) {
         const int scatter = L.kind != CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
         int fused = 0;
@@ -1119,7 +1164,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
         // BatchNorm + LeakyReLU is redone per tap and the fp32 source doubles the operand bytes: +6.6 us per consumer GEMM
         // (final_layer.0: +25 us) against 7.5-8 us per apply launch, and the last-block finalisation adds ~8 us per producer
         // (tools/bench_fi.py; step 1.06 -> 1.15 ms).  Kept as a tested option.
-        v.fi_on = epoch && !v.dp_epoch && v.overlap && (v.fuse & 0x40000u);
+        v.fi_on = epoch && !v.dp_epoch && v.overlap && (v.fuse & 0x40000u) && B <= 64;
         v.fi_npend = 0; v.acts_wait = false;
         v.merged = epoch && !v.dp_epoch && v.ada.on && !(v.fuse & 0x10000u);
         v.upd_half = v.merged ? (v.sh_sel ^ 1) : v.sh_sel;
@@ -1343,6 +1388,7 @@ extern "C" int favae_vae_train_fwdbwd(favae_vae* h, const float* data_nhwc, cons
     FAVAE_CHECK_ARG(h && data_nhwc && eps && metrics2_out, "favae_vae_train_fwdbwd: null pointer");
     Vae& v = h->v;
     FAVAE_CHECK_ARG(B >= 1 && B <= v.Bmax, "favae_vae_train_fwdbwd: batch %d outside [1, %d]", B, v.Bmax);
+    FAVAE_CHECK_ARG(B <= 64 || B % 64 == 0, "favae_vae_train_fwdbwd: a batch above 64 is a set of BatchNorm groups of 64 (got %d)", B);
     return train_stages(v, data_nhwc, idx, B, eps, prior, tau, beta, var_x, metrics2_out, 0, N_STAGES, st);
 }
 
@@ -1358,6 +1404,7 @@ extern "C" int favae_vae_train_stages(favae_vae* h, const float* data_nhwc, cons
     FAVAE_CHECK_ARG(h && data_nhwc && eps && metrics2_out, "favae_vae_train_stages: null pointer");
     Vae& v = h->v;
     FAVAE_CHECK_ARG(B >= 1 && B <= v.Bmax, "favae_vae_train_stages: batch %d outside [1, %d]", B, v.Bmax);
+    FAVAE_CHECK_ARG(B <= 64 || B % 64 == 0, "favae_vae_train_stages: a batch above 64 is a set of BatchNorm groups of 64 (got %d)", B);
     FAVAE_CHECK_ARG(stage_lo >= 0 && stage_lo <= stage_hi && stage_hi <= N_STAGES, "favae_vae_train_stages: stages [%d, %d)", stage_lo, stage_hi);
     return train_stages(v, data_nhwc, idx, B, eps, prior, tau, beta, var_x, metrics2_out, stage_lo, stage_hi, st);
 }
@@ -1474,20 +1521,39 @@ int check_wait_timeout(Vae& v) {
 }
 }  // namespace
 
-/* A whole epoch of steps on one device: perm [n] sample order, eps [n][z] in visiting order, metrics [nsteps][2].
- * Equivalent to the inner loop :227-255 with batch size `batch`; the last batch may be short. */
+// images of the step that starts with `rem` images left: `batch`, or what is left; in grouped-batch mode (batch > 64) the tail of
+// an epoch is a step of its whole groups of 64 followed by a step of the rest
+static int step_images(long long rem, int batch) {
+    long long B = std::min<long long>(batch, rem);
+    if (B > 64 && B % 64) B = B / 64 * 64;
+    return (int)B;
+}
+/* Steps of an epoch over n images with `batch` images per step (rows of `metrics`): ceil(n / batch), plus one in grouped-batch mode
+ * when the last batch is more than 64 images and not a whole number of groups. */
+extern "C" long long favae_vae_epoch_steps(long long n, int batch) {
+    if (n < 1 || batch < 1) return 0;
+    long long s = n / batch;
+    for (long long rem = n % batch; rem > 0; ++s) rem -= step_images(rem, batch);
+    return s;
+}
+
+/* A whole epoch of steps on one device: perm [n] sample order, eps [n][z] in visiting order, metrics [favae_vae_epoch_steps][2].
+ * Equivalent to the inner loop :227-255 with batch size `batch`; the last batch may be short.  batch > 64 (a multiple of 64) is the
+ * grouped-batch mode: batch / 64 BatchNorm groups per optimiser step (include/favae_hip.h). */
 extern "C" int favae_vae_train_epoch(favae_vae* h, const float* data_nhwc, const int* perm, long long n, int batch,
                                      const float* eps, const double* prior, float tau, float beta, float var_x, float lr,
                                      long long step0, double* metrics, void* st) {
     FAVAE_CHECK_ARG(h && perm && metrics && n >= 1 && batch >= 1, "favae_vae_train_epoch: bad argument");
+    FAVAE_CHECK_ARG(batch <= 64 || batch % 64 == 0, "favae_vae_train_epoch: a batch above 64 is a whole number of BatchNorm groups of 64 (got %d)", batch);
     Vae& v = h->v;
     long long s = 0;
     RC(check_wait_timeout(v));
     if (v.overlap) FAVAE_HIP(hipMemsetAsync(v.G, 0, (size_t)v.nparam * 4, (hipStream_t)st));   // the steps keep it cleared
     RC(epoch_worker_start(v, (n + batch - 1) / batch, (hipStream_t)st, 1u | 2u | 8u));   // main, weight-gradient and optimiser stream
     int rc = FAVAE_OK;
-    for (long long o = 0; o < n && rc == FAVAE_OK; o += batch, ++s) {
-        const int B = (int)std::min<long long>(batch, n - o);
+    for (long long o = 0, Bs = 0; o < n && rc == FAVAE_OK; o += Bs, ++s) {
+        const int B = step_images(n - o, batch);
+        Bs = B;
         if (v.overlap) {   // optimiser step layer by layer behind the weight gradients (same arithmetic, see adam_layer)
             v.ada = {true, lr, 0.9f, 0.999f, 1e-8f, step0 + s + 1, true};
             rc = favae_vae_train_fwdbwd(h, data_nhwc, perm + o, B, eps + o * v.z, prior, tau, beta, var_x, metrics + 2 * s, st);
@@ -1522,6 +1588,7 @@ extern "C" int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float
                                         const float* eps, const double* prior, float tau, float beta, float var_x, float lr,
                                         long long step0, double* metrics, void* st) {
     FAVAE_CHECK_ARG(h && c && perm && metrics && n >= 1 && batch >= 1, "favae_vae_train_epoch_dp: bad argument");
+    FAVAE_CHECK_ARG(batch <= 64 || batch % 64 == 0, "favae_vae_train_epoch_dp: a batch above 64 is a whole number of BatchNorm groups of 64 (got %d)", batch);
     Vae& v = h->v;
     FAVAE_CHECK_ARG(v.overlap, "favae_vae_train_epoch_dp needs the weight-gradient stream (FAVAE_SINGLE_STREAM is set)");
     RC(check_wait_timeout(v));
@@ -1547,8 +1614,9 @@ extern "C" int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float
     int rc = FAVAE_OK;
     long long s = 0;
     v.dp_epoch = true;
-    for (long long o = 0; o < n && rc == FAVAE_OK; o += batch, ++s) {
-        const int B = (int)std::min<long long>(batch, n - o);
+    for (long long o = 0, Bs = 0; o < n && rc == FAVAE_OK; o += Bs, ++s) {
+        const int B = step_images(n - o, batch);
+        Bs = B;
         int lo = 0;
         for (int b = 0; b < NBK && rc == FAVAE_OK; ++b) {
             rc = train_stages(v, data_nhwc, perm + o, B, eps + o * v.z, prior, tau, beta, var_x, metrics + 2 * s, lo, bk[b].stage_hi, st);

@@ -17,7 +17,7 @@ _f = ctypes.c_float
 _sz = ctypes.c_size_t
 
 _raw = L.raw()
-for _n in ("favae_vae_param_count", "favae_vae_buffer_count", "favae_vae_shadow_bytes", "favae_vae_workspace_bytes"):
+for _n in ("favae_vae_param_count", "favae_vae_buffer_count", "favae_vae_shadow_bytes", "favae_vae_workspace_bytes", "favae_vae_epoch_steps"):
     getattr(_raw, _n).restype = _ll
 
 KIND_CONV_S2, KIND_LINEAR, KIND_CONVT_S2, KIND_CONV_S1 = 0, 1, 2, 3
@@ -261,13 +261,21 @@ class VaeEngine:
         self.step += 1
         L.check(_raw.favae_vae_adam(self.h, _f(lr), _f(0.9), _f(0.999), _f(1e-8), _ll(self.step), L.stream_ptr()))
 
+    @staticmethod
+    def epoch_steps(n, batch):
+        """Optimiser steps (= rows of `metrics`) of an epoch over n images: ceil(n / batch), plus one in grouped-batch mode
+        (batch > 64) when the last batch is not a whole number of BatchNorm groups (favae_vae_epoch_steps)."""
+        return int(_raw.favae_vae_epoch_steps(_ll(n), _i(batch)))
+
     def train_epoch(self, data, perm, eps, prior, tau, beta, var_x, lr, batch, metrics):
         n = perm.numel()
+        if metrics.shape[0] < self.epoch_steps(n, batch):
+            raise ValueError("train_epoch: metrics has %d rows, the epoch has %d steps" % (metrics.shape[0], self.epoch_steps(n, batch)))
         self._fmt(data)
         L.check(_raw.favae_vae_train_epoch(self.h, L.ptr(data), L.ptr(perm), _ll(n), _i(batch), L.ptr(eps), L.ptr(prior),
                                            _f(tau), _f(beta), _f(var_x), _f(lr), _ll(self.step), L.ptr(metrics),
                                            L.stream_ptr()))
-        self.step += (n + batch - 1) // batch
+        self.step += self.epoch_steps(n, batch)
 
     def train_epoch_dp(self, comm, data, perm, eps, prior, tau, beta, var_x, lr, batch, metrics):
         """One data-parallel epoch in one call: bucketed gradient all-reduce + bucket-wise Adam on the communicator's stream."""
@@ -276,7 +284,7 @@ class VaeEngine:
         L.check(_raw.favae_vae_train_epoch_dp(self.h, comm, L.ptr(data), L.ptr(perm), _ll(n), _i(batch), L.ptr(eps), L.ptr(prior),
                                               _f(tau), _f(beta), _f(var_x), _f(lr), _ll(self.step), L.ptr(metrics),
                                               L.stream_ptr()))
-        self.step += (n + batch - 1) // batch
+        self.step += self.epoch_steps(n, batch)
 
     def poll_error(self):
         """Raise if a dependency wait of an earlier epoch gave up (favae_vae_poll_error); call after a synchronisation."""

@@ -61,6 +61,10 @@ class ImgVAE(VAE):
     ALWAYS_FA_PRIOR = False     # celeba2cartoon: trainloop has no `favae` flag, the FA prior is always used
     UPDATE_X_USES_SELF_IMG = False   # celeba2cartoon/betaVAE iterate self.img whatever `img` is (:244)
     BATCH = 64                  # DataLoader(batch_size=64), :218
+    # Grouped-batch mode (no counterpart in the reference; off = 1): GROUPS mini-batches of BATCH images per optimiser step, each
+    # with BatchNorm statistics of its own, gradients averaged: the step a GROUPS-rank data-parallel run takes, on one GPU.  The
+    # trajectory differs from the reference's (1 / GROUPS as many, larger steps); the visiting order and the noise are the same.
+    GROUPS = int(os.environ.get("FAVAE_GROUPS", "1"))
     CHECKPOINT_INFIX = "_celeba_vanilla_"   # file name of restore_weights' checkpoint (:308-314); celeba2cartoon uses "8"
     # restore_weights keeps its best-ELBO checkpoint on the device; with write_checkpoints the file the reference writes
     # (./checkpoints/<dataset><infix><latentspace_lr>.pt, {epoch, elbo, state_dict, optimizer}) is also written, once per
@@ -114,7 +118,8 @@ class ImgVAE(VAE):
         if self._eng is None:
             from .engine import VaeEngine
             torch.cuda.set_device(self.device)
-            self._eng = VaeEngine(self.dimx, self.channels, batch_max=self.BATCH, dtype=self.precision, device=self.device)
+            self._eng = VaeEngine(self.dimx, self.channels, batch_max=self.BATCH * max(1, int(self.GROUPS)), dtype=self.precision,
+                                  device=self.device)
             self._synced_version = None
         if self._synced_version != self._version():
             self._push()
@@ -289,7 +294,10 @@ class ImgVAE(VAE):
         if dist.active() and dist.max_scalar(n_loc, self.device) - n >= self.BATCH and not getattr(self, "_warned_shards", False):
             self._warned_shards = True
             print("favae_hip: unbalanced shards: ranks with more than %d rows skip the surplus in each VAE epoch" % n)
-        nb = (n + self.BATCH - 1) // self.BATCH
+        step_batch = self.BATCH * max(1, min(int(self.GROUPS), e.batch_max // self.BATCH))
+        if dist.active() and dist.native_comm(self.device) is None:
+            step_batch = self.BATCH     # (the torch.distributed rehearsal path below steps one mini-batch per rank)
+        nb = e.epoch_steps(n, step_batch)
         metrics = torch.zeros(nb, 2, dtype=torch.float64, device=self.device)
         elbo_checker = -1e20
         for ep in range(int(epochs)):
@@ -301,12 +309,12 @@ class ImgVAE(VAE):
             eps = torch.cat([torch.randn(min(self.BATCH, n - s), self.dimx) for s in range(0, n, self.BATCH)], 0)
             perm_d, eps_d = perm.to(torch.int32).to(self.device), eps.to(self.device)
             if not dist.active():
-                e.train_epoch(data, perm_d, eps_d, prior, tau_f, float(beta), float(self.var_x), float(self.lr), self.BATCH, metrics)
+                e.train_epoch(data, perm_d, eps_d, prior, tau_f, float(beta), float(self.var_x), float(self.lr), step_batch, metrics)
             elif dist.native_comm(self.device) is not None:
                 # data parallel over the N shards, RCCL driven from the executor's own launch loop: one call per epoch
                 # (bucketed all-reduce + bucket-wise Adam under the backward pass; favae_vae_train_epoch_dp)
                 e.train_epoch_dp(dist.native_comm(self.device), data, perm_d, eps_d, prior, tau_f, float(beta), float(self.var_x),
-                                 float(self.lr), self.BATCH, metrics)
+                                 float(self.lr), step_batch, metrics)
                 dist.mean_(metrics)
                 dist.mean_(e.BUF)
             else:

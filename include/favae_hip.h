@@ -82,6 +82,27 @@ int favae_conv_igemm_red(const void* in, const void* w, const float* bias, float
  *     LeakyReLU and in_ab the (a | b) its launch published; the activation lrelu(in * a[c] + b[c]), rounded to dtype, is formed
  *     when a chunk of the A operand goes to LDS.  Cin in {64, 128, 192, 256}, Cout > 32.  The materialised activation, where the
  *     backward pass wants it, is favae_bn_lrelu_fwd_ab(in, in_ab, ...): same bytes. */
+/* Grouped-batch mode (no counterpart launch in the reference; SURVEY.md 7 "Hard parts": a larger batch per step with the BatchNorm
+ * group size kept at the reference's 64, celeba_deepvanilla_vae.py:218 with nn.BatchNorm2d :34,58,72).  A batch of G x 64 images
+ * whose BatchNorm statistics are taken per group of 64: with the mean loss this is the G-rank data-parallel step on
+ * one GPU.  favae_conv_igemm_red_groups = favae_conv_igemm_red with the sums of group g at bins + g * nbins * 2 * Cout (mode 2 reads
+ * mean / invstd [G][Cout]); favae_gbn_sums fills such bins for a tensor whose producer could not; favae_gbn_fwd / favae_gbn_bwd are
+ * BatchNorm(train) + LeakyReLU forward / backward of the G groups (running statistics: average over the groups of the batch
+ * statistics; dgamma / dbeta / dbias are ADDED to).  Tensors [G * Rg][C] NHWC, C <= 1024 dividing 1024. */
+int favae_conv_igemm_red_groups(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cin, int Ho,
+                                int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk, int dtype, double* bins,
+                                int nbins, int mode, const void* act, const void* raw, const float* mean, const float* invstd,
+                                int group_images, int* fused, void* stream);
+int favae_gbn_sums(const float* y, const void* act, const float* raw, const float* mean, const float* invstd, double* bins, int nbins,
+                   int G, long long Rg, int C, int mode, int dtype, void* stream);
+int favae_gbn_fwd(const float* raw, const double* bins, int nbins, const float* gamma, const float* beta, void* act, float* mean,
+                  float* invstd, float* run_mean, float* run_var, int G, long long Rg, int C, float eps, float momentum, int dtype,
+                  void* stream);
+long long favae_vae_epoch_steps(long long n, int batch);
+int favae_gbn_bwd(const float* dact, const void* act, const float* raw, const float* mean, const float* invstd, const float* gamma,
+                  const double* bins, int nbins, void* draw, float* dgamma, float* dbeta, float* dbias, int G, long long Rg, int C,
+                  int dtype, void* stream);
+
 int favae_conv_igemm_bn(const void* in, const float* in_ab, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi,
                         int Cin, int Ho, int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk, int dtype,
                         double* bins, int nbins, const float* gamma, const float* beta, float eps, float momentum, float* mean,
