@@ -33,8 +33,9 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, float a, floa
 // ---- sums of a tensor whose producer could not take them in its epilogue ------------------------------------------------
 // MODE 1: (sum y, sum y^2) of y = raw;  MODE 2: (sum dd, sum dd * xhat) with dd = y * lrelu'(act), xhat = (raw - mean) * invstd, y = dact.
 // grid (C / 64, slabs, G), 256 threads = 16 channel quads x 16 row lanes; 128 fp64 atomics per block into bins[g][slab % nbin].
-template <class T, int MODE>
-__global__ __launch_bounds__(256) void gbn_sums_kernel(const float* __restrict__ y, const T* __restrict__ act, const float* __restrict__ raw,
+// (T: activation storage; YT: storage of y; RT: storage of raw)
+template <class T, class YT, class RT, int MODE>
+__global__ __launch_bounds__(256) void gbn_sums_kernel(const YT* __restrict__ y, const T* __restrict__ act, const RT* __restrict__ raw,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        double* __restrict__ bins, int nbin, int Rg, int C, int rps) {
     __shared__ double sm[2][16][64];
@@ -46,12 +47,12 @@ __global__ __launch_bounds__(256) void gbn_sums_kernel(const float* __restrict__
     if (MODE == 2) { mu = *(const float4*)(mean + (size_t)g * C + c0); is = *(const float4*)(invstd + (size_t)g * C + c0); }
     for (int r = r0 + rl; r < r1; r += 16) {
         const size_t e = ((size_t)g * Rg + r) * C + c0;
-        const float4 v = *(const float4*)(y + e);
+        const float4 v = ld4<YT>(y + e);
         if (MODE == 1) {
             s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
             q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
         } else {
-            const float4 a = ld4<T>(act + e), x = *(const float4*)(raw + e);
+            const float4 a = ld4<T>(act + e), x = ld4<RT>(raw + e);
             const float d0 = v.x * (a.x > 0.f ? 1.f : 0.01f), d1 = v.y * (a.y > 0.f ? 1.f : 0.01f);
             const float d2 = v.z * (a.z > 0.f ? 1.f : 0.01f), d3 = v.w * (a.w > 0.f ? 1.f : 0.01f);
             s[0] += d0; s[1] += d1; s[2] += d2; s[3] += d3;
@@ -71,31 +72,29 @@ __global__ __launch_bounds__(256) void gbn_sums_kernel(const float* __restrict__
     }
 }
 
-// per-block prologue: totals of the group's bins for every channel -> coefficient arrays in LDS
-// tot0[c], tot1[c] for c < C (C <= 1024), 256 threads
-__device__ __forceinline__ void group_totals(const double* __restrict__ bins, int nbin, int C, int g, double* t0, double* t1) {
+// totals of the group's bins for channel c (the threads of a block take consecutive channels: coalesced over c)
+__device__ __forceinline__ void group_totals(const double* __restrict__ bins, int nbin, int C, int g, int c, double& t0, double& t1) {
     const double* b = bins + (size_t)g * nbin * 2 * C;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        double a = 0.0, q = 0.0;
-        for (int k = 0; k < nbin; ++k) { a += b[((size_t)k * 2) * C + c]; q += b[((size_t)k * 2 + 1) * C + c]; }
-        t0[c] = a; t1[c] = q;
-    }
-    __syncthreads();
+    double a = 0.0, q = 0.0;
+    for (int k = 0; k < nbin; ++k) { a += b[((size_t)k * 2) * C + c]; q += b[((size_t)k * 2 + 1) * C + c]; }
+    t0 = a; t1 = q;
 }
 
 // ---- forward: act = lrelu((raw - mean_g) * invstd_g * gamma + beta); block 0 of a group publishes mean / invstd of the group -----
 // grid (blocks per group, G); the element stride of a block round is 1024, a multiple of C, so a thread keeps its 4 channels.
-template <class T>
-__global__ __launch_bounds__(256) void gbn_fwd_kernel(const float* __restrict__ raw, const double* __restrict__ bins, int nbin,
+template <class T, class RT>
+__global__ __launch_bounds__(256) void gbn_fwd_kernel(const RT* __restrict__ raw, const double* __restrict__ bins, int nbin,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ act,
                                                       float* __restrict__ mean, float* __restrict__ invstd, int Rg, int C, float eps) {
-    __shared__ double t0[1024], t1[1024];
+    // (8 KB of LDS: the 2048 blocks of a G = 8 launch are resident at once; with the fp64 totals staged in LDS too, 24 KB, only
+    // 1536 were and the launch ran a second, third-full round)
     __shared__ float ab[2048];
     const int g = blockIdx.y, tid = threadIdx.x;
-    group_totals(bins, nbin, C, g, t0, t1);
     for (int c = tid; c < C; c += 256) {
-        const double m = t0[c] / (double)Rg;
-        double var = t1[c] / (double)Rg - m * m;
+        double t0, t1;
+        group_totals(bins, nbin, C, g, c, t0, t1);
+        const double m = t0 / (double)Rg;
+        double var = t1 / (double)Rg - m * m;
         if (var < 0) var = 0;
         const float is = (float)(1.0 / sqrt(var + (double)eps));
         const float a = is * gamma[c];
@@ -110,7 +109,7 @@ __global__ __launch_bounds__(256) void gbn_fwd_kernel(const float* __restrict__ 
     const float b0 = ab[C + c], b1 = ab[C + c + 1], b2 = ab[C + c + 2], b3 = ab[C + c + 3];
 #pragma unroll 4
     for (size_t i = (size_t)blockIdx.x * 256 + tid; i < nvec; i += (size_t)gridDim.x * 256) {
-        const float4 x = *(const float4*)(raw + base + i * 4);
+        const float4 x = ld4<RT>(raw + base + i * 4);
         st4<T>(act + base + i * 4, lrelu_g(x.x * a0 + b0), lrelu_g(x.y * a1 + b1), lrelu_g(x.z * a2 + b2), lrelu_g(x.w * a3 + b3));
     }
 }
@@ -135,33 +134,36 @@ __global__ void gbn_running_kernel(const float* __restrict__ mean, const float* 
 
 // ---- backward: draw = gamma invstd_g (dd - s1_g / Rg - xhat s2_g / Rg); dgamma += s2_g, dbeta += s1_g (block 0 of a group),
 // dbias += column sums of draw (the bias of the convolution in front of the BatchNorm: analytically zero, rounding noise) ----------
-template <class T>
-__global__ __launch_bounds__(256) void gbn_bwd_kernel(const float* __restrict__ dact, const T* __restrict__ act, const float* __restrict__ raw,
+template <class T, class DT, class RT>
+__global__ __launch_bounds__(256) void gbn_bwd_kernel(const DT* __restrict__ dact, const T* __restrict__ act, const RT* __restrict__ raw,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ gamma, const double* __restrict__ bins, int nbin,
                                                       T* __restrict__ draw, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                       float* __restrict__ dbias, int Rg, int C) {
-    __shared__ double t0[1024], t1[1024];
+    __shared__ float kk[2048];
     __shared__ float cs[1024];
     const int g = blockIdx.y, tid = threadIdx.x;
-    group_totals(bins, nbin, C, g, t0, t1);
-    if (blockIdx.x == 0)
-        for (int c = tid; c < C; c += 256) { atomicAdd(dbeta + c, (float)t0[c]); atomicAdd(dgamma + c, (float)t1[c]); }
-    for (int c = tid; c < C; c += 256) cs[c] = 0.f;
-    __syncthreads();
     const float invR = (float)(1.0 / (double)Rg);
+    for (int c = tid; c < C; c += 256) {
+        double t0, t1;
+        group_totals(bins, nbin, C, g, c, t0, t1);
+        if (blockIdx.x == 0) { atomicAdd(dbeta + c, (float)t0); atomicAdd(dgamma + c, (float)t1); }
+        kk[c] = (float)t0 * invR; kk[C + c] = (float)t1 * invR;
+        cs[c] = 0.f;
+    }
+    __syncthreads();
     const int c = (tid * 4) % C;
     float mu[4], is[4], gi[4], k1[4], k2[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         mu[j] = mean[(size_t)g * C + c + j]; is[j] = invstd[(size_t)g * C + c + j]; gi[j] = gamma[c + j] * is[j];
-        k1[j] = (float)t0[c + j] * invR; k2[j] = (float)t1[c + j] * invR;
+        k1[j] = kk[c + j]; k2[j] = kk[C + c + j];
     }
     const size_t nvec = (size_t)Rg * C / 4, base = (size_t)g * Rg * C;
 #pragma unroll 2
     for (size_t i = (size_t)blockIdx.x * 256 + tid; i < nvec; i += (size_t)gridDim.x * 256) {
         const size_t e = base + i * 4;
-        const float4 d = *(const float4*)(dact + e), a = ld4<T>(act + e), x = *(const float4*)(raw + e);
+        const float4 d = ld4<DT>(dact + e), a = ld4<T>(act + e), x = ld4<RT>(raw + e);
         const float dv[4] = {d.x, d.y, d.z, d.w}, av[4] = {a.x, a.y, a.z, a.w}, xv[4] = {x.x, x.y, x.z, x.w};
         float o[4];
 #pragma unroll
@@ -189,42 +191,56 @@ inline int gbn_grid(long long Rg, int C) {
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+#define GB_BASE(d) ((d) & 0xF)
+#define GB_RAWBF(d) (((d) & FAVAE_RAW_BF16) != 0)
+#define GB_DACTBF(d) (((d) & FAVAE_DACT_BF16) != 0)
 
-/* Sums of a [G * Rg][C] tensor into bins [G][nbins][2][C] (the caller zeroes them): mode 1 = (sum, sum of squares) of y (BatchNorm
+/* Sums of a [G * Rg][C] tensor into bins [G][nbins][2][C] (the caller zeroes them): mode 1 = (sum, sum of squares) of y = raw (BatchNorm
  * statistics), mode 2 = the two BatchNorm-backward sums of y = dact given act, raw, mean [G][C], invstd [G][C].  For tensors whose
- * producing GEMM split its reduction (no epilogue sums).  C a multiple of 64. */
-extern "C" int favae_gbn_sums(const float* y, const void* act, const float* raw, const float* mean, const float* invstd, double* bins,
+ * producing GEMM split its reduction (no epilogue sums).  C a multiple of 64.  raw / dact are fp32, or bf16 with FAVAE_RAW_BF16 /
+ * FAVAE_DACT_BF16 in dtype (FAVAE_BF16 only). */
+extern "C" int favae_gbn_sums(const void* y, const void* act, const void* raw, const float* mean, const float* invstd, double* bins,
                               int nbins, int G, long long Rg, int C, int mode, int dtype, void* stream) {
     FAVAE_CHECK_ARG(y && bins && nbins >= 1 && G >= 1 && Rg >= 1 && Rg < (1LL << 30) && C >= 64 && C % 64 == 0, "favae_gbn_sums: bad argument");
     FAVAE_CHECK_ARG(mode == 1 || (mode == 2 && act && raw && mean && invstd), "favae_gbn_sums: mode 1, or mode 2 with act / raw / mean / invstd");
-    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_gbn_sums: dtype");
+    FAVAE_CHECK_ARG(GB_BASE(dtype) == FAVAE_F32 || GB_BASE(dtype) == FAVAE_BF16, "favae_gbn_sums: dtype");
+    FAVAE_CHECK_ARG(!((GB_RAWBF(dtype) || GB_DACTBF(dtype)) && GB_BASE(dtype) != FAVAE_BF16), "favae_gbn_sums: bf16 raw / dact need FAVAE_BF16");
     const int slabs = (int)std::max<long long>(1, std::min<long long>(std::max(1, 512 / (G * (C / 64))), (Rg + 63) / 64));
     const int rps = (int)((Rg + slabs - 1) / slabs);
     dim3 grid(C / 64, slabs, G);
-    if (mode == 1)
-        hipLaunchKernelGGL((gbn_sums_kernel<float, 1>), grid, dim3(256), 0, ST, y, (const float*)nullptr, raw, mean, invstd, bins, nbins, (int)Rg, C, rps);
-    else if (dtype == FAVAE_F32)
-        hipLaunchKernelGGL((gbn_sums_kernel<float, 2>), grid, dim3(256), 0, ST, y, (const float*)act, raw, mean, invstd, bins, nbins, (int)Rg, C, rps);
-    else
-        hipLaunchKernelGGL((gbn_sums_kernel<bf16_t, 2>), grid, dim3(256), 0, ST, y, (const bf16_t*)act, raw, mean, invstd, bins, nbins, (int)Rg, C, rps);
+    const bool rb = GB_RAWBF(dtype), db = GB_DACTBF(dtype);
+#define GS_LAUNCH(T, YT, RT, MODE) hipLaunchKernelGGL((gbn_sums_kernel<T, YT, RT, MODE>), grid, dim3(256), 0, ST, (const YT*)y, (const T*)act, (const RT*)raw, \
+                                                      mean, invstd, bins, nbins, (int)Rg, C, rps)
+    if (mode == 1) {
+        if (rb) GS_LAUNCH(bf16_t, bf16_t, bf16_t, 1); else GS_LAUNCH(float, float, float, 1);
+    } else if (GB_BASE(dtype) == FAVAE_F32) {
+        GS_LAUNCH(float, float, float, 2);
+    } else if (db) {
+        if (rb) GS_LAUNCH(bf16_t, bf16_t, bf16_t, 2); else GS_LAUNCH(bf16_t, bf16_t, float, 2);
+    } else {
+        if (rb) GS_LAUNCH(bf16_t, float, bf16_t, 2); else GS_LAUNCH(bf16_t, float, float, 2);
+    }
+#undef GS_LAUNCH
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }
 
 /* BatchNorm2d(train) + LeakyReLU forward of G groups from bins [G][nbins][2][C]: act (dtype) and mean / invstd [G][C]; the running
  * statistics take the average over the groups of the batch statistics (what averaging the ranks' running statistics gives in
- * the data-parallel run).  C <= 1024, a multiple of 4 that divides 1024. */
-extern "C" int favae_gbn_fwd(const float* raw, const double* bins, int nbins, const float* gamma, const float* beta, void* act, float* mean,
+ * the data-parallel run).  C <= 1024, a multiple of 4 that divides 1024.  raw fp32, or bf16 with FAVAE_RAW_BF16. */
+extern "C" int favae_gbn_fwd(const void* raw, const double* bins, int nbins, const float* gamma, const float* beta, void* act, float* mean,
                              float* invstd, float* run_mean, float* run_var, int G, long long Rg, int C, float eps, float momentum,
                              int dtype, void* stream) {
     FAVAE_CHECK_ARG(raw && bins && gamma && beta && act && mean && invstd && nbins >= 1 && G >= 1 && Rg >= 1 && Rg < (1LL << 30), "favae_gbn_fwd: bad argument");
     FAVAE_CHECK_ARG(C >= 4 && C <= 1024 && 1024 % C == 0, "favae_gbn_fwd: C = %d must divide 1024", C);
-    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_gbn_fwd: dtype");
+    FAVAE_CHECK_ARG(GB_BASE(dtype) == FAVAE_F32 || GB_BASE(dtype) == FAVAE_BF16, "favae_gbn_fwd: dtype");
+    FAVAE_CHECK_ARG(!(GB_RAWBF(dtype) && GB_BASE(dtype) != FAVAE_BF16), "favae_gbn_fwd: FAVAE_RAW_BF16 needs FAVAE_BF16");
     dim3 grid(gbn_grid(Rg, C), G);
-    if (dtype == FAVAE_F32)
-        hipLaunchKernelGGL(gbn_fwd_kernel<float>, grid, dim3(256), 0, ST, raw, bins, nbins, gamma, beta, (float*)act, mean, invstd, (int)Rg, C, eps);
-    else
-        hipLaunchKernelGGL(gbn_fwd_kernel<bf16_t>, grid, dim3(256), 0, ST, raw, bins, nbins, gamma, beta, (bf16_t*)act, mean, invstd, (int)Rg, C, eps);
+#define GF_LAUNCH(T, RT) hipLaunchKernelGGL((gbn_fwd_kernel<T, RT>), grid, dim3(256), 0, ST, (const RT*)raw, bins, nbins, gamma, beta, (T*)act, mean, invstd, (int)Rg, C, eps)
+    if (GB_BASE(dtype) == FAVAE_F32) GF_LAUNCH(float, float);
+    else if (GB_RAWBF(dtype)) GF_LAUNCH(bf16_t, bf16_t);
+    else GF_LAUNCH(bf16_t, float);
+#undef GF_LAUNCH
     FAVAE_LAUNCH_CHECK();
     if (run_mean && run_var) {
         hipLaunchKernelGGL(gbn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, mean, invstd, G, C, (int)Rg, eps, momentum, run_mean, run_var);
@@ -235,21 +251,23 @@ extern "C" int favae_gbn_fwd(const float* raw, const double* bins, int nbins, co
 
 /* BatchNorm2d(train) + LeakyReLU backward of G groups: bins [G][nbins][2][C] hold (sum dd, sum dd xhat) per group; draw (dtype) =
  * gradient w.r.t. the conv output; dgamma / dbeta / dbias (may be NULL) are ADDED to (fp32 atomics: the caller's gradient arena is
- * zero at the start of a step). */
-extern "C" int favae_gbn_bwd(const float* dact, const void* act, const float* raw, const float* mean, const float* invstd, const float* gamma,
+ * zero at the start of a step).  dact / raw fp32, or bf16 with FAVAE_DACT_BF16 / FAVAE_RAW_BF16. */
+extern "C" int favae_gbn_bwd(const void* dact, const void* act, const void* raw, const float* mean, const float* invstd, const float* gamma,
                              const double* bins, int nbins, void* draw, float* dgamma, float* dbeta, float* dbias, int G, long long Rg,
                              int C, int dtype, void* stream) {
     FAVAE_CHECK_ARG(dact && act && raw && mean && invstd && gamma && bins && draw && dgamma && dbeta && nbins >= 1 && G >= 1 && Rg >= 1 && Rg < (1LL << 30),
                     "favae_gbn_bwd: bad argument");
     FAVAE_CHECK_ARG(C >= 4 && C <= 1024 && 1024 % C == 0, "favae_gbn_bwd: C = %d must divide 1024", C);
-    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_gbn_bwd: dtype");
+    FAVAE_CHECK_ARG(GB_BASE(dtype) == FAVAE_F32 || GB_BASE(dtype) == FAVAE_BF16, "favae_gbn_bwd: dtype");
+    FAVAE_CHECK_ARG(!((GB_RAWBF(dtype) || GB_DACTBF(dtype)) && GB_BASE(dtype) != FAVAE_BF16), "favae_gbn_bwd: bf16 raw / dact need FAVAE_BF16");
     dim3 grid(gbn_grid(Rg, C), G);
-    if (dtype == FAVAE_F32)
-        hipLaunchKernelGGL(gbn_bwd_kernel<float>, grid, dim3(256), 0, ST, dact, (const float*)act, raw, mean, invstd, gamma, bins, nbins, (float*)draw,
-                           dgamma, dbeta, dbias, (int)Rg, C);
-    else
-        hipLaunchKernelGGL(gbn_bwd_kernel<bf16_t>, grid, dim3(256), 0, ST, dact, (const bf16_t*)act, raw, mean, invstd, gamma, bins, nbins,
-                           (bf16_t*)draw, dgamma, dbeta, dbias, (int)Rg, C);
+    const bool rb = GB_RAWBF(dtype), db = GB_DACTBF(dtype);
+#define GB_LAUNCH(T, DT, RT) hipLaunchKernelGGL((gbn_bwd_kernel<T, DT, RT>), grid, dim3(256), 0, ST, (const DT*)dact, (const T*)act, (const RT*)raw, mean, invstd, \
+                                                gamma, bins, nbins, (T*)draw, dgamma, dbeta, dbias, (int)Rg, C)
+    if (GB_BASE(dtype) == FAVAE_F32) GB_LAUNCH(float, float, float);
+    else if (db) { if (rb) GB_LAUNCH(bf16_t, bf16_t, bf16_t); else GB_LAUNCH(bf16_t, bf16_t, float); }
+    else { if (rb) GB_LAUNCH(bf16_t, float, bf16_t); else GB_LAUNCH(bf16_t, float, float); }
+#undef GB_LAUNCH
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

@@ -1147,9 +1147,10 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
     // one thread per output pixel pays off once the pixel count fills the chip several times over (the decoder side)
     if (!in_ab && !ep_ab && g_force_kc_tile < 0 && (long long)Nb * Ho * Wo >= 131072 && thin_in_applicable(Cin, Cout, ks, stride, scatter)) {
         ProfScope prof(14, 2.0 * Nb * Ho * Wo * (double)Cout * 9 * Cin, (hipStream_t)stream);
-        ThinRed tr{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
-        if (red.bins && red.mode == 2 && !out_bf16 && !red.raw_bf16) {   // the statistics form (mode 1) is not needed on this path
-            tr = ThinRed{red.bins, red.nbin, red.act, (const float*)red.raw, red.mean, red.invstd, red.group_images * Ho * Wo};
+        ThinRed tr{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0};
+        // (bf16 output / bf16 raw with the sums: grouped-batch mode only, where that form is tested)
+        if (red.bins && red.mode == 2 && ((!out_bf16 && !red.raw_bf16) || red.group_images > 0)) {   // the statistics form (mode 1) is not needed on this path
+            tr = ThinRed{red.bins, red.nbin, red.act, red.raw, red.mean, red.invstd, red.group_images * Ho * Wo, red.raw_bf16};
             if (red.fused) *red.fused = 1;
         }
         return thin_in_launch(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, stride, scatter, dtype, out_bf16, tr, (hipStream_t)stream);
@@ -1220,10 +1221,11 @@ extern "C" int favae_conv_igemm_red_groups(const void* in, const void* w, const 
                                            const float* mean, const float* invstd, int group_images, int* fused, void* stream) {
     FAVAE_CHECK_ARG(bins && fused && nbins >= 1 && nbins <= 256 && group_images >= 1, "favae_conv_igemm_red_groups: bins / fused / nbins / group_images");
     FAVAE_CHECK_ARG(mode == 1 || (mode == 2 && act && raw && mean && invstd), "favae_conv_igemm_red_groups: mode 1, or mode 2 with act/raw/mean/invstd");
-    FAVAE_CHECK_ARG(!(dtype & FAVAE_RAW_BF16), "favae_conv_igemm_red_groups: fp32 conv outputs only");
-    RedArgs red{bins, nbins, mode, act, raw, mean, invstd, fused, 0};
+    const int raw_bf16 = (dtype & FAVAE_RAW_BF16) != 0;
+    FAVAE_CHECK_ARG(!(raw_bf16 && (dtype & 0xF) != FAVAE_BF16), "favae_conv_igemm_red_groups: FAVAE_RAW_BF16 needs FAVAE_BF16");
+    RedArgs red{bins, nbins, mode, act, raw, mean, invstd, fused, raw_bf16};
     red.group_images = group_images;
-    return conv_igemm_impl(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype, red, stream);
+    return conv_igemm_impl(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype & ~FAVAE_RAW_BF16, red, stream);
 }
 
 extern "C" int favae_conv_igemm_bn(const void* in, const float* in_ab, const void* w, const float* bias, float* out, int Nb, int Hi,

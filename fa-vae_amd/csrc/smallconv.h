@@ -10,7 +10,7 @@ bool thin_in_applicable(int Cs, int Co, int ks, int stride, int scatter);
 // optional BatchNorm-backward sums taken while the result is stored (bins == nullptr: none); see favae_conv_igemm_red mode 2
 // group_pixels > 0 (grouped-batch mode): output pixels per BatchNorm group (a multiple of 256); group g = pixel / group_pixels takes
 // bins + g * nbin * 2 * Co and mean / invstd + g * Co
-struct ThinRed { double* bins; int nbin; const void* act; const float *raw, *mean, *invstd; int group_pixels; };
+struct ThinRed { double* bins; int nbin; const void* act; const void* raw; const float *mean, *invstd; int group_pixels; int raw_bf16; };
 int thin_in_launch(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cs, int Ho, int Wo,
                    int Co, int stride, int scatter, int dtype, int out_bf16, const ThinRed& red, hipStream_t st);
 

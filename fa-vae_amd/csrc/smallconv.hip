@@ -183,7 +183,12 @@ __global__ __launch_bounds__(256) void conv_thin_in(const T* __restrict__ in, co
                 const int prow = min(pix_w0 + i * PPI + lane / LPR, total - 1);
                 const size_t e = (size_t)prow * CO + hb + (lane % LPR) * 4;
                 pa[i] = *(const ActVec*)((const T*)red.act + e);
-                px[i] = *(const float4*)(red.raw + e);
+                if (red.raw_bf16) {   // block-uniform
+                    const uint2 u = *(const uint2*)((const bf16_t*)red.raw + e);
+                    px[i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+                } else {
+                    px[i] = *(const float4*)((const float*)red.raw + e);
+                }
             }
         }
 #pragma unroll

@@ -343,6 +343,18 @@ void choose_storage(Vae& v) {
         const size_t n = (size_t)v.rows(l, v.Bmax) * v.L[l].Cout;
         v.raw_bf[l] = v.dact_bf[l] = !off && v.L[l].bn && n >= ((size_t)1 << 22);
     }
+    // Grouped-batch mode (bf16 executor with Bmax > 64): at G = 8 the conv outputs and activation gradients of a step are 4 GB, far
+    // beyond the 256 MB Infinity Cache, and the step is bound by their HBM traffic (40 B per BatchNorm element and step; final_layer.0
+    // alone is half of it).  The activation gradients (dact) of every BatchNorm layer and the conv outputs (raw) of the DECODER side
+    // are stored as bf16 (28 B per element); the encoder keeps fp32 conv outputs, so the latent moments see no extra rounding, and
+    // the BatchNorm sums still come from the fp32 accumulators of the producing GEMM.  FAVAE_GROUPED_BF16_STORE=0: fp32 as before.
+    const char* gs = getenv("FAVAE_GROUPED_BF16_STORE");
+    if (v.dtype == FAVAE_BF16 && v.Bmax > 64 && off && !(gs && gs[0] == '0')) {
+        for (int l = 0; l < NL; ++l) {
+            v.raw_bf[l] = v.L[l].bn && l >= 7;
+            v.dact_bf[l] = v.L[l].bn && l != 4;   // (dact of encoder.4 comes from the fc heads' input-gradient GEMM, fp32)
+        }
+    }
 }
 
 int bins_for(long long rows);
@@ -509,6 +521,11 @@ int gather(const Vae& v, const float* data, const int* idx, int B, float* xf, vo
     return favae_gather_batch(data, idx, B, row, xf, xt, v.dtype, st);
 }
 
+// bins of layer l for the batch-64 launches: the layers with more than 256 channels take the channel-owner BatchNorm kernels there
+// (their bins exist in executors built for the grouped-batch mode only)
+inline double* sbins64(const Vae& v, int l) { return v.L[l].Cout <= 256 ? v.sbins[l] : nullptr; }
+inline double* gbins64(const Vae& v, int l) { return v.L[l].Cout <= 256 ? v.gbins[l] : nullptr; }
+
 int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false, int fi = -1) {
     const Layer& L = v.L[l];
     const float* bias = v.P + L.b_off;
@@ -528,9 +545,11 @@ int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false
         } else {
             const int scatter = L.kind == CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
             RC(favae_conv_igemm_red_groups(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, stride, 1, scatter, sk,
-                                           v.dtype, v.sbins[l], nb, 1, nullptr, nullptr, nullptr, nullptr, 64, &fused, st));
+                                           dt, v.sbins[l], nb, 1, nullptr, nullptr, nullptr, nullptr, 64, &fused, st));
         }
-        if (!fused) RC(favae_gbn_sums(v.raw[l], nullptr, nullptr, nullptr, nullptr, v.sbins[l], nb, G, v.rows(l, 64), L.Cout, 1, v.dtype, st));
+        if (!fused)
+            RC(favae_gbn_sums(v.raw[l], nullptr, nullptr, nullptr, nullptr, v.sbins[l], nb, G, v.rows(l, 64), L.Cout, 1,
+                              v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0), st));
         v.stats_fused[l] = true;
         return FAVAE_OK;
     }
@@ -543,7 +562,7 @@ int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false
     }
     if (l == 0 && v.hp && pooled && fi < 0 && thin_in_applicable(v.ch, L.Cout, 3, 2, 0)) {
         // no folded batch (four channels, one stream): the thin-input convolution on the fp32 batch with the fp32 master weights
-        const ThinRed none{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+        const ThinRed none{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0};
         return thin_in_launch(v.xf, v.P + L.w_off, bias, v.raw[0], B, L.Hin, L.Hin, v.ch, L.Hout, L.Hout, L.Cout, 2, 0, FAVAE_F32, 0, none,
                               (hipStream_t)st);
     }
@@ -551,11 +570,11 @@ int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false
         v.act4_ready = false;
         return favae_conv_igemm(v.act4_f32, v.P + L.w_off, bias, v.raw[l], B, 1, 1, L.Cin, 1, 1, L.Cout, 1, 1, 0, 0, sk, FAVAE_F32, st);
     }
-    const bool publish = pooled && v.fi_on && (v.fuse & 1u) && v.sbins[l] && L.kind != LINEAR && L.bn && !v.raw_bf[l];
+    const bool publish = pooled && v.fi_on && (v.fuse & 1u) && sbins64(v, l) && L.kind != LINEAR && L.bn && !v.raw_bf[l];
     if (fi >= 0 || publish) {
         // fused chain: the launch publishes this layer's BatchNorm quantities from its epilogue sums (where the shape runs
         // unsplit) and / or reads its input through the BatchNorm + LeakyReLU of layer fi
-        const bool own = (v.fuse & 1u) && v.sbins[l] != nullptr && L.bn;
+        const bool own = (v.fuse & 1u) && sbins64(v, l) != nullptr && L.bn;
         const int scatter = L.kind == CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
         int fused = 0;
         RC(favae_conv_igemm_bn(fi >= 0 ? (const void*)v.raw[fi] : in, fi >= 0 ? v.ab[fi] : nullptr, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin,
@@ -567,7 +586,7 @@ int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false
         v.bn_published[l] = fused != 0 && publish;
         return FAVAE_OK;
     }
-    if (pooled && (v.fuse & 1u) && v.sbins[l] && L.kind != LINEAR) {
+    if (pooled && (v.fuse & 1u) && sbins64(v, l) && L.kind != LINEAR) {
         // training step: the zero pool (and with it sbins) was cleared at the start of the step; take the BN statistics
         // in the GEMM epilogue where this shape runs unsplit
         const int scatter = L.kind == CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
@@ -596,7 +615,7 @@ int bn_fwd(Vae& v, int l, int B, bool train, void* st) {
     if (train && B > 64 && v.stats_fused[l]) {   // grouped-batch mode
         v.stats_fused[l] = false;
         return favae_gbn_fwd(v.raw[l], v.sbins[l], bins_for(v.rows(l, 64)), v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l], v.invstd[l],
-                             v.BUF + L.rm_off, v.BUF + L.rv_off, B / 64, v.rows(l, 64), L.Cout, 1e-5f, 0.1f, v.dtype, st);
+                             v.BUF + L.rm_off, v.BUF + L.rv_off, B / 64, v.rows(l, 64), L.Cout, 1e-5f, 0.1f, dt, st);
     }
     if (train && v.bn_published[l]) {   // the producing GEMM finished the statistics (mean, invstd, running stats, a | b)
         v.bn_published[l] = v.stats_fused[l] = false;
@@ -703,12 +722,17 @@ int bn_bwd(Vae& v, int l, int B, void* st) {
     const Layer& L = v.L[l];
     if (B > 64) {   // grouped-batch mode: the two sums per group from the epilogue of the GEMM that produced dact[l], else from a pass
         const int G = B / 64, nb = bins_for(v.rows(l, 64));
+        const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0) | (v.dact_bf[l] ? FAVAE_DACT_BF16 : 0);
         if (!v.grad_fused[l])
-            RC(favae_gbn_sums(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.gbins[l], nb, G, v.rows(l, 64), L.Cout, 2, v.dtype, st));
+            RC(favae_gbn_sums(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.gbins[l], nb, G, v.rows(l, 64), L.Cout, 2, dt, st));
         v.grad_fused[l] = false;
         v.dbias_slabs[l] = 0;
+        // The bias of a convolution in front of a train-mode BatchNorm has an analytically zero gradient (the mean subtraction
+        // removes it); the batch-64 step carries the column sums of draw, i.e. rounding noise, as the reference's autograd does.  Here
+        // the gradient is left at its exact value, zero: 2048 blocks x C atomics onto C addresses cost up to 3.5x the apply itself
+        // (enc.2 at G = 8: 60.7 us against 16.9 us for the forward apply over the same elements, tools/bench_gbn.py).
         return favae_gbn_bwd(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.gbins[l], nb, v.draw[l], v.G + L.g_off,
-                             v.G + L.be_off, v.G + L.b_off, G, v.rows(l, 64), L.Cout, v.dtype, st);
+                             v.G + L.be_off, nullptr, G, v.rows(l, 64), L.Cout, dt, st);
     }
     if (v.grad_fused[l]) {   // the GEMM that produced dact[l] summed the two reductions in its epilogue
         v.grad_fused[l] = false;
@@ -912,15 +936,16 @@ int dgrad(Vae& v, int l, float* out, int B, void* st, bool out_zeroed, bool out_
     const Layer& L = v.L[l];
     const int sk = out_zeroed ? -1 : 0;
     const int dt = v.dtype | (out_bf ? FAVAE_OUT_BF16 : 0);
-    if (o >= 0 && B > 64 && v.gbins[o] && L.kind != LINEAR && !out_bf) {   // grouped-batch mode: sums per BatchNorm group of layer o
+    if (o >= 0 && B > 64 && v.gbins[o] && L.kind != LINEAR) {   // grouped-batch mode: sums per BatchNorm group of layer o
         const int scatter = L.kind != CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
         int fused = 0;
         RC(favae_conv_igemm_red_groups(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, stride, 1, scatter, sk,
-                                       v.dtype, v.gbins[o], bins_for(v.rows(o, 64)), 2, v.act[o], v.raw[o], v.mean[o], v.invstd[o], 64, &fused, st));
+                                       dt | (v.raw_bf[o] ? FAVAE_RAW_BF16 : 0), v.gbins[o], bins_for(v.rows(o, 64)), 2, v.act[o], v.raw[o], v.mean[o],
+                                       v.invstd[o], 64, &fused, st));
         v.grad_fused[o] = fused != 0;
         return FAVAE_OK;
     }
-    if (o >= 0 && (v.fuse & (l == L_OUT ? 4u : 2u)) && v.gbins[o] && L.kind != LINEAR) {
+    if (o >= 0 && (v.fuse & (l == L_OUT ? 4u : 2u)) && gbins64(v, o) && L.kind != LINEAR) {
         const int scatter = L.kind != CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
         int fused = 0;
         RC(favae_conv_igemm_red(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, stride, 1, scatter,

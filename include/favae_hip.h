@@ -88,18 +88,19 @@ int favae_conv_igemm_red(const void* in, const void* w, const float* bias, float
  * one GPU.  favae_conv_igemm_red_groups = favae_conv_igemm_red with the sums of group g at bins + g * nbins * 2 * Cout (mode 2 reads
  * mean / invstd [G][Cout]); favae_gbn_sums fills such bins for a tensor whose producer could not; favae_gbn_fwd / favae_gbn_bwd are
  * BatchNorm(train) + LeakyReLU forward / backward of the G groups (running statistics: average over the groups of the batch
- * statistics; dgamma / dbeta / dbias are ADDED to).  Tensors [G * Rg][C] NHWC, C <= 1024 dividing 1024. */
+ * statistics; dgamma / dbeta / dbias are ADDED to).  Tensors [G * Rg][C] NHWC, C <= 1024 dividing 1024; raw / dact fp32, or bf16
+ * with FAVAE_RAW_BF16 / FAVAE_DACT_BF16 in dtype (the conv launch: FAVAE_OUT_BF16 for its output, FAVAE_RAW_BF16 for the raw it reads). */
 int favae_conv_igemm_red_groups(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cin, int Ho,
                                 int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk, int dtype, double* bins,
                                 int nbins, int mode, const void* act, const void* raw, const float* mean, const float* invstd,
                                 int group_images, int* fused, void* stream);
-int favae_gbn_sums(const float* y, const void* act, const float* raw, const float* mean, const float* invstd, double* bins, int nbins,
+int favae_gbn_sums(const void* y, const void* act, const void* raw, const float* mean, const float* invstd, double* bins, int nbins,
                    int G, long long Rg, int C, int mode, int dtype, void* stream);
-int favae_gbn_fwd(const float* raw, const double* bins, int nbins, const float* gamma, const float* beta, void* act, float* mean,
+int favae_gbn_fwd(const void* raw, const double* bins, int nbins, const float* gamma, const float* beta, void* act, float* mean,
                   float* invstd, float* run_mean, float* run_var, int G, long long Rg, int C, float eps, float momentum, int dtype,
                   void* stream);
 long long favae_vae_epoch_steps(long long n, int batch);
-int favae_gbn_bwd(const float* dact, const void* act, const float* raw, const float* mean, const float* invstd, const float* gamma,
+int favae_gbn_bwd(const void* dact, const void* act, const void* raw, const float* mean, const float* invstd, const float* gamma,
                   const double* bins, int nbins, void* draw, float* dgamma, float* dbeta, float* dbias, int G, long long Rg, int C,
                   int dtype, void* stream);
 

@@ -85,11 +85,13 @@ def test_grouped_step_is_the_average_of_its_groups(dtype, tol, tol_bulk, min_cos
         assert _rel(got[k].numpy(), run[k].numpy()) <= tol, (k, _rel(got[k].numpy(), run[k].numpy()))
 
 
-def test_grouped_epoch_with_a_ragged_tail_follows_the_averaged_steps():
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_grouped_epoch_with_a_ragged_tail_follows_the_averaged_steps(dtype):
     """An epoch of 356 images at 128 per step: steps of 128, 128, then the tail of 100 as its whole group (64) and the rest (36, an
     ordinary step).  Against the oracle stepping Adam on the hand-averaged group gradients.  fp32; the first step to 1e-4, later
-    steps to 2e-3 (Adam's first steps move every entry by ~lr whatever its gradient, so entries with rounding-noise gradients
-    differ between any two runs: tools/dbg_epoch_vs_steps.py)."""
+    steps to 5e-3 (measured up to 2.0e-3) (Adam's first steps move every entry by ~lr whatever its gradient, so entries with rounding-noise gradients
+    differ between any two runs: tools/dbg_epoch_vs_steps.py).  bf16 (conv outputs of the decoder and activation gradients stored as
+    bf16 in this mode; the ordinary tail step runs on the same storage): loss terms to 1e-2 / 3e-2."""
     from favae_hip.engine import VaeEngine
     z, n, batch = 20, 356, 128
     assert VaeEngine.epoch_steps(n, batch) == 4 and VaeEngine.epoch_steps(256, batch) == 2 and VaeEngine.epoch_steps(300, batch) == 3
@@ -106,7 +108,7 @@ def test_grouped_epoch_with_a_ragged_tail_follows_the_averaged_steps():
     eps = torch.randn(n, z, generator=torch.Generator().manual_seed(5))
     perm = torch.randperm(n, generator=torch.Generator().manual_seed(6))
 
-    eng = VaeEngine(z, 3, batch_max=batch, dtype="f32")
+    eng = VaeEngine(z, 3, batch_max=batch, dtype=dtype)
     eng.load_state_dict(sd)
     data = eng.upload_images(img)
     ms = torch.zeros(4, 2, dtype=torch.float64, device="cuda")
@@ -125,20 +127,28 @@ def test_grouped_epoch_with_a_ragged_tail_follows_the_averaged_steps():
         opt.step()
         for k in run:
             Bf[k].copy_(run[k].to(Bf[k].dtype))
-        tol = 1e-4 if s == 0 else 2e-3
+        tol = (1e-4 if s == 0 else 5e-3) if dtype == "f32" else (1e-2 if s == 0 else 3e-2)
         assert abs(got_m[s, 0] - rec_m) <= tol * abs(rec_m), (s, got_m[s], rec_m)
         assert abs(got_m[s, 1] - kl_m) <= tol * abs(kl_m) + 1e-6, (s, got_m[s], kl_m)
         o += B
     got = eng.state_dict()
+    if dtype != "f32":
+        return
     for k in names:
         if k in NOISE_ONLY:
             continue
         d = np.abs(got[k].numpy() - P[k].detach().numpy())
         assert np.median(d) <= 1e-5 and d.max() <= 4 * 2.1e-4, (k, d.max(), np.median(d))
     for k in Bf:
-        if "num_batches" not in k:
-            # (after four Adam steps; the update rule itself is held to 1e-4 in the one-step test above.  Measured 3.2e-3 for enc.4)
-            assert _rel(got[k].numpy(), Bf[k].numpy()) <= 1e-2, (k, _rel(got[k].numpy(), Bf[k].numpy()))
+        if "num_batches" in k:
+            continue
+        # The running mean follows the bias of the convolution in front of the BatchNorm.  That bias has a zero gradient, which the
+        # grouped step keeps exactly (the bias stays put), while autograd's rounding noise, normalised by Adam, moves the oracle's
+        # bias by ~lr per step (4e-4 after this epoch, 1/3 of it in the running mean, against running means of ~1e-2).
+        # (after four Adam steps; the update rule itself is held to 1e-4 in the one-step test above.  Measured 3.2e-3 for enc.4's
+        # running variance, 1.3e-2 for dec.0's running mean)
+        tol = 3e-2 if k.endswith("running_mean") else 1e-2
+        assert _rel(got[k].numpy(), Bf[k].numpy()) <= tol, (k, _rel(got[k].numpy(), Bf[k].numpy()))
 
 
 def test_a_batch_above_64_must_be_whole_groups():
