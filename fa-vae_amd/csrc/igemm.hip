@@ -1328,6 +1328,18 @@ extern "C" int favae_conv_folded_fwd_split(const void* fold_hl, const float* w, 
     return folded_fwd_launch(fold_hl, w, K, bias, out, P, bins, nbins, 1, (hipStream_t)stream);
 }
 
+extern "C" int favae_conv_folded_dgrad(const void* fold, const void* w, void* out, long long P, int K, int Cin, double* bins, int nbins,
+                                       const void* act, const void* raw, const float* mean, const float* invstd, int groups, int dtype,
+                                       void* stream) {
+    FAVAE_CHECK_ARG(fold && w && out && P > 0 && P < (1ll << 31) && groups >= 1, "favae_conv_folded_dgrad: bad argument");
+    FAVAE_CHECK_ARG((dtype & 0xF) == FAVAE_BF16 && Cin == 64 && K >= 1 && K <= 32, "favae_conv_folded_dgrad: bf16, 64 input channels, K <= 32");
+    FAVAE_CHECK_ARG((dtype & ~(0xF | FAVAE_OUT_BF16 | FAVAE_RAW_BF16)) == 0, "favae_conv_folded_dgrad: unknown storage flag in dtype 0x%x", dtype);
+    FAVAE_CHECK_ARG(!bins || (nbins >= 1 && act && raw && mean && invstd), "favae_conv_folded_dgrad: the sums need nbins, act, raw, mean, invstd");
+    FAVAE_CHECK_ARG(((uintptr_t)fold % 16) == 0 && ((uintptr_t)out % 16) == 0, "favae_conv_folded_dgrad: 16-byte alignment");
+    return folded_dgrad_launch(fold, w, K, out, P, groups, (dtype & FAVAE_OUT_BF16) != 0, bins, nbins, act, raw, (dtype & FAVAE_RAW_BF16) != 0, mean,
+                               invstd, (hipStream_t)stream);
+}
+
 extern "C" int favae_conv_wgrad_prefolded(const void* rows, int Rc, int Rst, const void* cols, int Cc, int Cst, float* dw,
                                           long long K, int splitk, int dtype, void* stream) {
     FAVAE_CHECK_ARG(rows && cols && dw, "favae_conv_wgrad_prefolded: null pointer");

@@ -30,4 +30,10 @@ int fold_taps_launch(const void* src, void* dst, int Nb, int Hq, int Wq, int Hn,
 int folded_fwd_launch(const void* fold, const void* w, int K, const float* bias, float* out, long long P, double* bins, int nbin,
                       int split, hipStream_t st, int groups = 1);
 // fold_taps (shifted = 0) of an fp32 source into two bf16 planes: dst [P][32] = bf16(x), dst + P * 32 = bf16(x - bf16(x))
+// Input gradient of a 3x3 stride-1 convolution with <= 3 output channels over its tap-folded output gradient (fold_taps_launch,
+// shifted = 1): out [P][64] (fp32, or bf16 with out_bf16) = fold [P][32] x w [K][64], w = the layer's weight [Cout][9][64] as it lies.
+// bins != NULL: the BatchNorm-backward sums of the layer in front per group of P / groups pixels (bins [groups][nbin][2][64], act bf16,
+// raw fp32 or bf16, mean / invstd [groups][64]).
+int folded_dgrad_launch(const void* fold, const void* w, int K, void* out, long long P, int groups, int out_bf16, double* bins, int nbin,
+                        const void* act, const void* raw, int raw_bf16, const float* mean, const float* invstd, hipStream_t st);
 int fold_taps_hl_launch(const float* src, void* dst, int Nb, int Hq, int Wq, int Hn, int Wn, int Cs, int stride, hipStream_t st);

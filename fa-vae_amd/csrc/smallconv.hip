@@ -462,6 +462,126 @@ __global__ __launch_bounds__(256) void folded_fwd_kernel(const bf16_t* __restric
         unsafeAtomicAdd(bins + ((size_t)(blockIdx.x % (unsigned)nbin) * 2 + qq) * 64 + col, t);
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Input gradient of final_layer.3 = Conv2d(64 -> 3, k3 s1 p1) (loss.backward(), celeba_deepvanilla_vae.py:249) on the matrix cores,
+// over the tap-folded output gradient that the layer's weight gradient needs anyway (fold_taps, shifted form: fold[p][c * 9 + tap] =
+// draw[p + 1 - tap][c]):   dact[p][ci] = sum_k fold[p][k] * w[k][ci],  w = the layer's weight [3][9][64] read as [27][64].
+// Same wave-level shape as folded_fwd_kernel (32 pixels x 64 channels x K = 32: four 32x32x16 MFMAs), but MFMA column r of the two
+// n-tiles stands for the channels 2r and 2r + 1, so that a lane holds two neighbouring channels of a pixel and a store instruction
+// writes whole pixel rows (256 B fp32 / 128 B bf16 per 32 lanes).  RED: the two BatchNorm-backward sums of the layer in front
+// (final_layer.0) per channel, sum dd and sum dd * xhat with dd = dact * lrelu'(act), from the fp32 accumulators (igemm_kc red_mode 2),
+// fp64 atomics into bins[nbin][2][64].  blockIdx.y = BatchNorm group (P pixels each, own bins / mean / invstd).
+// The VALU form (conv_thin_in: 27 * 64 FMAs per pixel in one thread, 203 registers, two waves per SIMD) took 71 us per 64 images.
+template <bool OUT_BF, bool RAW_BF, bool RED>
+__global__ __launch_bounds__(256) void folded_dgrad_kernel(const bf16_t* __restrict__ fold, const bf16_t* __restrict__ w, int K,
+                                                           void* __restrict__ out_, int P, double* __restrict__ bins, int nbin,
+                                                           const bf16_t* __restrict__ act, const void* __restrict__ raw_,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const FlagCarry carry) {
+    carry_store(carry);
+    const size_t goff = (size_t)blockIdx.y * P;
+    fold += goff * 32;
+    __shared__ __attribute__((aligned(16))) bf16_t wl[64 * 40];   // [channel][32] + 8 columns of padding
+    __shared__ double redsm[4 * 2 * 64];
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+        const int k = i >> 6, o = i & 63;                          // (consecutive threads read consecutive channels of row k)
+        wl[o * 40 + k] = k < K ? w[k * 64 + o] : (bf16_t)0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    union U { uint4 u; bf16x8 b; };
+    U b00, b01, b10, b11;   // [n tile][k step]; n tile 0 = even channels, 1 = odd channels
+    b00.u = *(const uint4*)(wl + (2 * r) * 40 + h * 8);
+    b01.u = *(const uint4*)(wl + (2 * r) * 40 + 16 + h * 8);
+    b10.u = *(const uint4*)(wl + (2 * r + 1) * 40 + h * 8);
+    b11.u = *(const uint4*)(wl + (2 * r + 1) * 40 + 16 + h * 8);
+    float mu0 = 0.f, mu1 = 0.f, is0 = 0.f, is1 = 0.f;
+    if (RED) {
+        mu0 = mean[blockIdx.y * 64 + 2 * r]; mu1 = mean[blockIdx.y * 64 + 2 * r + 1];
+        is0 = invstd[blockIdx.y * 64 + 2 * r]; is1 = invstd[blockIdx.y * 64 + 2 * r + 1];
+    }
+    double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+    const int ngroup = (P + 31) / 32, nw = gridDim.x * 4;
+    for (int g = blockIdx.x * 4 + wave; g < ngroup; g += nw) {
+        const int p0 = g * 32, pa = min(p0 + r, P - 1);
+        U a0, a1;
+        a0.u = *(const uint4*)(fold + (size_t)pa * 32 + h * 8);
+        a1.u = *(const uint4*)(fold + (size_t)pa * 32 + 16 + h * 8);
+        // act / raw of the 16 pixel rows this lane finishes, fetched ahead of the MFMAs
+        [[maybe_unused]] unsigned pa2[16];
+        [[maybe_unused]] float2 px[16];
+        if (RED) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int p = min(p0 + (i & 3) + 8 * (i >> 2) + 4 * h, P - 1);
+                const size_t e = (goff + p) * 64 + 2 * r;
+                pa2[i] = *(const unsigned*)(act + e);
+                if (RAW_BF) {
+                    const unsigned u = *(const unsigned*)((const bf16_t*)raw_ + e);
+                    px[i] = make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
+                } else {
+                    px[i] = *(const float2*)((const float*)raw_ + e);
+                }
+            }
+        }
+        f32x16 c0, c1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { c0[i] = 0.f; c1[i] = 0.f; }
+        c0 = mfma_bf16_32x32x16(a0.b, b00.b, c0);
+        c0 = mfma_bf16_32x32x16(a1.b, b01.b, c0);
+        c1 = mfma_bf16_32x32x16(a0.b, b10.b, c1);
+        c1 = mfma_bf16_32x32x16(a1.b, b11.b, c1);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int p = p0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (p < P) {
+                const size_t e = (goff + p) * 64 + 2 * r;
+                if (OUT_BF) *(unsigned*)((bf16_t*)out_ + e) = (unsigned)f32_to_bf16(c0[i]) | ((unsigned)f32_to_bf16(c1[i]) << 16);
+                else *(float2*)((float*)out_ + e) = make_float2(c0[i], c1[i]);
+                if (RED) {
+                    const float a_e = __uint_as_float(pa2[i] << 16), a_o = __uint_as_float(pa2[i] & 0xffff0000u);
+                    const float d0 = c0[i] * (a_e > 0.f ? 1.f : 0.01f), d1 = c1[i] * (a_o > 0.f ? 1.f : 0.01f);
+                    s0 += d0; s1 += d1;
+                    q0 += (double)d0 * ((px[i].x - mu0) * is0); q1 += (double)d1 * ((px[i].y - mu1) * is1);
+                }
+            }
+        }
+    }
+    if (!RED) return;
+    s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+    if (h == 0) {
+        redsm[(wave * 2 + 0) * 64 + 2 * r] = s0; redsm[(wave * 2 + 0) * 64 + 2 * r + 1] = s1;
+        redsm[(wave * 2 + 1) * 64 + 2 * r] = q0; redsm[(wave * 2 + 1) * 64 + 2 * r + 1] = q1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int qq = threadIdx.x >> 6, col = threadIdx.x & 63;
+        const double t = (redsm[(0 * 2 + qq) * 64 + col] + redsm[(1 * 2 + qq) * 64 + col]) + (redsm[(2 * 2 + qq) * 64 + col] + redsm[(3 * 2 + qq) * 64 + col]);
+        unsafeAtomicAdd(bins + (((size_t)blockIdx.y * nbin + blockIdx.x % (unsigned)nbin) * 2 + qq) * 64 + col, t);
+    }
+}
+}  // namespace
+
+int folded_dgrad_launch(const void* fold, const void* w, int K, void* out, long long P, int groups, int out_bf16, double* bins, int nbin,
+                        const void* act, const void* raw, int raw_bf16, const float* mean, const float* invstd, hipStream_t st) {
+    const FlagCarry carry = favae_take_flag_carry();
+    FAVAE_CHECK_ARG(groups >= 1 && P % groups == 0 && (groups == 1 || (P / groups) % 32 == 0), "folded input gradient: %lld pixels in %d groups", P, groups);
+    const int Pg = (int)(P / groups);
+    const int ngroup = (Pg + 31) / 32;
+    const int grid = std::max(1, std::min((ngroup + 3) / 4, std::max(128, 1024 / groups)));
+#define FD_LAUNCH(OB, RB, RD) hipLaunchKernelGGL((folded_dgrad_kernel<OB, RB, RD>), dim3(grid, groups), dim3(256), 0, st, (const bf16_t*)fold, (const bf16_t*)w, K, \
+                                                 out, Pg, bins, std::max(1, nbin), (const bf16_t*)act, raw, mean, invstd, carry)
+    if (!bins) { if (out_bf16) FD_LAUNCH(true, false, false); else FD_LAUNCH(false, false, false); }
+    else if (out_bf16) { if (raw_bf16) FD_LAUNCH(true, true, true); else FD_LAUNCH(true, false, true); }
+    else { if (raw_bf16) FD_LAUNCH(false, true, true); else FD_LAUNCH(false, false, true); }
+#undef FD_LAUNCH
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+namespace {
 }  // namespace
 
 int folded_fwd_launch(const void* fold, const void* w, int K, const float* bias, float* out, long long P, double* bins, int nbin,
@@ -491,28 +611,46 @@ template <class T, int CS>
 __global__ __launch_bounds__(256) void fold_taps(const T* __restrict__ src, T* __restrict__ dst, int Hq, int Wq, int Hn, int Wn,
                                                  int stride, int shifted, int total) {
     const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= total) return;
-    const int n = pix / (Hq * Wq), rem = pix - n * Hq * Wq, y = rem / Wq, x = rem - y * Wq;
     T v[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) v[i] = (T)0;
+    if (pix < total) {
+        const int n = pix / (Hq * Wq), rem = pix - n * Hq * Wq, y = rem / Wq, x = rem - y * Wq;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int sy = shifted ? y + 1 - kh : y * stride - 1 + kh, sx = shifted ? x + 1 - kw : x * stride - 1 + kw;
-            if (sy < 0 || sy >= Hn || sx < 0 || sx >= Wn) continue;
-            const T* s = src + ((size_t)(n * Hn + sy) * Wn + sx) * CS;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int sy = shifted ? y + 1 - kh : y * stride - 1 + kh, sx = shifted ? x + 1 - kw : x * stride - 1 + kw;
+                if (sy < 0 || sy >= Hn || sx < 0 || sx >= Wn) continue;
+                const T* s = src + ((size_t)(n * Hn + sy) * Wn + sx) * CS;
 #pragma unroll
-            for (int c = 0; c < CS; ++c) {
-                if (shifted) v[c * 9 + kh * 3 + kw] = s[c];
-                else v[(kh * 3 + kw) * CS + c] = s[c];
+                for (int c = 0; c < CS; ++c) {
+                    if (shifted) v[c * 9 + kh * 3 + kw] = s[c];
+                    else v[(kh * 3 + kw) * CS + c] = s[c];
+                }
             }
-        }
-    uint4* out = (uint4*)(dst + (size_t)pix * 32);
+    }
     const uint4* vv = (const uint4*)v;
+    if constexpr (sizeof(T) == 2) {
+        // the 64-byte rows leave through LDS so that every store instruction of a wave writes 1 KB of consecutive bytes (a thread
+        // storing its own row in 16-byte pieces writes every 128-byte line several times; see fold_taps_hl)
+        __shared__ __attribute__((aligned(16))) T sh[256 * 32];
+        const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < (int)(32 * sizeof(T) / 16); ++i) out[i] = vv[i];
+        for (int i = 0; i < 4; ++i) *(uint4*)(sh + t * 32 + ((i + (t >> 2)) & 3) * 8) = vv[i];
+        __syncthreads();
+        const int p0 = blockIdx.x * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = i * 256 + t, row = q >> 2, piece = q & 3;
+            if (p0 + row < total) *(uint4*)(dst + (size_t)(p0 + row) * 32 + piece * 8) = *(const uint4*)(sh + row * 32 + ((piece + (row >> 2)) & 3) * 8);
+        }
+    } else {
+        if (pix >= total) return;
+        uint4* out = (uint4*)(dst + (size_t)pix * 32);
+#pragma unroll
+        for (int i = 0; i < (int)(32 * sizeof(T) / 16); ++i) out[i] = vv[i];
+    }
 }
 }  // namespace
 

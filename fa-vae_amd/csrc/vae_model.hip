@@ -195,6 +195,7 @@ struct Vae {
     char* wk_out;   // weights of final_layer.3 in the MFMA operand order for favae_conv_out_ll (rebuilt whenever the layer changes)
     char* fold0_buf[2]; int fold_sel; hipEvent_t ev_batch, ev_fold; bool inline_tail;   // see train_stages
     bool fwd_folded;   // this step's encoder.0 forward reads the folded batch (the caller's stream has waited for the fold)
+    bool out_folded;   // final_layer.3's output gradient is folded on the caller's stream, for its weight AND its input gradient
     char* fold0; size_t fold0_bytes; hipEvent_t ev_x; bool x_folded;   // encoder.0's folded input batch, gathered on the side stream while the forward pass runs
     // bf16 executor: the two ends of the encoder keep fp32 precision in the training step (FAVAE_BF16_EXACT_ENDS=0: plain bf16, as
     // before).  encoder.0 reads the image as two bf16 terms (hi + lo planes of the folded batch, fp32 master weights split in the
@@ -915,6 +916,8 @@ int wgrad_launch(Vae& v, int l, const void* in, int B, void* st) {
         // (256 slices of the 65536-pixel reduction, the automatic choice: 64 to 1024 measured the same or slower)
         return favae_conv_wgrad_prefolded(v.draw[0], L.Cout, L.Cout, v.fold0, 32, 9 * L.Cin, dw, (long long)B * L.Hout * L.Hout, -1, v.dtype, st);
     }
+    if (l == L_OUT && v.out_folded)   // the output gradient was folded on the caller's stream (train_stages, stage 0): its input gradient reads it too
+        return favae_conv_wgrad_prefolded(v.fold, 32, 9 * L.Cout, in, L.Cin, L.Cin, dw, (long long)B * L.Hout * L.Hout, -1, v.dtype, st);
     if ((v.fuse & 64u) && v.ch <= 3 && (l == 0 || l == L_OUT))   // image-sized channel count on one side: one GEMM over folded taps
         return favae_conv_wgrad_folded(v.draw[l], L.Cout, in, L.Cin, dw, B, L.Hout, L.Hout, L.Hin, L.Hin, l == 0 ? 2 : 1, -1, v.dtype,
                                        v.fold, v.fold_bytes, st);
@@ -936,6 +939,16 @@ int dgrad(Vae& v, int l, float* out, int B, void* st, bool out_zeroed, bool out_
     const Layer& L = v.L[l];
     const int sk = out_zeroed ? -1 : 0;
     const int dt = v.dtype | (out_bf ? FAVAE_OUT_BF16 : 0);
+    if (l == L_OUT && v.out_folded && o == 11) {
+        // final_layer.3 on the matrix cores over the folded output gradient (smallconv.hip, folded_dgrad_kernel); the sums of
+        // final_layer.0's BatchNorm backward ride along, per BatchNorm group in the grouped-batch mode
+        const int G = B > 64 ? B / 64 : 1;
+        double* bins = B > 64 ? v.gbins[o] : ((v.fuse & 4u) ? gbins64(v, o) : nullptr);
+        RC(favae_conv_folded_dgrad(v.fold, v.Wf(L_OUT), out, (long long)B * L.Hin * L.Hin, 9 * L.Cout, L.Cin, bins, bins_for(v.rows(o, B > 64 ? 64 : B)),
+                                   v.act[o], v.raw[o], v.mean[o], v.invstd[o], G, dt | (v.raw_bf[o] ? FAVAE_RAW_BF16 : 0), st));
+        v.grad_fused[o] = bins != nullptr;
+        return FAVAE_OK;
+    }
     if (o >= 0 && B > 64 && v.gbins[o] && L.kind != LINEAR) {   // grouped-batch mode: sums per BatchNorm group of layer o
         const int scatter = L.kind != CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
         int fused = 0;
@@ -1054,6 +1067,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.eval_fused = batch_max >= 256 && !(getenv("FAVAE_EVAL_FUSED") && getenv("FAVAE_EVAL_FUSED")[0] == '0');
     v.eval_ab_ready = false;
     v.fwd_folded = false;
+    v.out_folded = false;
     {
         const char* hpe = getenv("FAVAE_BF16_EXACT_ENDS");
         v.hp = dtype == FAVAE_BF16 && !(hpe && hpe[0] == '0');
@@ -1284,6 +1298,11 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             v.acts_wait = false;
         }
         if (sg == 0) {
+            // bf16, image-sized channel count: the output gradient of final_layer.3 is folded once, here, for both its weight gradient
+            // (weight-gradient stream) and its input gradient (next launch)   (FAVAE_FUSE_MASK bit 0x8000000: the thin-input kernel, as before)
+            v.out_folded = v.dtype == FAVAE_BF16 && (v.fuse & 64u) && v.ch <= 3 && !(v.fuse & 0x8000000u) && v.L[11].Cout == 64;
+            if (v.out_folded)
+                RC(favae_conv_fold_taps(v.draw[L_OUT], v.fold, v.fold_bytes, B, 64, 64, 64, 64, v.ch, 1, 1, v.dtype, st));
             RC(wgrad(v, L_OUT, v.act[11], B, st));
             RC(dgrad(v, L_OUT, v.dact[11], B, st, v.dact_pooled[11], v.dact_bf[11], 11));
             RC(sp_flush_carry((hipStream_t)st));

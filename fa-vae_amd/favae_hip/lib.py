@@ -9,6 +9,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
+RAW_BF16, DACT_BF16, OUT_BF16 = 0x10, 0x20, 0x40      # storage flags of include/favae_hip.h
 NOT_SPD = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -148,6 +149,20 @@ def conv_folded_fwd_split(folded_hl, w_f32, bias, out, bins=None):
     assert folded_hl.dtype == torch.bfloat16 and w_f32.dtype == torch.float32 and out.dtype == torch.float32 and out.shape == (P, Cout)
     check(_lib.favae_conv_folded_fwd_split(ptr(folded_hl), ptr(w_f32), ptr(bias), ptr(out), ctypes.c_longlong(P), _i(K), _i(Cout), ptr(bins),
                                            _i(0 if bins is None else bins.shape[0]), stream_ptr()))
+    return out
+
+
+def conv_folded_dgrad(folded, w, out, bins=None, act=None, raw=None, mean=None, invstd=None, groups=1):
+    """favae_conv_folded_dgrad: out [P, 64] (f32 or bf16) = folded [P, 32] x w [K, 64] (bf16); optional BatchNorm-backward sums of the
+    layer in front into bins [groups, nbins, 2, 64] f64 (zeroed by the caller) given act (bf16), raw (f32 / bf16), mean / invstd
+    [groups, 64]."""
+    P, K = folded.shape[0], w.numel() // 64
+    assert folded.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and out.shape == (P, 64)
+    assert out.dtype in (torch.float32, torch.bfloat16) and out.is_contiguous()
+    flags = BF16 | (OUT_BF16 if out.dtype == torch.bfloat16 else 0) | (RAW_BF16 if raw is not None and raw.dtype == torch.bfloat16 else 0)
+    check(_lib.favae_conv_folded_dgrad(ptr(folded), ptr(w), ptr(out), ctypes.c_longlong(P), _i(K), _i(64), ptr(bins),
+                                       _i(0 if bins is None else bins.shape[-3]), ptr(act), ptr(raw), ptr(mean), ptr(invstd), _i(groups),
+                                       _i(flags), stream_ptr()))
     return out
 
 

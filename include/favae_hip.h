@@ -173,6 +173,16 @@ int favae_conv_fold_taps_split(const float* src, void* dst, size_t dst_bytes, in
 int favae_conv_folded_fwd_split(const void* fold_hl, const float* w, const float* bias, float* out, long long P, int K, int Cout,
                                 double* bins, int nbins, void* stream);
 
+/* Input gradient of final_layer.3 = Conv2d(64 -> C <= 3, k3 s1 p1) (loss.backward(), cA/celeba_deepvanilla_vae.py:249 through :74-76)
+ * over the tap-folded output gradient that the layer's weight gradient uses as well (favae_conv_fold_taps with shifted = 1:
+ * fold [P][32], column c * 9 + tap): out [P][64] = fold x w, w = the layer's weight [C][9][64] in dtype bf16, K = 9 * C.  out is fp32,
+ * or bf16 with FAVAE_OUT_BF16.  bins != NULL: the BatchNorm-backward sums of the layer in front (favae_conv_igemm_red mode 2) for
+ * `groups` BatchNorm groups of P / groups pixels: bins [groups][nbins][2][64], mean / invstd [groups][64], act bf16, raw fp32 or
+ * bf16 (FAVAE_RAW_BF16). */
+int favae_conv_folded_dgrad(const void* fold, const void* w, void* out, long long P, int K, int Cin, double* bins, int nbins,
+                            const void* act, const void* raw, const float* mean, const float* invstd, int groups, int dtype,
+                            void* stream);
+
 /* Live HIP-event timing of selected launches (measurement only; no reference counterpart). Every stride-th launch of each
  * kernel class is timed on its launch stream; collect() synchronises and returns [16][3] = launches, seconds, algorithmic
  * work per class: flops for the GEMM classes, bytes for the HBM-bound ones (7 BatchNorm-backward apply, 13 Adam); classes

@@ -548,6 +548,45 @@ def test_forward_convolution_over_the_folded_batch_in_two_bf16_terms(Nb, H, Cs):
     assert (rounded.cpu().double() - ref).abs().max() > 20 * (out.cpu().double() - ref).abs().max()
 
 
+@pytest.mark.parametrize("out_dt,raw_dt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
+@pytest.mark.parametrize("Nb,H,Co,groups", [(2, 64, 3, 1), (3, 20, 2, 1), (4, 32, 3, 2), (2, 16, 1, 2)])
+def test_input_gradient_of_the_final_conv_over_the_folded_gradient(Nb, H, Co, groups, out_dt, raw_dt):
+    """favae_conv_fold_taps(shifted) + favae_conv_folded_dgrad: the input gradient of final_layer.3 (Conv2d 64 -> Co, k3 s1 p1) as a
+    K = 32 GEMM on the bf16 matrix cores over the folded output gradient, against autograd on the bf16-rounded operands (1e-4 of
+    scale; bf16 output: one more rounding); the BatchNorm-backward sums of the layer in front per group of images against the same
+    sums formed from the fp32 result in float64."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(97 + H + Co)
+    Cin = 64
+    x = torch.zeros(Nb, Cin, H, H, requires_grad=True)
+    w = q(torch.randn(Co, Cin, 3, 3, generator=g) * 0.2, torch.bfloat16)
+    dy = q(torch.randn(Nb, Co, H, H, generator=g), torch.bfloat16)
+    F.conv2d(x, w, None, stride=1, padding=1).backward(dy)
+    ref = nhwc(x.grad).reshape(-1, Cin).double()
+    fold = lib.conv_fold_taps(nhwc(dy).to(torch.bfloat16).cuda(), Nb, H, H, H, H, 1, shifted=1)
+    wd = w.permute(0, 2, 3, 1).reshape(Co, 9, Cin).contiguous().to(torch.bfloat16).cuda()     # the layer's weight [Cout][tap][Cin]
+    P = Nb * H * H
+    act = torch.randn(P, Cin, generator=g).to(torch.bfloat16)
+    raw = q(torch.randn(P, Cin, generator=g), raw_dt)
+    mean = torch.randn(groups, Cin, generator=g) * 0.1
+    invstd = torch.rand(groups, Cin, generator=g) + 0.5
+    bins = torch.zeros(groups, 8, 2, Cin, dtype=torch.float64, device="cuda")
+    out = torch.full((P, Cin), float("nan"), device="cuda").to(out_dt)
+    lib.conv_folded_dgrad(fold, wd, out, bins, act.cuda(), raw.to(raw_dt).cuda(), mean.cuda(), invstd.cuda(), groups)
+    assert_close(out.float().cpu().double(), ref, 1e-4 if out_dt == torch.float32 else 4e-3)
+    plain = torch.full((P, Cin), float("nan"), device="cuda").to(out_dt)
+    lib.conv_folded_dgrad(fold, wd, plain)
+    assert torch.equal(plain, out)
+    dd = ref * torch.where(act.double() > 0, 1.0, 0.01)
+    Pg = P // groups
+    mu = mean.double().repeat_interleave(Pg, 0)
+    isd = invstd.double().repeat_interleave(Pg, 0)
+    xh = (raw.double() - mu) * isd
+    tot = bins.sum(1).cpu()
+    assert_close(tot[:, 0], dd.reshape(groups, Pg, Cin).sum(1), 1e-4)
+    assert_close(tot[:, 1], (dd * xh).reshape(groups, Pg, Cin).sum(1), 1e-4)
+
+
 @pytest.mark.parametrize("dt,tol", DT)
 @pytest.mark.parametrize("Nb,H,Co", [(2, 64, 3), (3, 18, 2), (64, 64, 3)])
 def test_folded_weight_gradient_final_conv(dt, tol, Nb, H, Co):
