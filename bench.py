@@ -43,7 +43,7 @@ CLASS_KERNEL = {2: "void igemm_kc<unsigned short, 64, 64, 2, 2, false, false>(Kc
 
 CLASS_KERNEL.update({7: "void colreduce<1, 4, BnBwdApplyF<unsigned short, float, float> >(int, int, int, int, int, double*, unsigned int*, BnBwdApplyF<unsigned short, float, float>)",
                      13: "void adam_kernel<true, false>(float*, float*, float*, float*, unsigned long, float, float, float, float, float, unsigned short*, unsigned long)"})
-PMC_JSON = os.path.join(ROOT, "profiles", "r2_pmc_traffic_per_launch.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r3_pmc_traffic_per_launch.json")
 
 
 def pmc_traffic(cls, dtype, key=None):
@@ -338,7 +338,7 @@ def main():
                         "region (weight gradients run on a side stream next to the main chain, so their durations include that "
                         "overlap); achieved = algorithmic flops per launch (dense-tap convention) / mean launch duration; traffic = "
                         "mean HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes "
-                        "(profiles/r2_pmc_traffic_per_launch.json)"},
+                        "(profiles/r3_pmc_traffic_per_launch.json)"},
             "roofline_hbm": None if domh is None else {
                 "bound": "hbm", "kernel": domh["kernel"], "achieved": domh["gb_per_s"], "peak": 8000.0, "unit": "GB/s",
                 "frac": domh["gb_per_s"] / 8000.0, "traffic": pmc_traffic(domh["cls"], a.dtype),

@@ -114,5 +114,11 @@ extern "C" int favae_allreduce_f32(favae_comm* c, float* buf, long long n, int a
     return FAVAE_OK;
 }
 
+extern "C" int favae_allreduce_f64(favae_comm* c, double* buf, long long n, int average, void* stream) {
+    FAVAE_CHECK_ARG(c && buf && n > 0, "favae_allreduce_f64: bad argument");
+    FAVAE_RCCL(g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat64, average ? ncclAvg : ncclSum, c->comm, (hipStream_t)stream));
+    return FAVAE_OK;
+}
+
 // ---- internal (vae_model.hip) ----------------------------------------------------------------------------------------
 int favae_comm_size(favae_comm* c) { return c->nranks; }

@@ -35,9 +35,25 @@ def _staged(t, fn):
     return t
 
 
+def _native_reduce(t, average):
+    """All-reduce of a contiguous fp64 / fp32 device tensor through the library's own communicator (favae_allreduce_f64 / _f32), on
+    the current stream: one communicator serves the gradient buckets of the VAE epochs and the FA statistics.  False when there is
+    no such communicator (gloo rehearsals, FAVAE_NATIVE_COMM=0) or the tensor is not eligible."""
+    if not (t.is_cuda and t.is_contiguous() and t.dtype in (torch.float64, torch.float32) and t.numel() > 0):
+        return False
+    comm = native_comm(t.device)
+    if comm is None:
+        return False
+    import ctypes
+    from . import lib as L
+    f = L.raw().favae_allreduce_f64 if t.dtype == torch.float64 else L.raw().favae_allreduce_f32
+    L.check(f(comm, L.ptr(t), ctypes.c_longlong(t.numel()), ctypes.c_int(1 if average else 0), L.stream_ptr()))
+    return True
+
+
 def sum_(t):
     """In-place sum over ranks (RCCL all-reduce on the device buffer)."""
-    if active():
+    if active() and not _native_reduce(t, False):
         _staged(t, lambda x: td.all_reduce(x, op=td.ReduceOp.SUM))
     return t
 
@@ -59,7 +75,7 @@ def sum_many_(ts):
 
 def mean_(t):
     """In-place mean over ranks.  RCCL has a native AVG; gloo does not."""
-    if active():
+    if active() and not _native_reduce(t, True):
         if td.get_backend() == "nccl":
             td.all_reduce(t, op=td.ReduceOp.AVG)
         else:

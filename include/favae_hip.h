@@ -408,6 +408,9 @@ int favae_comm_init(favae_comm** out, const char* rccl_path, const void* id128, 
 int favae_comm_destroy(favae_comm* c);
 /* In-place all-reduce (sum, or mean with average != 0) of n floats on `stream`. */
 int favae_allreduce_f32(favae_comm* c, float* buf, long long n, int average, void* stream);
+/* The same for n doubles: the sufficient statistics of the FA updates (X^T Z, Z^T Z, the sums of the multilabel update and of the
+ * reconstruction diagnostic) travel over the same communicator as the gradient buckets, on the caller's stream. */
+int favae_allreduce_f64(favae_comm* c, double* buf, long long n, int average, void* stream);
 /* favae_vae_train_epoch for data-parallel training (each rank passes its own shard / permutation / eps): per step the
  * gradient arena is averaged over the ranks in four buckets (decoder | enc.4 + heads | enc.3 | enc.0-2); a bucket's all-reduce
  * and the Adam step + weight re-layout of its layers run on the communicator's stream as soon as its last weight
