@@ -161,3 +161,40 @@ def test_a_batch_above_64_must_be_whole_groups():
     z = torch.zeros(100, 20, device="cuda")
     with pytest.raises(FavaeHipError, match="groups of 64"):
         eng.train_fwdbwd(data, idx, 100, z, None, 1.0, 1.0, 0.01)
+
+
+def test_imgvae_groups_option_runs_the_grouped_epoch():
+    """ImgVAE.GROUPS = 2 through the drop-in class (trainloop with no FA prior, as the pretraining call of cA/favae.py:690-700 makes
+    it): same visiting order and noise as the batch-64 trainloop, steps of 128 images.  Against the executor's epoch entry point
+    called directly with the replayed random draws from the same initial state (the plumbing: step count, metric averaging,
+    executor size), to 1e-4 of the epoch ELBO (same kernels; atomics reorder sums and Adam amplifies that over the three steps)."""
+    from favae_hip import imgvae
+    from favae_hip.engine import VaeEngine
+
+    class Grouped(imgvae.ImgVAE):
+        GROUPS = 2
+
+    n, z = 300, 20
+    img, _ = img_inputs(n)
+    torch.manual_seed(4)
+    np.random.seed(4)
+    vae = Grouped(dimx=z, channels=3, lr=1e-4, dataset="grouped", precision="f32")
+    sd0 = {k: v.detach().clone() for k, v in vae.state_dict().items()}
+    state = torch.get_rng_state()
+    vae.trainloop(img, epochs=1, favae=False)
+    assert vae._eng.batch_max == 128 and vae._eng.step == 3            # 128 + 128 + 44
+    torch.set_rng_state(state)                                            # replay the draws of the epoch (imgvae.py trainloop)
+    torch.empty((), dtype=torch.int64).random_()
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    g = torch.Generator()
+    g.manual_seed(seed)
+    perm = torch.randperm(n, generator=g)
+    eps = torch.cat([torch.randn(min(64, n - s), z) for s in range(0, n, 64)], 0)
+    eng = VaeEngine(z, 3, batch_max=128, dtype="f32")
+    eng.load_state_dict(sd0)
+    data = eng.upload_images(img)
+    ms = torch.zeros(3, 2, dtype=torch.float64, device="cuda")
+    eng.train_epoch(data, perm.to(torch.int32).cuda(), eps.cuda(), None, 1.0, 1.0, 0.01, 1e-4, 128, ms)
+    m = ms.cpu().numpy()
+    want = -(m[:, 0] + m[:, 1]).sum() / 3
+    assert abs(vae.elbo_training[0] - want) <= 1e-4 * abs(want), (vae.elbo_training[0], want)   # (measured 2.8e-6)
