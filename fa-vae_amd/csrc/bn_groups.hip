@@ -37,14 +37,16 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, float a, floa
 template <class T, class YT, class RT, int MODE>
 __global__ __launch_bounds__(256) void gbn_sums_kernel(const YT* __restrict__ y, const T* __restrict__ act, const RT* __restrict__ raw,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                       double* __restrict__ bins, int nbin, int Rg, int C, int rps) {
+                                                       const float* __restrict__ ab, double* __restrict__ bins, int nbin, int Rg, int C, int rps) {
     __shared__ double sm[2][16][64];
     const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4, g = blockIdx.z;
     const int c0 = blockIdx.x * 64 + cq * 4;
     const int r0 = blockIdx.y * rps, r1 = min(Rg, r0 + rps);
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
+    float4 fa = mu, fb = mu;   // ab != NULL: the forward pass's affine form, the LeakyReLU slope follows the sign of raw * a + b (act is not read)
     if (MODE == 2) { mu = *(const float4*)(mean + (size_t)g * C + c0); is = *(const float4*)(invstd + (size_t)g * C + c0); }
+    if (MODE == 2 && ab) { fa = *(const float4*)(ab + ((size_t)g * 2) * C + c0); fb = *(const float4*)(ab + ((size_t)g * 2 + 1) * C + c0); }
     for (int r = r0 + rl; r < r1; r += 16) {
         const size_t e = ((size_t)g * Rg + r) * C + c0;
         const float4 v = ld4<YT>(y + e);
@@ -52,7 +54,8 @@ __global__ __launch_bounds__(256) void gbn_sums_kernel(const YT* __restrict__ y,
             s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
             q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
         } else {
-            const float4 a = ld4<T>(act + e), x = ld4<RT>(raw + e);
+            const float4 x = ld4<RT>(raw + e);
+            const float4 a = ab ? make_float4(x.x * fa.x + fb.x, x.y * fa.y + fb.y, x.z * fa.z + fb.z, x.w * fa.w + fb.w) : ld4<T>(act + e);
             const float d0 = v.x * (a.x > 0.f ? 1.f : 0.01f), d1 = v.y * (a.y > 0.f ? 1.f : 0.01f);
             const float d2 = v.z * (a.z > 0.f ? 1.f : 0.01f), d3 = v.w * (a.w > 0.f ? 1.f : 0.01f);
             s[0] += d0; s[1] += d1; s[2] += d2; s[3] += d3;
@@ -85,7 +88,8 @@ __device__ __forceinline__ void group_totals(const double* __restrict__ bins, in
 template <class T, class RT>
 __global__ __launch_bounds__(256) void gbn_fwd_kernel(const RT* __restrict__ raw, const double* __restrict__ bins, int nbin,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ act,
-                                                      float* __restrict__ mean, float* __restrict__ invstd, int Rg, int C, float eps) {
+                                                      float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ ab_out, int Rg, int C,
+                                                      float eps) {
     // (8 KB of LDS: the 2048 blocks of a G = 8 launch are resident at once; with the fp64 totals staged in LDS too, 24 KB, only
     // 1536 were and the launch ran a second, third-full round)
     __shared__ float ab[2048];
@@ -100,7 +104,10 @@ __global__ __launch_bounds__(256) void gbn_fwd_kernel(const RT* __restrict__ raw
         const float a = is * gamma[c];
         ab[c] = a;
         ab[C + c] = beta[c] - (float)m * a;
-        if (blockIdx.x == 0) { mean[(size_t)g * C + c] = (float)m; invstd[(size_t)g * C + c] = is; }
+        if (blockIdx.x == 0) {
+            mean[(size_t)g * C + c] = (float)m; invstd[(size_t)g * C + c] = is;
+            if (ab_out) { ab_out[((size_t)g * 2) * C + c] = a; ab_out[((size_t)g * 2 + 1) * C + c] = beta[c] - (float)m * a; }
+        }
     }
     __syncthreads();
     const size_t nvec = (size_t)Rg * C / 4, base = (size_t)g * Rg * C;
@@ -137,8 +144,8 @@ __global__ void gbn_running_kernel(const float* __restrict__ mean, const float* 
 template <class T, class DT, class RT>
 __global__ __launch_bounds__(256) void gbn_bwd_kernel(const DT* __restrict__ dact, const T* __restrict__ act, const RT* __restrict__ raw,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                      const float* __restrict__ gamma, const double* __restrict__ bins, int nbin,
-                                                      T* __restrict__ draw, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      const float* __restrict__ gamma, const float* __restrict__ ab, const double* __restrict__ bins,
+                                                      int nbin, T* __restrict__ draw, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                       float* __restrict__ dbias, int Rg, int C) {
     __shared__ float kk[2048];
     __shared__ float cs[1024];
@@ -153,17 +160,20 @@ __global__ __launch_bounds__(256) void gbn_bwd_kernel(const DT* __restrict__ dac
     }
     __syncthreads();
     const int c = (tid * 4) % C;
-    float mu[4], is[4], gi[4], k1[4], k2[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float mu[4], is[4], gi[4], k1[4], k2[4], fa[4], fb[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         mu[j] = mean[(size_t)g * C + c + j]; is[j] = invstd[(size_t)g * C + c + j]; gi[j] = gamma[c + j] * is[j];
+        fa[j] = ab ? ab[((size_t)g * 2) * C + c + j] : 0.f; fb[j] = ab ? ab[((size_t)g * 2 + 1) * C + c + j] : 0.f;
         k1[j] = kk[c + j]; k2[j] = kk[C + c + j];
     }
     const size_t nvec = (size_t)Rg * C / 4, base = (size_t)g * Rg * C;
 #pragma unroll 2
     for (size_t i = (size_t)blockIdx.x * 256 + tid; i < nvec; i += (size_t)gridDim.x * 256) {
         const size_t e = base + i * 4;
-        const float4 d = ld4<DT>(dact + e), a = ld4<T>(act + e), x = ld4<RT>(raw + e);
+        const float4 d = ld4<DT>(dact + e), x = ld4<RT>(raw + e);
+        float4 a = make_float4(x.x * fa[0] + fb[0], x.y * fa[1] + fb[1], x.z * fa[2] + fb[2], x.w * fa[3] + fb[3]);   // (the forward pass's expression)
+        if (!ab) a = ld4<T>(act + e);   // uniform
         const float dv[4] = {d.x, d.y, d.z, d.w}, av[4] = {a.x, a.y, a.z, a.w}, xv[4] = {x.x, x.y, x.z, x.w};
         float o[4];
 #pragma unroll
@@ -199,10 +209,10 @@ inline int gbn_grid(long long Rg, int C) {
  * statistics), mode 2 = the two BatchNorm-backward sums of y = dact given act, raw, mean [G][C], invstd [G][C].  For tensors whose
  * producing GEMM split its reduction (no epilogue sums).  C a multiple of 64.  raw / dact are fp32, or bf16 with FAVAE_RAW_BF16 /
  * FAVAE_DACT_BF16 in dtype (FAVAE_BF16 only). */
-extern "C" int favae_gbn_sums(const void* y, const void* act, const void* raw, const float* mean, const float* invstd, double* bins,
-                              int nbins, int G, long long Rg, int C, int mode, int dtype, void* stream) {
+extern "C" int favae_gbn_sums(const void* y, const void* act, const void* raw, const float* mean, const float* invstd, const float* ab,
+                              double* bins, int nbins, int G, long long Rg, int C, int mode, int dtype, void* stream) {
     FAVAE_CHECK_ARG(y && bins && nbins >= 1 && G >= 1 && Rg >= 1 && Rg < (1LL << 30) && C >= 64 && C % 64 == 0, "favae_gbn_sums: bad argument");
-    FAVAE_CHECK_ARG(mode == 1 || (mode == 2 && act && raw && mean && invstd), "favae_gbn_sums: mode 1, or mode 2 with act / raw / mean / invstd");
+    FAVAE_CHECK_ARG(mode == 1 || (mode == 2 && (act || ab) && raw && mean && invstd), "favae_gbn_sums: mode 1, or mode 2 with act (or ab) / raw / mean / invstd");
     FAVAE_CHECK_ARG(GB_BASE(dtype) == FAVAE_F32 || GB_BASE(dtype) == FAVAE_BF16, "favae_gbn_sums: dtype");
     FAVAE_CHECK_ARG(!((GB_RAWBF(dtype) || GB_DACTBF(dtype)) && GB_BASE(dtype) != FAVAE_BF16), "favae_gbn_sums: bf16 raw / dact need FAVAE_BF16");
     const int slabs = (int)std::max<long long>(1, std::min<long long>(std::max(1, 512 / (G * (C / 64))), (Rg + 63) / 64));
@@ -210,7 +220,7 @@ extern "C" int favae_gbn_sums(const void* y, const void* act, const void* raw, c
     dim3 grid(C / 64, slabs, G);
     const bool rb = GB_RAWBF(dtype), db = GB_DACTBF(dtype);
 #define GS_LAUNCH(T, YT, RT, MODE) hipLaunchKernelGGL((gbn_sums_kernel<T, YT, RT, MODE>), grid, dim3(256), 0, ST, (const YT*)y, (const T*)act, (const RT*)raw, \
-                                                      mean, invstd, bins, nbins, (int)Rg, C, rps)
+                                                      mean, invstd, ab, bins, nbins, (int)Rg, C, rps)
     if (mode == 1) {
         if (rb) GS_LAUNCH(bf16_t, bf16_t, bf16_t, 1); else GS_LAUNCH(float, float, float, 1);
     } else if (GB_BASE(dtype) == FAVAE_F32) {
@@ -229,14 +239,14 @@ extern "C" int favae_gbn_sums(const void* y, const void* act, const void* raw, c
  * statistics take the average over the groups of the batch statistics (what averaging the ranks' running statistics gives in
  * the data-parallel run).  C <= 1024, a multiple of 4 that divides 1024.  raw fp32, or bf16 with FAVAE_RAW_BF16. */
 extern "C" int favae_gbn_fwd(const void* raw, const double* bins, int nbins, const float* gamma, const float* beta, void* act, float* mean,
-                             float* invstd, float* run_mean, float* run_var, int G, long long Rg, int C, float eps, float momentum,
+                             float* invstd, float* ab, float* run_mean, float* run_var, int G, long long Rg, int C, float eps, float momentum,
                              int dtype, void* stream) {
     FAVAE_CHECK_ARG(raw && bins && gamma && beta && act && mean && invstd && nbins >= 1 && G >= 1 && Rg >= 1 && Rg < (1LL << 30), "favae_gbn_fwd: bad argument");
     FAVAE_CHECK_ARG(C >= 4 && C <= 1024 && 1024 % C == 0, "favae_gbn_fwd: C = %d must divide 1024", C);
     FAVAE_CHECK_ARG(GB_BASE(dtype) == FAVAE_F32 || GB_BASE(dtype) == FAVAE_BF16, "favae_gbn_fwd: dtype");
     FAVAE_CHECK_ARG(!(GB_RAWBF(dtype) && GB_BASE(dtype) != FAVAE_BF16), "favae_gbn_fwd: FAVAE_RAW_BF16 needs FAVAE_BF16");
     dim3 grid(gbn_grid(Rg, C), G);
-#define GF_LAUNCH(T, RT) hipLaunchKernelGGL((gbn_fwd_kernel<T, RT>), grid, dim3(256), 0, ST, (const RT*)raw, bins, nbins, gamma, beta, (T*)act, mean, invstd, (int)Rg, C, eps)
+#define GF_LAUNCH(T, RT) hipLaunchKernelGGL((gbn_fwd_kernel<T, RT>), grid, dim3(256), 0, ST, (const RT*)raw, bins, nbins, gamma, beta, (T*)act, mean, invstd, ab, (int)Rg, C, eps)
     if (GB_BASE(dtype) == FAVAE_F32) GF_LAUNCH(float, float);
     else if (GB_RAWBF(dtype)) GF_LAUNCH(bf16_t, bf16_t);
     else GF_LAUNCH(bf16_t, float);
@@ -253,9 +263,9 @@ extern "C" int favae_gbn_fwd(const void* raw, const double* bins, int nbins, con
  * gradient w.r.t. the conv output; dgamma / dbeta / dbias (may be NULL) are ADDED to (fp32 atomics: the caller's gradient arena is
  * zero at the start of a step).  dact / raw fp32, or bf16 with FAVAE_DACT_BF16 / FAVAE_RAW_BF16. */
 extern "C" int favae_gbn_bwd(const void* dact, const void* act, const void* raw, const float* mean, const float* invstd, const float* gamma,
-                             const double* bins, int nbins, void* draw, float* dgamma, float* dbeta, float* dbias, int G, long long Rg,
+                             const float* ab, const double* bins, int nbins, void* draw, float* dgamma, float* dbeta, float* dbias, int G, long long Rg,
                              int C, int dtype, void* stream) {
-    FAVAE_CHECK_ARG(dact && act && raw && mean && invstd && gamma && bins && draw && dgamma && dbeta && nbins >= 1 && G >= 1 && Rg >= 1 && Rg < (1LL << 30),
+    FAVAE_CHECK_ARG(dact && (act || ab) && raw && mean && invstd && gamma && bins && draw && dgamma && dbeta && nbins >= 1 && G >= 1 && Rg >= 1 && Rg < (1LL << 30),
                     "favae_gbn_bwd: bad argument");
     FAVAE_CHECK_ARG(C >= 4 && C <= 1024 && 1024 % C == 0, "favae_gbn_bwd: C = %d must divide 1024", C);
     FAVAE_CHECK_ARG(GB_BASE(dtype) == FAVAE_F32 || GB_BASE(dtype) == FAVAE_BF16, "favae_gbn_bwd: dtype");
@@ -263,7 +273,7 @@ extern "C" int favae_gbn_bwd(const void* dact, const void* act, const void* raw,
     dim3 grid(gbn_grid(Rg, C), G);
     const bool rb = GB_RAWBF(dtype), db = GB_DACTBF(dtype);
 #define GB_LAUNCH(T, DT, RT) hipLaunchKernelGGL((gbn_bwd_kernel<T, DT, RT>), grid, dim3(256), 0, ST, (const DT*)dact, (const T*)act, (const RT*)raw, mean, invstd, \
-                                                gamma, bins, nbins, (T*)draw, dgamma, dbeta, dbias, (int)Rg, C)
+                                                gamma, ab, bins, nbins, (T*)draw, dgamma, dbeta, dbias, (int)Rg, C)
     if (GB_BASE(dtype) == FAVAE_F32) GB_LAUNCH(float, float, float);
     else if (db) { if (rb) GB_LAUNCH(bf16_t, bf16_t, bf16_t); else GB_LAUNCH(bf16_t, bf16_t, float); }
     else { if (rb) GB_LAUNCH(bf16_t, float, bf16_t); else GB_LAUNCH(bf16_t, float, float); }

@@ -141,6 +141,7 @@ struct KcParams {
     const void* red_act;
     const void* red_raw;   // fp32, or bf16 with red_raw_bf16
     const float *red_mean, *red_invstd;
+    const float* red_ab;   // grouped-batch mode, mode 2: [groups][2][Cout] affine form of the forward pass; the slope from raw * a + b, act is not read
     int red_raw_bf16;
     // FI kernels: `in` is the fp32 output `raw` [pixels][Cin] of a convolution whose BatchNorm(train) + LeakyReLU has not been
     // applied; the A operand is lrelu(raw * a[c] + b[c]) rounded to T, formed when a chunk goes to LDS.  in_ab = a[Cin] | b[Cin]
@@ -516,6 +517,11 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
             float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
             const int rgrp = p.red_group_rows ? m0 / p.red_group_rows : 0;   // block-uniform
             if (red == 2 && n < p.Cout) { mu = *(const float4*)(p.red_mean + (size_t)rgrp * p.Cout + n); is = *(const float4*)(p.red_invstd + (size_t)rgrp * p.Cout + n); }
+            float4 fa = make_float4(0.f, 0.f, 0.f, 0.f), fb = fa;
+            if (red == 2 && p.red_ab && n < p.Cout) {
+                fa = *(const float4*)(p.red_ab + ((size_t)rgrp * 2) * p.Cout + n);
+                fb = *(const float4*)(p.red_ab + ((size_t)rgrp * 2 + 1) * p.Cout + n);
+            }
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) {
                 const int row = (ftid >> 4) + RPP * i, m = m0 + row;
@@ -550,15 +556,6 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
                     rq[0] += (double)v.x * v.x; rq[1] += (double)v.y * v.y; rq[2] += (double)v.z * v.z; rq[3] += (double)v.w * v.w;
                 } else if (red == 2) {
                     const size_t e = opix * p.Cout + n;
-                    float a[4];
-                    if constexpr (sizeof(T) == 2) {
-                        const uint2 u = *(const uint2*)((const bf16_t*)p.red_act + e);
-                        a[0] = __uint_as_float(u.x << 16); a[1] = __uint_as_float(u.x & 0xffff0000u);
-                        a[2] = __uint_as_float(u.y << 16); a[3] = __uint_as_float(u.y & 0xffff0000u);
-                    } else {
-                        const float4 t = *(const float4*)((const float*)p.red_act + e);
-                        a[0] = t.x; a[1] = t.y; a[2] = t.z; a[3] = t.w;
-                    }
                     float4 x;
                     if (p.red_raw_bf16) {
                         const uint2 u = *(const uint2*)((const bf16_t*)p.red_raw + e);
@@ -566,6 +563,17 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
                                         __uint_as_float(u.y & 0xffff0000u));
                     } else {
                         x = *(const float4*)((const float*)p.red_raw + e);
+                    }
+                    float a[4];
+                    if (p.red_ab) {   // block-uniform: the forward pass's expression, its sign is the sign of the stored activation
+                        a[0] = x.x * fa.x + fb.x; a[1] = x.y * fa.y + fb.y; a[2] = x.z * fa.z + fb.z; a[3] = x.w * fa.w + fb.w;
+                    } else if constexpr (sizeof(T) == 2) {
+                        const uint2 u = *(const uint2*)((const bf16_t*)p.red_act + e);
+                        a[0] = __uint_as_float(u.x << 16); a[1] = __uint_as_float(u.x & 0xffff0000u);
+                        a[2] = __uint_as_float(u.y << 16); a[3] = __uint_as_float(u.y & 0xffff0000u);
+                    } else {
+                        const float4 t = *(const float4*)((const float*)p.red_act + e);
+                        a[0] = t.x; a[1] = t.y; a[2] = t.z; a[3] = t.w;
                     }
                     const float d0 = v.x * (a[0] > 0.f ? 1.f : 0.01f), d1 = v.y * (a[1] > 0.f ? 1.f : 0.01f);
                     const float d2 = v.z * (a[2] > 0.f ? 1.f : 0.01f), d3 = v.w * (a[3] > 0.f ? 1.f : 0.01f);
@@ -1106,7 +1114,7 @@ int dispatch_pm(PmParams p, hipStream_t st) {
 
 #define RC_(x) do { int rc_ = (x); if (rc_ != FAVAE_OK) return rc_; } while (0)
 namespace {
-struct RedArgs { double* bins; int nbin, mode; const void* act; const void* raw; const float *mean, *invstd; int* fused; int raw_bf16; int group_images = 0; };
+struct RedArgs { double* bins; int nbin, mode; const void* act; const void* raw; const float *mean, *invstd; int* fused; int raw_bf16; int group_images = 0; const float* ab = nullptr; };
 struct Fin { const float *gamma, *beta; float *mean, *invstd, *ab, *run_mean, *run_var; float eps, mom; };
 
 // a ticket per launch that finalises BatchNorm statistics: slots of a zero-initialised device array handed out in rotation
@@ -1160,7 +1168,7 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
     p.Nb = Nb; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
     p.ks = ks; p.stride = stride; p.pad = pad; p.ldw = ks * ks * Cin; p.splitk = splitk; p.out_bf16 = out_bf16;
     p.red_bins = red.bins; p.red_nbin = red.nbin; p.red_mode = red.mode; p.red_act = red.act; p.red_raw = red.raw;
-    p.red_mean = red.mean; p.red_invstd = red.invstd; p.red_raw_bf16 = red.raw_bf16;
+    p.red_mean = red.mean; p.red_invstd = red.invstd; p.red_raw_bf16 = red.raw_bf16; p.red_ab = red.ab;
     p.ep_ab = ep_ab;
     if (ep_ab) FAVAE_CHECK_ARG(splitk == 1 && Cout % 4 == 0 && Cout > 32 && ((uintptr_t)ep_ab % 16) == 0,
                                "favae_conv_igemm_affine: needs splitk = 1 and Cout > 32, a multiple of 4");
@@ -1218,13 +1226,16 @@ extern "C" int favae_conv_igemm_red(const void* in, const void* w, const float* 
 extern "C" int favae_conv_igemm_red_groups(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi,
                                            int Cin, int Ho, int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk,
                                            int dtype, double* bins, int nbins, int mode, const void* act, const void* raw,
-                                           const float* mean, const float* invstd, int group_images, int* fused, void* stream) {
+                                           const float* mean, const float* invstd, const float* ab, int group_images, int* fused,
+                                           void* stream) {
     FAVAE_CHECK_ARG(bins && fused && nbins >= 1 && nbins <= 256 && group_images >= 1, "favae_conv_igemm_red_groups: bins / fused / nbins / group_images");
     FAVAE_CHECK_ARG(mode == 1 || (mode == 2 && act && raw && mean && invstd), "favae_conv_igemm_red_groups: mode 1, or mode 2 with act/raw/mean/invstd");
+    FAVAE_CHECK_ARG(!ab || ((uintptr_t)ab % 16 == 0 && Cout % 4 == 0), "favae_conv_igemm_red_groups: ab must be 16-byte aligned, Cout a multiple of 4");
     const int raw_bf16 = (dtype & FAVAE_RAW_BF16) != 0;
     FAVAE_CHECK_ARG(!(raw_bf16 && (dtype & 0xF) != FAVAE_BF16), "favae_conv_igemm_red_groups: FAVAE_RAW_BF16 needs FAVAE_BF16");
     RedArgs red{bins, nbins, mode, act, raw, mean, invstd, fused, raw_bf16};
     red.group_images = group_images;
+    red.ab = mode == 2 ? ab : nullptr;
     return conv_igemm_impl(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype & ~FAVAE_RAW_BF16, red, stream);
 }
 
@@ -1329,15 +1340,15 @@ extern "C" int favae_conv_folded_fwd_split(const void* fold_hl, const float* w, 
 }
 
 extern "C" int favae_conv_folded_dgrad(const void* fold, const void* w, void* out, long long P, int K, int Cin, double* bins, int nbins,
-                                       const void* act, const void* raw, const float* mean, const float* invstd, int groups, int dtype,
-                                       void* stream) {
+                                       const void* act, const void* raw, const float* mean, const float* invstd, const float* ab, int groups,
+                                       int dtype, void* stream) {
     FAVAE_CHECK_ARG(fold && w && out && P > 0 && P < (1ll << 31) && groups >= 1, "favae_conv_folded_dgrad: bad argument");
     FAVAE_CHECK_ARG((dtype & 0xF) == FAVAE_BF16 && Cin == 64 && K >= 1 && K <= 32, "favae_conv_folded_dgrad: bf16, 64 input channels, K <= 32");
     FAVAE_CHECK_ARG((dtype & ~(0xF | FAVAE_OUT_BF16 | FAVAE_RAW_BF16)) == 0, "favae_conv_folded_dgrad: unknown storage flag in dtype 0x%x", dtype);
-    FAVAE_CHECK_ARG(!bins || (nbins >= 1 && act && raw && mean && invstd), "favae_conv_folded_dgrad: the sums need nbins, act, raw, mean, invstd");
+    FAVAE_CHECK_ARG(!bins || (nbins >= 1 && (act || ab) && raw && mean && invstd), "favae_conv_folded_dgrad: the sums need nbins, act (or ab), raw, mean, invstd");
     FAVAE_CHECK_ARG(((uintptr_t)fold % 16) == 0 && ((uintptr_t)out % 16) == 0, "favae_conv_folded_dgrad: 16-byte alignment");
     return folded_dgrad_launch(fold, w, K, out, P, groups, (dtype & FAVAE_OUT_BF16) != 0, bins, nbins, act, raw, (dtype & FAVAE_RAW_BF16) != 0, mean,
-                               invstd, (hipStream_t)stream);
+                               invstd, ab, (hipStream_t)stream);
 }
 
 extern "C" int favae_conv_wgrad_prefolded(const void* rows, int Rc, int Rst, const void* cols, int Cc, int Cst, float* dw,

@@ -35,5 +35,5 @@ int folded_fwd_launch(const void* fold, const void* w, int K, const float* bias,
 // bins != NULL: the BatchNorm-backward sums of the layer in front per group of P / groups pixels (bins [groups][nbin][2][64], act bf16,
 // raw fp32 or bf16, mean / invstd [groups][64]).
 int folded_dgrad_launch(const void* fold, const void* w, int K, void* out, long long P, int groups, int out_bf16, double* bins, int nbin,
-                        const void* act, const void* raw, int raw_bf16, const float* mean, const float* invstd, hipStream_t st);
+                        const void* act, const void* raw, int raw_bf16, const float* mean, const float* invstd, const float* ab, hipStream_t st);
 int fold_taps_hl_launch(const float* src, void* dst, int Nb, int Hq, int Wq, int Hn, int Wn, int Cs, int stride, hipStream_t st);

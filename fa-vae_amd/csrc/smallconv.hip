@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void folded_dgrad_kernel(const bf16_t* __restr
                                                            void* __restrict__ out_, int P, double* __restrict__ bins, int nbin,
                                                            const bf16_t* __restrict__ act, const void* __restrict__ raw_,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const FlagCarry carry) {
+                                                           const float* __restrict__ ab, const FlagCarry carry) {
     carry_store(carry);
     const size_t goff = (size_t)blockIdx.y * P;
     fold += goff * 32;
@@ -501,6 +501,12 @@ __global__ __launch_bounds__(256) void folded_dgrad_kernel(const bf16_t* __restr
         mu0 = mean[blockIdx.y * 64 + 2 * r]; mu1 = mean[blockIdx.y * 64 + 2 * r + 1];
         is0 = invstd[blockIdx.y * 64 + 2 * r]; is1 = invstd[blockIdx.y * 64 + 2 * r + 1];
     }
+    // ab != NULL: the slope of the LeakyReLU from the forward pass's affine form raw * a + b instead of the stored activation
+    float fa0 = 0.f, fa1 = 0.f, fb0 = 0.f, fb1 = 0.f;
+    if (RED && ab) {
+        fa0 = ab[(blockIdx.y * 2) * 64 + 2 * r]; fa1 = ab[(blockIdx.y * 2) * 64 + 2 * r + 1];
+        fb0 = ab[(blockIdx.y * 2 + 1) * 64 + 2 * r]; fb1 = ab[(blockIdx.y * 2 + 1) * 64 + 2 * r + 1];
+    }
     double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
     const int ngroup = (P + 31) / 32, nw = gridDim.x * 4;
     for (int g = blockIdx.x * 4 + wave; g < ngroup; g += nw) {
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(256) void folded_dgrad_kernel(const bf16_t* __restr
             for (int i = 0; i < 16; ++i) {
                 const int p = min(p0 + (i & 3) + 8 * (i >> 2) + 4 * h, P - 1);
                 const size_t e = (goff + p) * 64 + 2 * r;
-                pa2[i] = *(const unsigned*)(act + e);
+                pa2[i] = ab ? 0u : *(const unsigned*)(act + e);
                 if (RAW_BF) {
                     const unsigned u = *(const unsigned*)((const bf16_t*)raw_ + e);
                     px[i] = make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
@@ -540,7 +546,8 @@ __global__ __launch_bounds__(256) void folded_dgrad_kernel(const bf16_t* __restr
                 if (OUT_BF) *(unsigned*)((bf16_t*)out_ + e) = (unsigned)f32_to_bf16(c0[i]) | ((unsigned)f32_to_bf16(c1[i]) << 16);
                 else *(float2*)((float*)out_ + e) = make_float2(c0[i], c1[i]);
                 if (RED) {
-                    const float a_e = __uint_as_float(pa2[i] << 16), a_o = __uint_as_float(pa2[i] & 0xffff0000u);
+                    float a_e = __uint_as_float(pa2[i] << 16), a_o = __uint_as_float(pa2[i] & 0xffff0000u);
+                    if (ab) { a_e = px[i].x * fa0 + fb0; a_o = px[i].y * fa1 + fb1; }   // uniform
                     const float d0 = c0[i] * (a_e > 0.f ? 1.f : 0.01f), d1 = c1[i] * (a_o > 0.f ? 1.f : 0.01f);
                     s0 += d0; s1 += d1;
                     q0 += (double)d0 * ((px[i].x - mu0) * is0); q1 += (double)d1 * ((px[i].y - mu1) * is1);
@@ -565,14 +572,14 @@ __global__ __launch_bounds__(256) void folded_dgrad_kernel(const bf16_t* __restr
 }  // namespace
 
 int folded_dgrad_launch(const void* fold, const void* w, int K, void* out, long long P, int groups, int out_bf16, double* bins, int nbin,
-                        const void* act, const void* raw, int raw_bf16, const float* mean, const float* invstd, hipStream_t st) {
+                        const void* act, const void* raw, int raw_bf16, const float* mean, const float* invstd, const float* ab, hipStream_t st) {
     const FlagCarry carry = favae_take_flag_carry();
     FAVAE_CHECK_ARG(groups >= 1 && P % groups == 0 && (groups == 1 || (P / groups) % 32 == 0), "folded input gradient: %lld pixels in %d groups", P, groups);
     const int Pg = (int)(P / groups);
     const int ngroup = (Pg + 31) / 32;
     const int grid = std::max(1, std::min((ngroup + 3) / 4, std::max(128, 1024 / groups)));
 #define FD_LAUNCH(OB, RB, RD) hipLaunchKernelGGL((folded_dgrad_kernel<OB, RB, RD>), dim3(grid, groups), dim3(256), 0, st, (const bf16_t*)fold, (const bf16_t*)w, K, \
-                                                 out, Pg, bins, std::max(1, nbin), (const bf16_t*)act, raw, mean, invstd, carry)
+                                                 out, Pg, bins, std::max(1, nbin), (const bf16_t*)act, raw, mean, invstd, ab, carry)
     if (!bins) { if (out_bf16) FD_LAUNCH(true, false, false); else FD_LAUNCH(false, false, false); }
     else if (out_bf16) { if (raw_bf16) FD_LAUNCH(true, true, true); else FD_LAUNCH(true, false, true); }
     else { if (raw_bf16) FD_LAUNCH(false, true, true); else FD_LAUNCH(false, false, true); }

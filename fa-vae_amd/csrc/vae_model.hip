@@ -226,6 +226,9 @@ struct Vae {
     unsigned* flags; unsigned step_no, join_seq; bool vals; int vals_ok;   // vals_ok: -1 not probed, 0 unsupported, 1 usable
     unsigned mark_prev, mark_cur;   // worker queue positions at the start of the previous / this step (bounded run-ahead)
     char* shp(int half) const { return SH + (size_t)half * sh_half; }
+    // grouped-batch mode: the affine form of layer l's BatchNorm as the forward pass wrote it (the backward launches take the LeakyReLU
+    // slope from raw * a + b and leave the stored activation unread; FAVAE_FUSE_MASK bit 0x10000000: from the activation, as before)
+    const float* gab(int l) const { return (fuse & 0x10000000u) ? nullptr : ab[l]; }
     const void* Wf(int l) const { return dtype == FAVAE_F32 ? (const void*)(P + L[l].w_off) : (const void*)(shp(sh_sel) + L[l].wc_off * esz); }
     const void* Wt(int l) const { return (const void*)(shp(sh_sel) + L[l].wt_off * esz); }
     long long rows(int l, int B) const { return (long long)B * L[l].Hout * L[l].Hout; }
@@ -400,7 +403,7 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
         v.draw[l] = (char*)c.take(n * v.esz);
         v.mean[l] = (float*)c.take((size_t)Gmax * v.L[l].Cout * 4);
         v.invstd[l] = (float*)c.take((size_t)Gmax * v.L[l].Cout * 4);
-        v.ab[l] = (float*)c.take((size_t)v.L[l].Cout * 8);
+        v.ab[l] = (float*)c.take((size_t)Gmax * v.L[l].Cout * 8);   // a | b of the forward pass's BatchNorm, per group
         v.dbp[l] = v.L[l].bn ? (double*)c.take((size_t)DBP_SLABS * v.L[l].Cout * 8) : nullptr;
     }
     const size_t img = (size_t)B * 64 * 64 * v.ch;
@@ -546,10 +549,10 @@ int conv_fwd(Vae& v, int l, const void* in, int B, void* st, bool pooled = false
         } else {
             const int scatter = L.kind == CONVT_S2, stride = L.kind == CONV_S1 ? 1 : 2;
             RC(favae_conv_igemm_red_groups(in, v.Wf(l), bias, v.raw[l], B, L.Hin, L.Hin, L.Cin, L.Hout, L.Hout, L.Cout, 3, stride, 1, scatter, sk,
-                                           dt, v.sbins[l], nb, 1, nullptr, nullptr, nullptr, nullptr, 64, &fused, st));
+                                           dt, v.sbins[l], nb, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 64, &fused, st));
         }
         if (!fused)
-            RC(favae_gbn_sums(v.raw[l], nullptr, nullptr, nullptr, nullptr, v.sbins[l], nb, G, v.rows(l, 64), L.Cout, 1,
+            RC(favae_gbn_sums(v.raw[l], nullptr, nullptr, nullptr, nullptr, nullptr, v.sbins[l], nb, G, v.rows(l, 64), L.Cout, 1,
                               v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0), st));
         v.stats_fused[l] = true;
         return FAVAE_OK;
@@ -616,7 +619,7 @@ int bn_fwd(Vae& v, int l, int B, bool train, void* st) {
     if (train && B > 64 && v.stats_fused[l]) {   // grouped-batch mode
         v.stats_fused[l] = false;
         return favae_gbn_fwd(v.raw[l], v.sbins[l], bins_for(v.rows(l, 64)), v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l], v.invstd[l],
-                             v.BUF + L.rm_off, v.BUF + L.rv_off, B / 64, v.rows(l, 64), L.Cout, 1e-5f, 0.1f, dt, st);
+                             v.ab[l], v.BUF + L.rm_off, v.BUF + L.rv_off, B / 64, v.rows(l, 64), L.Cout, 1e-5f, 0.1f, dt, st);
     }
     if (train && v.bn_published[l]) {   // the producing GEMM finished the statistics (mean, invstd, running stats, a | b)
         v.bn_published[l] = v.stats_fused[l] = false;
@@ -725,14 +728,14 @@ int bn_bwd(Vae& v, int l, int B, void* st) {
         const int G = B / 64, nb = bins_for(v.rows(l, 64));
         const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0) | (v.dact_bf[l] ? FAVAE_DACT_BF16 : 0);
         if (!v.grad_fused[l])
-            RC(favae_gbn_sums(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.gbins[l], nb, G, v.rows(l, 64), L.Cout, 2, dt, st));
+            RC(favae_gbn_sums(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.gab(l), v.gbins[l], nb, G, v.rows(l, 64), L.Cout, 2, dt, st));
         v.grad_fused[l] = false;
         v.dbias_slabs[l] = 0;
         // The bias of a convolution in front of a train-mode BatchNorm has an analytically zero gradient (the mean subtraction
         // removes it); the batch-64 step carries the column sums of draw, i.e. rounding noise, as the reference's autograd does.  Here
         // the gradient is left at its exact value, zero: 2048 blocks x C atomics onto C addresses cost up to 3.5x the apply itself
         // (enc.2 at G = 8: 60.7 us against 16.9 us for the forward apply over the same elements, tools/bench_gbn.py).
-        return favae_gbn_bwd(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.gbins[l], nb, v.draw[l], v.G + L.g_off,
+        return favae_gbn_bwd(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.gab(l), v.gbins[l], nb, v.draw[l], v.G + L.g_off,
                              v.G + L.be_off, nullptr, G, v.rows(l, 64), L.Cout, dt, st);
     }
     if (v.grad_fused[l]) {   // the GEMM that produced dact[l] summed the two reductions in its epilogue
@@ -945,7 +948,7 @@ int dgrad(Vae& v, int l, float* out, int B, void* st, bool out_zeroed, bool out_
         const int G = B > 64 ? B / 64 : 1;
         double* bins = B > 64 ? v.gbins[o] : ((v.fuse & 4u) ? gbins64(v, o) : nullptr);
         RC(favae_conv_folded_dgrad(v.fold, v.Wf(L_OUT), out, (long long)B * L.Hin * L.Hin, 9 * L.Cout, L.Cin, bins, bins_for(v.rows(o, B > 64 ? 64 : B)),
-                                   v.act[o], v.raw[o], v.mean[o], v.invstd[o], G, dt | (v.raw_bf[o] ? FAVAE_RAW_BF16 : 0), st));
+                                   v.act[o], v.raw[o], v.mean[o], v.invstd[o], B > 64 ? v.gab(o) : nullptr, G, dt | (v.raw_bf[o] ? FAVAE_RAW_BF16 : 0), st));
         v.grad_fused[o] = bins != nullptr;
         return FAVAE_OK;
     }
@@ -954,7 +957,7 @@ int dgrad(Vae& v, int l, float* out, int B, void* st, bool out_zeroed, bool out_
         int fused = 0;
         RC(favae_conv_igemm_red_groups(v.draw[l], v.Wt(l), nullptr, out, B, L.Hout, L.Hout, L.Cout, L.Hin, L.Hin, L.Cin, 3, stride, 1, scatter, sk,
                                        dt | (v.raw_bf[o] ? FAVAE_RAW_BF16 : 0), v.gbins[o], bins_for(v.rows(o, 64)), 2, v.act[o], v.raw[o], v.mean[o],
-                                       v.invstd[o], 64, &fused, st));
+                                       v.invstd[o], v.gab(o), 64, &fused, st));
         v.grad_fused[o] = fused != 0;
         return FAVAE_OK;
     }

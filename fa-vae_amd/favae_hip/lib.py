@@ -152,7 +152,7 @@ def conv_folded_fwd_split(folded_hl, w_f32, bias, out, bins=None):
     return out
 
 
-def conv_folded_dgrad(folded, w, out, bins=None, act=None, raw=None, mean=None, invstd=None, groups=1):
+def conv_folded_dgrad(folded, w, out, bins=None, act=None, raw=None, mean=None, invstd=None, groups=1, ab=None):
     """favae_conv_folded_dgrad: out [P, 64] (f32 or bf16) = folded [P, 32] x w [K, 64] (bf16); optional BatchNorm-backward sums of the
     layer in front into bins [groups, nbins, 2, 64] f64 (zeroed by the caller) given act (bf16), raw (f32 / bf16), mean / invstd
     [groups, 64]."""
@@ -161,7 +161,7 @@ def conv_folded_dgrad(folded, w, out, bins=None, act=None, raw=None, mean=None, 
     assert out.dtype in (torch.float32, torch.bfloat16) and out.is_contiguous()
     flags = BF16 | (OUT_BF16 if out.dtype == torch.bfloat16 else 0) | (RAW_BF16 if raw is not None and raw.dtype == torch.bfloat16 else 0)
     check(_lib.favae_conv_folded_dgrad(ptr(folded), ptr(w), ptr(out), ctypes.c_longlong(P), _i(K), _i(64), ptr(bins),
-                                       _i(0 if bins is None else bins.shape[-3]), ptr(act), ptr(raw), ptr(mean), ptr(invstd), _i(groups),
+                                       _i(0 if bins is None else bins.shape[-3]), ptr(act), ptr(raw), ptr(mean), ptr(invstd), ptr(ab), _i(groups),
                                        _i(flags), stream_ptr()))
     return out
 

@@ -89,19 +89,21 @@ int favae_conv_igemm_red(const void* in, const void* w, const float* bias, float
  * mean / invstd [G][Cout]); favae_gbn_sums fills such bins for a tensor whose producer could not; favae_gbn_fwd / favae_gbn_bwd are
  * BatchNorm(train) + LeakyReLU forward / backward of the G groups (running statistics: average over the groups of the batch
  * statistics; dgamma / dbeta / dbias are ADDED to).  Tensors [G * Rg][C] NHWC, C <= 1024 dividing 1024; raw / dact fp32, or bf16
- * with FAVAE_RAW_BF16 / FAVAE_DACT_BF16 in dtype (the conv launch: FAVAE_OUT_BF16 for its output, FAVAE_RAW_BF16 for the raw it reads). */
+ * with FAVAE_RAW_BF16 / FAVAE_DACT_BF16 in dtype (the conv launch: FAVAE_OUT_BF16 for its output, FAVAE_RAW_BF16 for the raw it reads).
+ * ab (may be NULL) [G][2][C]: the affine form act = lrelu(raw * a + b) of the forward pass, written by favae_gbn_fwd; the backward
+ * launches that are given it take the LeakyReLU slope from the sign of raw * a + b and do not read act (2 bytes per element less). */
 int favae_conv_igemm_red_groups(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi, int Cin, int Ho,
                                 int Wo, int Cout, int ks, int stride, int pad, int scatter, int splitk, int dtype, double* bins,
                                 int nbins, int mode, const void* act, const void* raw, const float* mean, const float* invstd,
-                                int group_images, int* fused, void* stream);
-int favae_gbn_sums(const void* y, const void* act, const void* raw, const float* mean, const float* invstd, double* bins, int nbins,
-                   int G, long long Rg, int C, int mode, int dtype, void* stream);
+                                const float* ab, int group_images, int* fused, void* stream);
+int favae_gbn_sums(const void* y, const void* act, const void* raw, const float* mean, const float* invstd, const float* ab, double* bins,
+                   int nbins, int G, long long Rg, int C, int mode, int dtype, void* stream);
 int favae_gbn_fwd(const void* raw, const double* bins, int nbins, const float* gamma, const float* beta, void* act, float* mean,
-                  float* invstd, float* run_mean, float* run_var, int G, long long Rg, int C, float eps, float momentum, int dtype,
-                  void* stream);
+                  float* invstd, float* ab, float* run_mean, float* run_var, int G, long long Rg, int C, float eps, float momentum,
+                  int dtype, void* stream);
 long long favae_vae_epoch_steps(long long n, int batch);
 int favae_gbn_bwd(const void* dact, const void* act, const void* raw, const float* mean, const float* invstd, const float* gamma,
-                  const double* bins, int nbins, void* draw, float* dgamma, float* dbeta, float* dbias, int G, long long Rg, int C,
+                  const float* ab, const double* bins, int nbins, void* draw, float* dgamma, float* dbeta, float* dbias, int G, long long Rg, int C,
                   int dtype, void* stream);
 
 int favae_conv_igemm_bn(const void* in, const float* in_ab, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi,
@@ -178,10 +180,10 @@ int favae_conv_folded_fwd_split(const void* fold_hl, const float* w, const float
  * fold [P][32], column c * 9 + tap): out [P][64] = fold x w, w = the layer's weight [C][9][64] in dtype bf16, K = 9 * C.  out is fp32,
  * or bf16 with FAVAE_OUT_BF16.  bins != NULL: the BatchNorm-backward sums of the layer in front (favae_conv_igemm_red mode 2) for
  * `groups` BatchNorm groups of P / groups pixels: bins [groups][nbins][2][64], mean / invstd [groups][64], act bf16, raw fp32 or
- * bf16 (FAVAE_RAW_BF16). */
+ * bf16 (FAVAE_RAW_BF16); ab (may be NULL) [groups][2][64] as in favae_gbn_fwd: the slope from raw * a + b, act is not read. */
 int favae_conv_folded_dgrad(const void* fold, const void* w, void* out, long long P, int K, int Cin, double* bins, int nbins,
-                            const void* act, const void* raw, const float* mean, const float* invstd, int groups, int dtype,
-                            void* stream);
+                            const void* act, const void* raw, const float* mean, const float* invstd, const float* ab, int groups,
+                            int dtype, void* stream);
 
 /* Live HIP-event timing of selected launches (measurement only; no reference counterpart). Every stride-th launch of each
  * kernel class is timed on its launch stream; collect() synchronises and returns [16][3] = launches, seconds, algorithmic

@@ -585,6 +585,15 @@ def test_input_gradient_of_the_final_conv_over_the_folded_gradient(Nb, H, Co, gr
     tot = bins.sum(1).cpu()
     assert_close(tot[:, 0], dd.reshape(groups, Pg, Cin).sum(1), 1e-4)
     assert_close(tot[:, 1], (dd * xh).reshape(groups, Pg, Cin).sum(1), 1e-4)
+    # the slope of the LeakyReLU from the forward pass's affine form (raw * a + b) instead of the stored activation
+    ab = torch.stack([torch.rand(groups, Cin, generator=g) + 0.5, torch.randn(groups, Cin, generator=g) * 0.3], 1).contiguous()     # [groups][2][Cin]
+    pre = raw.to(raw_dt).float() * ab[:, 0].repeat_interleave(Pg, 0) + ab[:, 1].repeat_interleave(Pg, 0)
+    dd2 = ref * torch.where(pre.double() > 0, 1.0, 0.01)
+    bins.zero_()
+    lib.conv_folded_dgrad(fold, wd, out, bins, None, raw.to(raw_dt).cuda(), mean.cuda(), invstd.cuda(), groups, ab=ab.cuda())
+    tot = bins.sum(1).cpu()
+    assert_close(tot[:, 0], dd2.reshape(groups, Pg, Cin).sum(1), 1e-4)
+    assert_close(tot[:, 1], (dd2 * xh).reshape(groups, Pg, Cin).sum(1), 1e-4)
 
 
 @pytest.mark.parametrize("dt,tol", DT)

@@ -47,23 +47,25 @@ for name, Rg, C in (("final_layer.0", 64 * 4096, 64), ("enc.0/dec.3", 64 * 1024,
     rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
     dg, db, dbias = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
     st = L.stream_ptr()
+    ab_t = torch.zeros(G, 2, C, device="cuda")
+    AB = L.ptr(ab_t) if os.environ.get("GBN_AB", "1") == "1" else None
     if C >= 64:
-        L.check(raw_.favae_gbn_sums(L.ptr(raw), None, None, None, None, L.ptr(bins), _i(nb), _i(G), _ll(Rg), _i(C), _i(1), _i(L.BF16), st))
+        L.check(raw_.favae_gbn_sums(L.ptr(raw), None, None, None, None, None, L.ptr(bins), _i(nb), _i(G), _ll(Rg), _i(C), _i(1), _i(L.BF16), st))
     else:
         x = raw.view(G, Rg, C).double()
         bins[:, 0, 0] = x.sum(1)
         bins[:, 0, 1] = (x * x).sum(1)
 
     def fwd():
-        L.check(raw_.favae_gbn_fwd(L.ptr(raw), L.ptr(bins), _i(nb), L.ptr(gamma), L.ptr(beta), L.ptr(act), L.ptr(mean), L.ptr(invstd), L.ptr(rm),
+        L.check(raw_.favae_gbn_fwd(L.ptr(raw), L.ptr(bins), _i(nb), L.ptr(gamma), L.ptr(beta), L.ptr(act), L.ptr(mean), L.ptr(invstd), AB, L.ptr(rm),
                                    L.ptr(rv), _i(G), _ll(Rg), _i(C), _f(1e-5), _f(0.1), _i(L.BF16), st))
 
     def bwd():
-        L.check(raw_.favae_gbn_bwd(L.ptr(dact), L.ptr(act), L.ptr(raw), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(gbins), _i(nb), L.ptr(draw),
+        L.check(raw_.favae_gbn_bwd(L.ptr(dact), L.ptr(act), L.ptr(raw), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), AB, L.ptr(gbins), _i(nb), L.ptr(draw),
                                    L.ptr(dg), L.ptr(db), L.ptr(dbias), _i(G), _ll(Rg), _i(C), _i(L.BF16), st))
 
     def sums2():
-        L.check(raw_.favae_gbn_sums(L.ptr(dact), L.ptr(act), L.ptr(raw), L.ptr(mean), L.ptr(invstd), L.ptr(gbins), _i(nb), _i(G), _ll(Rg), _i(C), _i(2),
+        L.check(raw_.favae_gbn_sums(L.ptr(dact), L.ptr(act), L.ptr(raw), L.ptr(mean), L.ptr(invstd), AB, L.ptr(gbins), _i(nb), _i(G), _ll(Rg), _i(C), _i(2),
                                     _i(L.BF16), st))
 
     fwd()

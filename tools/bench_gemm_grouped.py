@@ -65,7 +65,7 @@ for name, kind, Ci, Co, Hi, Ho in LAYERS:
 
     def fwd_red():
         L.check(raw_.favae_conv_igemm_red_groups(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(out), _i(B), _i(Hi), _i(Hi), _i(Ci), _i(Ho), _i(Ho), _i(Co), _i(3),
-                                                 _i(2), _i(1), _i(sc_f), _i(0), _i(L.BF16), L.ptr(bins), _i(nb(64 * Ho * Ho)), _i(1), None, None, None, None,
+                                                 _i(2), _i(1), _i(sc_f), _i(0), _i(L.BF16), L.ptr(bins), _i(nb(64 * Ho * Ho)), _i(1), None, None, None, None, None,
                                                  _i(64), ctypes.byref(fused), st))
 
     def dg():
@@ -75,7 +75,7 @@ for name, kind, Ci, Co, Hi, Ho in LAYERS:
     def dg_red():
         L.check(raw_.favae_conv_igemm_red_groups(L.ptr(dy), L.ptr(wt), None, L.ptr(dx), _i(B), _i(Ho), _i(Ho), _i(Co), _i(Hi), _i(Hi), _i(Ci), _i(3), _i(2),
                                                  _i(1), _i(sc_b), _i(0), _i(L.BF16), L.ptr(bins), _i(nb(64 * Hi * Hi)), _i(2), L.ptr(actin), L.ptr(rawin),
-                                                 L.ptr(mean), L.ptr(invstd), _i(64), ctypes.byref(fused), st))
+                                                 L.ptr(mean), L.ptr(invstd), None, _i(64), ctypes.byref(fused), st))
 
     flop = 2.0 * B * Ho * Ho * Co * 9 * Ci / (4 if kind == "t" else 1)
     mb_f = (x.numel() * 2 + out.numel() * 4) / 1e6
