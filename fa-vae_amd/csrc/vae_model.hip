@@ -1268,7 +1268,9 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             v.join_pending = false;
         }
         RC(encoder_fwd(v, B, true, st, true));
-        const bool decin = !(v.fuse & 0x4000u) && v.z <= 128 && (long long)B * v.z <= 12288;   // reparameterise + KL + decoder_input in one launch
+        // reparameterise + KL + decoder_input in one launch (every block recomputes z: beyond 128 images the separate launches are faster,
+        // 3.186 -> 3.158 ms per 512-image step)
+        const bool decin = !(v.fuse & 0x4000u) && v.z <= 128 && (long long)B * v.z <= 12288 && B <= 128;
         if (decin)
             RC(favae_reparam_kl_decoder_input(v.raw[L_FC], eps, prior, idx, tau, B, v.z, v.zlat, v.stdq, metrics2_out + 1, v.Wf(L_DI),
                                               v.P + v.L[L_DI].b_off, v.act[L_DI], v.L[L_DI].Cout, v.dtype, st));
