@@ -300,14 +300,24 @@ class ImgVAE(VAE):
         nb = e.epoch_steps(n, step_batch)
         metrics = torch.zeros(nb, 2, dtype=torch.float64, device=self.device)
         elbo_checker = -1e20
-        for ep in range(int(epochs)):
+
+        def draw_epoch():
+            """The random draws of one epoch, in the reference's order (:227-231 through the DataLoader and reparameterize :89-92)."""
             torch.empty((), dtype=torch.int64).random_()                      # DataLoader iterator base seed
             seed = int(torch.empty((), dtype=torch.int64).random_().item())   # RandomSampler seed
             g = torch.Generator()
             g.manual_seed(seed)
             perm = torch.randperm(n_loc, generator=g)[:n]
             eps = torch.cat([torch.randn(min(self.BATCH, n - s), self.dimx) for s in range(0, n, self.BATCH)], 0)
-            perm_d, eps_d = perm.to(torch.int32).to(self.device), eps.to(self.device)
+            return perm.to(torch.int32), eps
+
+        # The draws of epoch e + 1 (65 ms of host time at N = 202 599: one randn per mini-batch from the global generator) are made
+        # while the kernels of epoch e run: nothing else touches the generators between the epochs of one trainloop, so their order
+        # is the reference's; the last epoch draws nothing ahead.
+        drawn = draw_epoch() if int(epochs) > 0 else None
+        for ep in range(int(epochs)):
+            perm, eps = drawn
+            perm_d, eps_d = perm.to(self.device), eps.to(self.device)
             if not dist.active():
                 e.train_epoch(data, perm_d, eps_d, prior, tau_f, float(beta), float(self.var_x), float(self.lr), step_batch, metrics)
             elif dist.native_comm(self.device) is not None:
@@ -341,6 +351,7 @@ class ImgVAE(VAE):
                     e.adam(float(self.lr))
                 dist.mean_(metrics)
                 dist.mean_(e.BUF)
+            drawn = draw_epoch() if ep + 1 < int(epochs) else None              # (the epoch above is still running on the GPU)
             m = metrics.cpu().numpy()
             e.poll_error()
             rec, kl = m[:, 0], m[:, 1]
