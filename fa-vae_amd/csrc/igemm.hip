@@ -738,6 +738,12 @@ struct PmParams {
     SlabRider rider;   // a small reduction for the first blocks (common.h); partial == NULL: none
     int xcd_units;     // > 0: XCD-contiguous work units (see the kernel), = blocks / 8
     int hw_shift, ws_shift;   // log2 of Hs*Ws and Ws when both are powers of two (every layer of the model), else -1
+    // ADAM instantiation (unsplit 64x64 launches whose Rst, Cst are multiples of 64): the tile is not stored as a gradient; the
+    // optimiser step of its weights is taken in the epilogue, with the arithmetic of adam_kernel (vae_kernels.hip), and the dtype copy
+    // ad_wc [Rst][taps][Cst] and the transpose ad_wt [Cst][taps][Rst] (either may be NULL) are written from the fresh weights.
+    float *ad_p, *ad_m, *ad_v;
+    void *ad_wc, *ad_wt;
+    float ad_b1, ad_b2, ad_eps, ad_step, ad_bc2s;
 };
 
 // LEAN: both channel counts fill 16-byte vectors and both operands are below 2 GB.  The operands come through buffer
@@ -746,7 +752,7 @@ struct PmParams {
 // from shifts (power-of-two feature maps) and halo pixels get an out-of-range offset.  Out-of-range loads return zeros: no
 // select per vector.  (The general form below spent ~100 instructions per vector on two integer divisions, clamps and 64-bit
 // products, against two MFMAs per chunk and wave: issue-bound, like igemm_kc before its addressing was hoisted.)
-template <class T, int BM, int BN, int WM, int WN, bool LEAN>
+template <class T, int BM, int BN, int WM, int WN, bool LEAN, bool ADAM = false>
 __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
     constexpr int VE = 16 / sizeof(T);
     constexpr int PADB = sizeof(T) == 2 ? 0 : 16;   // bf16: swizzled rows without padding (frag_pm); fp32: 16 bytes of padding
@@ -975,6 +981,43 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
     }
 
     const int ntaps = p.ks * p.ks;
+    if constexpr (ADAM) {
+        static_assert(BM == 64 && BN == 64 && TM == 1 && TN == 1, "Adam in the epilogue: 64x64 tiles");
+        // Adam on the tile (torch.optim.Adam, cA/celeba_deepvanilla_vae.py:131,250; same expressions as adam_kernel), then the two
+        // dtype layouts of the fresh weights: wc in place, wt through an LDS transpose so that its rows leave as 128 contiguous bytes
+        constexpr int TRS = 64 + 16 / (int)sizeof(T);   // elements per LDS row (+16 B against bank conflicts)
+        static_assert(64 * TRS * (int)sizeof(T) <= STAGE, "the transposed tile must fit a stage");
+        __syncthreads();                                // every wave is done with the operand stages
+        T* tr = (T*)lds;
+        const int col_l = wn * 32 + (lane & 31), col = c0 + col_l;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row_l = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), row = r0 + row_l;
+            const size_t idx = ((size_t)row * ntaps + tap) * p.Cst + col;
+            const float g = acc[0][0][r];
+            float P = p.ad_p[idx], M = p.ad_m[idx], V = p.ad_v[idx];
+            adam_update(P, g, M, V, p.ad_b1, p.ad_b2, p.ad_eps, p.ad_step, p.ad_bc2s);
+            p.ad_p[idx] = P; p.ad_m[idx] = M; p.ad_v[idx] = V;
+            if constexpr (sizeof(T) == 2) {
+                const bf16_t q = f32_to_bf16(P);
+                if (p.ad_wc) ((bf16_t*)p.ad_wc)[idx] = q;
+                tr[col_l * TRS + row_l] = q;
+            } else {
+                if (p.ad_wc) ((float*)p.ad_wc)[idx] = P;
+                tr[col_l * TRS + row_l] = P;
+            }
+        }
+        __syncthreads();
+        if (p.ad_wt) {   // block-uniform: 64 columns x 4 pieces of 16 rows per thread pass
+            const int cl = tid >> 2, piece = tid & 3;
+            T* dst = (T*)p.ad_wt + ((size_t)(c0 + cl) * ntaps + tap) * p.Rst + r0 + piece * 16;
+            const uint4* src = (const uint4*)(tr + cl * TRS + piece * 16);
+            constexpr int NV = 16 * (int)sizeof(T) / 16;   // 16-byte vectors per piece
+#pragma unroll
+            for (int i = 0; i < NV; ++i) ((uint4*)dst)[i] = src[i];
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -1059,6 +1102,8 @@ int dispatch_kc(KcParams p, int classes, int target_blocks, int* fused, hipStrea
     return launch_kc<T, TR, false, 64, 64, 2, 2>(p, classes, st);
 }
 
+thread_local int g_pm_adam_applied = 0;   // did the last weight-gradient launch of this thread take the optimiser step in its epilogue?
+
 template <class T>
 int dispatch_pm(PmParams p, hipStream_t st) {
     p.carry = favae_take_flag_carry();
@@ -1102,7 +1147,14 @@ int dispatch_pm(PmParams p, hipStream_t st) {
         if (lean) hipLaunchKernelGGL((igemm_pm<T, BM_, BN_, WM_, WN_, true>), grid, dim3(256), 0, st, p);    \
         else hipLaunchKernelGGL((igemm_pm<T, BM_, BN_, WM_, WN_, false>), grid, dim3(256), 0, st, p);        \
     } while (0)
-    if (tile == 0) PM_LAUNCH(32, 128, 1, 4);
+    // the optimiser step in the epilogue: unsplit 64x64 launches over whole tiles, 16-byte aligned transposed rows
+    g_pm_adam_applied = 0;
+    if (p.ad_p && !(tile == 2 && p.splitk == 1 && lean && p.Rst % 64 == 0 && p.Cst % 64 == 0 && p.Rst == p.Rc && p.Cst == p.Cc)) p.ad_p = nullptr;
+    if (p.ad_p) {
+        g_pm_adam_applied = 1;
+        hipLaunchKernelGGL((igemm_pm<T, 64, 64, 2, 2, true, true>), grid, dim3(256), 0, st, p);
+    }
+    else if (tile == 0) PM_LAUNCH(32, 128, 1, 4);
     else if (tile == 1) PM_LAUNCH(128, 32, 4, 1);
     else PM_LAUNCH(64, 64, 2, 2);
 #undef PM_LAUNCH
@@ -1288,7 +1340,39 @@ extern "C" int favae_conv_wgrad(const void* rows, int Rc, int rows_large, const 
     p.rp = rows; p.cp = cols; p.dw = dw; p.Rc = Rc; p.Cc = Cc; p.r_large = rows_large; p.c_large = cols_large;
     p.Nb = Nb; p.Hs = Hs; p.Ws = Ws; p.Hl = Hl; p.Wl = Wl; p.ks = ks; p.stride = stride; p.pad = pad;
     p.splitk = splitk; p.ntn = 1; p.K = Nb * Hs * Ws; p.Rst = Rc; p.Cst = Cc;
+    p.ad_p = nullptr;
     return dtype == FAVAE_F32 ? dispatch_pm<float>(p, st) : dispatch_pm<bf16_t>(p, st);
+}
+
+/* favae_conv_wgrad whose epilogue takes the Adam step of the layer's weights (torch.optim.Adam of cA/celeba_deepvanilla_vae.py:131
+ * applied by optimizer.step() :250; same arithmetic as favae_adam_step) and writes their dtype copy wc [Rc][ks*ks][Cc] and transpose
+ * wt [Cc][ks*ks][Rc] (either may be NULL), where the launch runs unsplit in 64x64 tiles (Rc, Cc multiples of 64): *applied = 1, dw is
+ * not touched, p / m / v [Rc][ks*ks][Cc] are updated in place.  Otherwise *applied = 0 and the call is favae_conv_wgrad into dw. */
+extern "C" int favae_conv_wgrad_adam(const void* rows, int Rc, int rows_large, const void* cols, int Cc, int cols_large, float* dw,
+                                     float* p_, float* m_, float* v_, void* wc, void* wt, int Nb, int Hs, int Ws, int Hl, int Wl, int ks,
+                                     int stride, int pad, int splitk, float lr, float beta1, float beta2, float eps, long long step,
+                                     int dtype, int* applied, void* stream) {
+    FAVAE_CHECK_ARG(rows && cols && dw && p_ && m_ && v_ && applied && step >= 1, "favae_conv_wgrad_adam: null pointer / step");
+    FAVAE_CHECK_ARG(Nb > 0 && Hs > 0 && Ws > 0 && Rc > 0 && Cc > 0, "favae_conv_wgrad_adam: bad shape");
+    FAVAE_CHECK_ARG((ks == 1 && pad == 0) || (ks == 3 && pad == 1), "favae_conv_wgrad_adam: ks/pad must be 1/0 or 3/1");
+    FAVAE_CHECK_ARG(stride == 1 || stride == 2, "favae_conv_wgrad_adam: stride");
+    FAVAE_CHECK_ARG(dtype == FAVAE_F32 || dtype == FAVAE_BF16, "favae_conv_wgrad_adam: dtype");
+    FAVAE_CHECK_ARG(!(rows_large && cols_large), "favae_conv_wgrad_adam: at most one gathered operand");
+    FAVAE_CHECK_ARG(Hs == (Hl + 2 * pad - ks) / stride + 1 && Ws == (Wl + 2 * pad - ks) / stride + 1, "favae_conv_wgrad_adam: small/large size mismatch");
+    FAVAE_CHECK_ARG((size_t)Nb * Hl * Wl < (1u << 31), "favae_conv_wgrad_adam: too many pixels");
+    FAVAE_CHECK_ARG(((uintptr_t)rows % 16) == 0 && ((uintptr_t)cols % 16) == 0 && (!wt || (uintptr_t)wt % 16 == 0), "favae_conv_wgrad_adam: 16-byte alignment");
+    *applied = 0;
+    if (Rc <= 4 || Cc <= 4) return favae_conv_wgrad(rows, Rc, rows_large, cols, Cc, cols_large, dw, Nb, Hs, Ws, Hl, Wl, ks, stride, pad, splitk, dtype, stream);
+    PmParams p;
+    p.rp = rows; p.cp = cols; p.dw = dw; p.Rc = Rc; p.Cc = Cc; p.r_large = rows_large; p.c_large = cols_large;
+    p.Nb = Nb; p.Hs = Hs; p.Ws = Ws; p.Hl = Hl; p.Wl = Wl; p.ks = ks; p.stride = stride; p.pad = pad;
+    p.splitk = splitk; p.ntn = 1; p.K = Nb * Hs * Ws; p.Rst = Rc; p.Cst = Cc;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    p.ad_p = p_; p.ad_m = m_; p.ad_v = v_; p.ad_wc = wc; p.ad_wt = wt;
+    p.ad_b1 = beta1; p.ad_b2 = beta2; p.ad_eps = eps; p.ad_step = (float)((double)lr / bc1); p.ad_bc2s = (float)sqrt(bc2);
+    const int rc = dtype == FAVAE_F32 ? dispatch_pm<float>(p, (hipStream_t)stream) : dispatch_pm<bf16_t>(p, (hipStream_t)stream);
+    if (rc == FAVAE_OK) *applied = g_pm_adam_applied;
+    return rc;
 }
 
 extern "C" size_t favae_conv_wgrad_folded_scratch(int Nb, int Hl, int Wl, int dtype) {
@@ -1362,6 +1446,7 @@ extern "C" int favae_conv_wgrad_prefolded(const void* rows, int Rc, int Rst, con
     PmParams p;
     p.rp = rows; p.cp = cols; p.dw = dw; p.Rc = Rc; p.Cc = Cc; p.Rst = Rst; p.Cst = Cst; p.r_large = 0; p.c_large = 0;
     p.Nb = 1; p.Hs = 1; p.Ws = (int)K; p.Hl = 1; p.Wl = (int)K; p.ks = 1; p.stride = 1; p.pad = 0; p.splitk = splitk; p.ntn = 1; p.K = (int)K;
+    p.ad_p = nullptr;
     return dtype == FAVAE_F32 ? dispatch_pm<float>(p, (hipStream_t)stream) : dispatch_pm<bf16_t>(p, (hipStream_t)stream);
 }
 

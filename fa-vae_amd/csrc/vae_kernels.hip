@@ -1337,12 +1337,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         float4 P = ((float4*)p)[i], G = ((const float4*)g)[i], M = ((float4*)m)[i], V = ((float4*)v)[i];
         float* pp = (float*)&P; float* gg = (float*)&G; float* mm = (float*)&M; float* vv = (float*)&V;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            mm[j] = mm[j] + (1.f - b1) * (gg[j] - mm[j]);
-            vv[j] = vv[j] * b2 + (1.f - b2) * gg[j] * gg[j];
-            const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
-            pp[j] = pp[j] - step_size * (mm[j] / denom);
-        }
+        for (int j = 0; j < 4; ++j) adam_update(pp[j], gg[j], mm[j], vv[j], b1, b2, eps, step_size, bc2_sqrt);
         ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V;
         if (CLEAR_G) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (COPY && i < ncopy4) {   // bf16 shadow of the leading (weight) part of the slice, same layout
@@ -1366,12 +1361,7 @@ __global__ __launch_bounds__(256) void adam_wprep_kernel(float* __restrict__ p, 
     auto upd = [&](float4& P, const float4& G, float4& M, float4& V) {
         float* pp = (float*)&P; const float* gg = (const float*)&G; float* mm = (float*)&M; float* vv = (float*)&V;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            mm[j] = mm[j] + (1.f - b1) * (gg[j] - mm[j]);
-            vv[j] = vv[j] * b2 + (1.f - b2) * gg[j] * gg[j];
-            const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
-            pp[j] = pp[j] - step_size * (mm[j] / denom);
-        }
+        for (int j = 0; j < 4; ++j) adam_update(pp[j], gg[j], mm[j], vv[j], b1, b2, eps, step_size, bc2_sqrt);
     };
     if ((int)blockIdx.x >= ntiles) {
         const size_t nb = gridDim.x - ntiles;

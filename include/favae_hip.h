@@ -82,6 +82,15 @@ int favae_conv_igemm_red(const void* in, const void* w, const float* bias, float
  *     LeakyReLU and in_ab the (a | b) its launch published; the activation lrelu(in * a[c] + b[c]), rounded to dtype, is formed
  *     when a chunk of the A operand goes to LDS.  Cin in {64, 128, 192, 256}, Cout > 32.  The materialised activation, where the
  *     backward pass wants it, is favae_bn_lrelu_fwd_ab(in, in_ab, ...): same bytes. */
+/* favae_conv_wgrad whose epilogue takes the Adam step of the layer's weights (torch.optim.Adam, cA/celeba_deepvanilla_vae.py:131,
+ * applied by optimizer.step() :250; the arithmetic of favae_adam_step) and writes their dtype copy wc [Rc][ks*ks][Cc] and transpose
+ * wt [Cc][ks*ks][Rc] (either may be NULL) where the launch runs unsplit in 64x64 tiles (Rc, Cc multiples of 64): *applied = 1, dw is
+ * not touched, p / m / v [Rc][ks*ks][Cc] are updated in place.  Otherwise *applied = 0 and the call is favae_conv_wgrad into dw. */
+int favae_conv_wgrad_adam(const void* rows, int Rc, int rows_large, const void* cols, int Cc, int cols_large, float* dw, float* p,
+                          float* m, float* v, void* wc, void* wt, int Nb, int Hs, int Ws, int Hl, int Wl, int ks, int stride, int pad,
+                          int splitk, float lr, float beta1, float beta2, float eps, long long step, int dtype, int* applied,
+                          void* stream);
+
 /* Grouped-batch mode (no counterpart launch in the reference; SURVEY.md 7 "Hard parts": a larger batch per step with the BatchNorm
  * group size kept at the reference's 64, celeba_deepvanilla_vae.py:218 with nn.BatchNorm2d :34,58,72).  A batch of G x 64 images
  * whose BatchNorm statistics are taken per group of 64: with the mean loss this is the G-rank data-parallel step on

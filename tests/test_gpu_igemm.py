@@ -671,3 +671,57 @@ def test_final_conv_with_loss_in_one_launch(dt, tol, Nb, H, Co):
             lib.conv_wgrad(rows, 0, cols, 1, torch.zeros(128, 9, 64, device="cuda"), 4, 8, 8, 16, 16, 3, 2, 1, -1)
         assert abs(rec.item() - rec0.item()) <= 1e-12 * abs(rec0.item())
         assert_close(dbias.cpu(), dbias0.cpu(), 1e-6)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind,Nb,Cin,Cout,H", [("conv", 64, 512, 1024, 4), ("convT", 64, 1024, 512, 4), ("conv", 64, 256, 512, 8), ("conv", 64, 64, 128, 32)])
+def test_weight_gradient_with_the_adam_step_in_its_epilogue(dt, kind, Nb, Cin, Cout, H):
+    """favae_conv_wgrad_adam: where the weight-gradient GEMM runs unsplit in 64x64 tiles its epilogue takes the optimiser step and
+    writes both dtype layouts of the fresh weights: bit-identical to favae_conv_wgrad + favae_adam_step + favae_weight_prep (same
+    accumulators, same expressions); where it does not (the last case: 18 tiles x 9 taps split their reduction over 16 384 pixels)
+    it is favae_conv_wgrad."""
+    import ctypes
+    lib = _lib()
+    rawl = lib.raw()
+    i_, ll_, f_ = ctypes.c_int, ctypes.c_longlong, ctypes.c_float
+    g = torch.Generator().manual_seed(5 + Cin + H)
+    Hs, Hl = (H // 2, H) if kind == "conv" else (H, H * 2)       # small / large feature map of the stride-2 layer
+    if kind == "conv":      # rows = draw [Nb, Hs, Hs, Cout] (small grid), cols = layer input [Nb, Hl, Hl, Cin] (gathered)
+        rows = torch.randn(Nb, Hs, Hs, Cout, generator=g).to(dt).cuda()
+        cols = torch.randn(Nb, Hl, Hl, Cin, generator=g).to(dt).cuda()
+        rl, cl = 0, 1
+    else:                   # ConvTranspose: rows = draw on the large grid (gathered), cols = layer input on the small grid
+        rows = torch.randn(Nb, Hl, Hl, Cout, generator=g).to(dt).cuda()
+        cols = torch.randn(Nb, Hs, Hs, Cin, generator=g).to(dt).cuda()
+        rl, cl = 1, 0
+    n = Cout * 9 * Cin
+    P0 = (torch.randn(n, generator=g) * 0.05).cuda()
+    M0, V0 = (torch.randn(n, generator=g) * 1e-3).cuda(), (torch.rand(n, generator=g) * 1e-4).cuda()
+    code = lib.dtype_code(rows)
+    # reference: three launches
+    dw = torch.zeros(n, device="cuda")
+    lib.check(rawl.favae_conv_wgrad(lib.ptr(rows), i_(Cout), i_(rl), lib.ptr(cols), i_(Cin), i_(cl), lib.ptr(dw), i_(Nb), i_(Hs), i_(Hs), i_(Hl), i_(Hl),
+                                    i_(3), i_(2), i_(1), i_(-1), i_(code), lib.stream_ptr()))
+    P1, M1, V1 = P0.clone(), M0.clone(), V0.clone()
+    lib.check(rawl.favae_adam_step(lib.ptr(P1), lib.ptr(dw), lib.ptr(M1), lib.ptr(V1), ll_(n), f_(1e-3), f_(0.9), f_(0.999), f_(1e-8), ll_(7), lib.stream_ptr()))
+    wc1, wt1 = torch.empty(n, dtype=dt, device="cuda"), torch.empty(n, dtype=dt, device="cuda")
+    lib.check(rawl.favae_weight_prep(lib.ptr(P1), lib.ptr(wc1), lib.ptr(wt1), i_(Cout), i_(9), i_(Cin), i_(code), lib.stream_ptr()))
+    # one launch
+    P2, M2, V2 = P0.clone(), M0.clone(), V0.clone()
+    dw2 = torch.zeros(n, device="cuda")
+    wc2, wt2 = torch.zeros(n, dtype=dt, device="cuda"), torch.zeros(n, dtype=dt, device="cuda")
+    applied = ctypes.c_int(-1)
+    lib.check(rawl.favae_conv_wgrad_adam(lib.ptr(rows), i_(Cout), i_(rl), lib.ptr(cols), i_(Cin), i_(cl), lib.ptr(dw2), lib.ptr(P2), lib.ptr(M2), lib.ptr(V2),
+                                         lib.ptr(wc2), lib.ptr(wt2), i_(Nb), i_(Hs), i_(Hs), i_(Hl), i_(Hl), i_(3), i_(2), i_(1), i_(-1), f_(1e-3), f_(0.9),
+                                         f_(0.999), f_(1e-8), ll_(7), i_(code), ctypes.byref(applied), lib.stream_ptr()))
+    torch.cuda.synchronize()
+    if H == 32:
+        assert applied.value == 0 and torch.equal(P2, P0)
+        assert_close(dw2.cpu(), dw.cpu(), 1e-5)           # (split reduction: atomics reorder the sum)
+        return
+    assert applied.value == 1
+    assert not dw2.any()
+    assert torch.equal(M2, M1), ((M2 - M1).abs().max().item(), (M2 != M1).sum().item(), n)
+    assert torch.equal(V2, V1), ((V2 - V1).abs().max().item(), (V2 != V1).sum().item())
+    assert torch.equal(P2, P1), ((P2 - P1).abs().max().item(), (P2 != P1).sum().item())
+    assert torch.equal(wc2, wc1) and torch.equal(wt2, wt1)

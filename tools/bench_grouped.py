@@ -1,5 +1,5 @@
 """Grouped-batch mode: samples/s of the epoch entry point at G = 1, 2, 4, 8 BatchNorm groups per step (bf16 and fp32).
-Run on the GPU box: python tools/bench_grouped.py [n]"""
+Run on the GPU box: python tools/bench_grouped.py [n [dtypes [groups]]]"""
 import os
 import sys
 import time
@@ -16,8 +16,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 z = 20
 rng = np.random.RandomState(0)
 img = torch.from_numpy(rng.randint(0, 256, size=(n, 64, 64, 3), dtype=np.uint8)).cuda()
-for dtype in ("bf16", "f32"):
-    for G in (1, 2, 4, 8, 16):
+dtypes = sys.argv[2].split(",") if len(sys.argv) > 2 else ("bf16", "f32")
+groups = [int(g) for g in sys.argv[3].split(",")] if len(sys.argv) > 3 else (1, 2, 4, 8, 16)
+for dtype in dtypes:
+    for G in groups:
         batch = 64 * G
         eng = VaeEngine(z, 3, batch_max=batch, dtype=dtype)
         torch.manual_seed(0)
