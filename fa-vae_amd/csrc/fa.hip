@@ -28,9 +28,13 @@ __device__ __forceinline__ f64x4 mfma_f64(double a, double b, f64x4 c) {
 // nothing to stage).  The eight waves are added through LDS in wave order, the slabs in slab order by atb_finish =>
 // bitwise reproducible.  HBM-bound: 8 B * N * (da + db) read, 8 B * nslab * da * dbp of partials written and re-read.
 // ---------------------------------------------------------------------------------------------------------
+// SYM (A and B are the same matrix, Z^T [Z | 1] and X^T [X | 1]): the tile groups on the diagonal load the rows once for both
+// operands and run the 10 tiles on or above the diagonal of their 4 x 4 instead of 16; the tiles below leave as the transposes
+// of those above (bitwise the value the full product gives: the same products in the same order).
 constexpr int TI = 4, TJ = 4;
 constexpr int ATB_WAVES = 8;   // 8: two waves per SIMD at one block per CU (see atb_geom)
 
+template <bool SYM>
 __global__ __launch_bounds__(64 * ATB_WAVES) void atb_kernel(const double* __restrict__ A, int lda, int da,
                                                              const double* __restrict__ B, int ldb, int db, int ones, long long N,
                                                              int rps, int gj, double* __restrict__ partial) {
@@ -46,6 +50,7 @@ __global__ __launch_bounds__(64 * ATB_WAVES) void atb_kernel(const double* __res
         for (int b = 0; b < TJ; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
     // tiles of this group that exist (block-uniform): a 20 x 21 statistic is 2 x 2 tiles, not the 4 x 4 of the group
     const int ti = min(TI, (da - i0 + 15) / 16), tj = min(TJ, (dbp - j0 + 15) / 16);
+    const bool diag = SYM && i0 == j0;   // block-uniform
     // Two 4-row steps per iteration: up to 16 independent 8-byte loads per lane in flight.  The loads of the NEXT iteration are
     // issued before the MFMAs of this one (two register sets, the loop unrolled by two): the kernel is a stream over A and B, and
     // with ~3 waves per SIMD a wave that waits for its loads before every batch of MFMAs left the matrix pipe idle two thirds of the time.
@@ -59,10 +64,18 @@ __global__ __launch_bounds__(64 * ATB_WAVES) void atb_kernel(const double* __res
                 const int i = i0 + a * 16 + lc;
                 av[u][a] = (a < ti && ok && i < da) ? A[r * lda + i] : 0.0;
             }
+            if (diag) {   // (TI == TJ: column j of tile b is row i of tile b)
 #pragma unroll
-            for (int b = 0; b < TJ; ++b) {
-                const int j = j0 + b * 16 + lc;
-                bv[u][b] = (b >= tj || !ok) ? 0.0 : (j < db ? B[r * ldb + j] : (j == db && ones ? 1.0 : 0.0));
+                for (int b = 0; b < TJ; ++b) {
+                    const int j = j0 + b * 16 + lc;
+                    bv[u][b] = (b >= tj || !ok) ? 0.0 : (j < db ? av[u][b] : (j == db && ones ? 1.0 : 0.0));
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < TJ; ++b) {
+                    const int j = j0 + b * 16 + lc;
+                    bv[u][b] = (b >= tj || !ok) ? 0.0 : (j < db ? B[r * ldb + j] : (j == db && ones ? 1.0 : 0.0));
+                }
             }
         }
     };
@@ -73,7 +86,7 @@ __global__ __launch_bounds__(64 * ATB_WAVES) void atb_kernel(const double* __res
             for (int a = 0; a < TI; ++a)
 #pragma unroll
                 for (int b = 0; b < TJ; ++b)
-                    if (a < ti && b < tj) acc[a][b] = mfma_f64(av[u][a], bv[u][b], acc[a][b]);   // uniform
+                    if (a < ti && b < tj && !(diag && b < a)) acc[a][b] = mfma_f64(av[u][a], bv[u][b], acc[a][b]);   // uniform
     };
     constexpr long long STEP = 8 * ATB_WAVES;
     double av0[2][TI], bv0[2][TJ], av1[2][TI], bv1[2][TJ];
@@ -104,7 +117,11 @@ __global__ __launch_bounds__(64 * ATB_WAVES) void atb_kernel(const double* __res
             double t = (red[0][bg][lane] + red[1][bg][lane]) + (red[2][bg][lane] + red[3][bg][lane]);
             if constexpr (ATB_WAVES == 8) t += (red[4][bg][lane] + red[5][bg][lane]) + (red[6][bg][lane] + red[7][bg][lane]);
             const int i = i0 + a * 16 + lr + 4 * g, j = j0 + b * 16 + lc;
-            if (i < da && j < dbp) out[(size_t)i * dbp + j] = t;
+            if (diag && b < a) continue;   // (written as the transpose of tile (b, a))
+            if (i < da && j < dbp) {
+                out[(size_t)i * dbp + j] = t;
+                if (diag && b > a && j < da) out[(size_t)j * dbp + i] = t;
+            }
         }
         __syncthreads();
     }
@@ -123,30 +140,68 @@ __global__ void atb_finish(const double* __restrict__ partial, int nslab, int n,
 // ---------------------------------------------------------------------------------------------------------
 // out[N][K] = alpha * (X[N][d] @ P[d][K] + c[K]) + beta * base[N][K]      (accumulate: out += alpha * X @ P)
 // one wave = 16 rows x all K columns; A operand lane (row l&15, k l>>4), B operand lane (k l>>4, col l&15).
+// The kernel is a stream over X and out with ~50 waves of 16 rows per CU; with one 8-byte load per lane in flight a wave holds
+// 512 B and the chip ~4 MB, a third of what 8 TB/s needs at the loaded latency (measured 2.8 TB/s).  So a wave issues the loads of
+// 64 columns of its rows at once (16 per lane) and, PL, the block first stages P, zero-padded to whole tiles, in LDS (d * K <= 7168
+// doubles, the FA shapes; larger P is read through the caches as before), so that the MFMA loop waits for LDS, not for L2.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int MAXTJ = 13;  // K <= 208
+constexpr int RG_LDS_DOUBLES = 7168;   // 56 KB
 
-template <int NT>
+__host__ __device__ constexpr int rg_lds_ld(int nt) { return nt * 16 + ((nt & 1) ? 0 : 16); }   // row stride = 16 mod 32 doubles: the 4 k-rows of a B fragment fall into different banks
+
+template <int NT, bool PL>
 __global__ __launch_bounds__(256) void rows_gemm_kernel(const double* __restrict__ X, int ldx, int d, const double* __restrict__ P,
                                                         int ldp, int K, const double* __restrict__ c, double alpha,
                                                         const double* __restrict__ base, int ldbase, double beta,
                                                         double* __restrict__ out, int ldo, long long N, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) double Ps[];   // PL: [(d + 3) & ~3][LDS_LD]
+    constexpr int LDS_LD = rg_lds_ld(NT);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane >> 4, lc = lane & 15;
     const long long n0 = ((long long)blockIdx.x * 4 + wave) * 16;
+    const long long ra = n0 + lc;
+    const bool oka = ra < N;
+    constexpr int KU = 4;   // 4-column steps per panel (more in flight costs the registers that keep 8 waves per SIMD resident)
+    double a[KU];
+    // the first panel of X is on its way while P is staged
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+        const int k = 4 * u + lr;
+        a[u] = (oka && k < d) ? X[ra * ldx + k] : 0.0;
+    }
+    if constexpr (PL) {
+        const int d4 = (d + 3) & ~3;
+        for (int e = threadIdx.x; e < d4 * NT * 16; e += 256) {
+            const int k = e / (NT * 16), j = e - k * (NT * 16);
+            Ps[k * LDS_LD + j] = (k < d && j < K) ? P[(size_t)k * ldp + j] : 0.0;
+        }
+        __syncthreads();
+    }
     if (n0 >= N) return;
     f64x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
-    const long long ra = n0 + lc;
-    const bool oka = ra < N;
-    for (int k0 = 0; k0 < d; k0 += 4) {
-        const int k = k0 + lr;
-        const double a = (oka && k < d) ? X[ra * ldx + k] : 0.0;
+    for (int kb = 0; kb < d; kb += 4 * KU) {
+        if (kb > 0) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int j = t * 16 + lc;
-            const double b = (k < d && j < K) ? P[(size_t)k * ldp + j] : 0.0;
-            acc[t] = mfma_f64(a, b, acc[t]);
+            for (int u = 0; u < KU; ++u) {
+                const int k = kb + 4 * u + lr;
+                a[u] = (oka && k < d) ? X[ra * ldx + k] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int k = kb + 4 * u + lr;
+            if (kb + 4 * u < d) {   // wave-uniform
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int j = t * 16 + lc;
+                    double b;
+                    if constexpr (PL) b = Ps[k * LDS_LD + j];
+                    else b = (k < d && j < K) ? P[(size_t)k * ldp + j] : 0.0;
+                    acc[t] = mfma_f64(a[u], b, acc[t]);
+                }
+            }
         }
     }
 #pragma unroll
@@ -177,6 +232,11 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const double* __restrict
 //   partial[0] += log cov ; partial[1] += log sig(xi') + mean*t - (mean + xi')/2
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double ref_sigmoid(double x) { return exp(-log(1.0 + exp(-x))); }
+// The reference's expressions nest exp(log(.)) pairs: 12 fp64 transcendentals per element as written, which made mult_kernel bound
+// by the fp64 ALUs (1.65 TB/s).  exp(-log(u)) = 1 / u, exp(log(p) - log(q)) = p / q and log(exp(-y)) = -y to within two or three
+// roundings of the nested form (1e-16 relative; x = xi >= sqrt(cov) ~ 0.9 here, sig(x) - 1/2 does not cancel): 4 transcendentals,
+// 3 divisions, 1 square root.  Held to 1e-13 against the oracle's expressions as written (tests/test_gpu_fa_kernels.py).
+__device__ __forceinline__ double sigmoid_div(double x) { return 1.0 / (1.0 + exp(-x)); }
 
 __global__ __launch_bounds__(256) void mult_kernel(const double* __restrict__ t, const double* __restrict__ zwb, double* __restrict__ xi,
                                                    double* __restrict__ mean, double* __restrict__ cov, double tau, size_t n,
@@ -185,13 +245,14 @@ __global__ __launch_bounds__(256) void mult_kernel(const double* __restrict__ t,
     double a0 = 0.0, a1 = 0.0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const double x = xi[i];
-        const double lam = exp(log(ref_sigmoid(x) - 0.5) - log(2.0 * x));
+        const double ti = t[i];
+        const double lam = (sigmoid_div(x) - 0.5) / (2.0 * x);
         const double cv = 1.0 / (tau + 2.0 * lam);
-        const double mn = (t[i] - 0.5 + tau * zwb[i]) * cv;
+        const double mn = (ti - 0.5 + tau * zwb[i]) * cv;
         const double xn = sqrt(cv + mn * mn);
         cov[i] = cv; mean[i] = mn; xi[i] = xn;
         a0 += log(cv);
-        a1 += log(ref_sigmoid(xn)) + mn * t[i] - 0.5 * (mn + xn);
+        a1 += -log(1.0 + exp(-xn)) + mn * ti - 0.5 * (mn + xn);
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1);
     if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = a0; sm[4 + (threadIdx.x >> 6)] = a1; }
@@ -735,7 +796,11 @@ static int atb_run(const double* A, int lda, int da, const double* B, int ldb, i
     FAVAE_CHECK_ARG((size_t)nslab * da * dbp <= scratch_doubles, "%s: scratch too small (%zu < %zu doubles)", who, scratch_doubles,
                     (size_t)nslab * da * dbp);
     FAVAE_CHECK_ARG(lda >= da && (db == 0 || ldb >= db), "%s: leading dimension smaller than the row", who);
-    hipLaunchKernelGGL(atb_kernel, dim3(nslab, gi * gj), dim3(64 * ATB_WAVES), 0, ST, A, lda, da, B ? B : A, ldb, db, ones ? 1 : 0, N, rps, gj, scratch);
+    static const bool no_sym = getenv("FAVAE_ATB_NO_SYM") != nullptr;   // (developer switch: the full product)
+    if ((!B || B == A) && db == da && ldb == lda && !no_sym)
+        hipLaunchKernelGGL(atb_kernel<true>, dim3(nslab, gi * gj), dim3(64 * ATB_WAVES), 0, ST, A, lda, da, A, lda, db, ones ? 1 : 0, N, rps, gj, scratch);
+    else
+        hipLaunchKernelGGL(atb_kernel<false>, dim3(nslab, gi * gj), dim3(64 * ATB_WAVES), 0, ST, A, lda, da, B ? B : A, ldb, db, ones ? 1 : 0, N, rps, gj, scratch);
     FAVAE_LAUNCH_CHECK();
     const int n = da * dbp;
     hipLaunchKernelGGL(atb_finish, dim3(cdiv(n, 8)), dim3(256), 0, ST, scratch, nslab, n, C);
@@ -789,7 +854,11 @@ extern "C" int favae_fa_rows_gemm(const double* X, int ldx, int d, const double*
         const double* cp = c ? c + k0 : nullptr;
         const double* bp = base ? base + k0 : nullptr;
         double* op = out + k0;
-#define RG_CASE(n) case n: hipLaunchKernelGGL(rows_gemm_kernel<n>, grid, block, 0, ST, X, ldx, d, Pp, ldp, Kp, cp, alpha, bp, ldbase, beta, op, ldo, N, accumulate); break;
+        static const bool no_pl = getenv("FAVAE_RG_NO_LDS") != nullptr;   // (developer switch)
+        const size_t pdoubles = (size_t)((d + 3) & ~3) * rg_lds_ld(nt);
+        const bool pl = pdoubles <= (size_t)RG_LDS_DOUBLES && !no_pl;
+#define RG_CASE(n) case n: if (pl) hipLaunchKernelGGL((rows_gemm_kernel<n, true>), grid, block, pdoubles * 8, ST, X, ldx, d, Pp, ldp, Kp, cp, alpha, bp, ldbase, beta, op, ldo, N, accumulate); \
+                           else hipLaunchKernelGGL((rows_gemm_kernel<n, false>), grid, block, 0, ST, X, ldx, d, Pp, ldp, Kp, cp, alpha, bp, ldbase, beta, op, ldo, N, accumulate); break;
         switch (nt) {
             RG_CASE(1) RG_CASE(2) RG_CASE(3) RG_CASE(4) RG_CASE(5) RG_CASE(6) RG_CASE(7) RG_CASE(8) RG_CASE(9) RG_CASE(10) RG_CASE(11) RG_CASE(12) RG_CASE(13)
         }

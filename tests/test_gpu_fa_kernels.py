@@ -40,7 +40,24 @@ def test_atb_statistics(N, da, db, ones):
     assert np.array_equal(C, C2)
 
 
-@pytest.mark.parametrize("N,d,K", [(512, 20, 10), (2048, 40, 100), (20001, 50, 20), (100, 200, 40), (65, 3, 200), (300, 200, 512)])
+@pytest.mark.parametrize("N,da,ones", [(20001, 50, True), (777, 64, True), (3000, 20, False), (4096, 130, True), (512, 65, True), (5, 3, True)])
+def test_atb_of_a_matrix_with_itself(N, da, ones):
+    """Z^T [Z | 1] (cA/favae.py:989, 1070): the same buffer as both operands takes the triangular path (rows loaded once, the tiles
+    below the diagonal written as transposes); bitwise the result of the full product (a copy of Z as second operand)."""
+    fa = _fa()
+    A = np.random.RandomState(N + da).randn(N, da)
+    sc = fa.Scratch("cuda")
+    Ad = dev(A)
+    C = fa.atb(Ad, Ad, ones, sc).cpu().numpy()
+    Bp = np.hstack([A, np.ones((N, 1))]) if ones else A
+    assert _rel(C, A.T @ Bp) < 1e-12
+    assert np.array_equal(C[:, :da], C[:, :da].T)
+    C2 = fa.atb(Ad, Ad.clone(), ones, sc).cpu().numpy()
+    assert np.array_equal(C, C2)
+
+
+@pytest.mark.parametrize("N,d,K", [(512, 20, 10), (2048, 40, 100), (20001, 50, 20), (100, 200, 40), (65, 3, 200), (300, 200, 512),
+                                    (20001, 40, 50), (1000, 70, 51), (333, 130, 33), (64, 1, 1)])
 def test_rows_gemm(N, d, K):
     fa = _fa()
     rs = np.random.RandomState(d)

@@ -29,9 +29,10 @@ def rec(name, t, nbytes, flops):
     rows.append((name, t, nbytes, flops))
     print("%-46s %8.1f us  %7.1f MB  %6.0f GB/s (%4.1f %% of 8 TB/s)  %6.2f TFLOP/s f64" % (name, t * 1e6, nbytes / 1e6, nbytes / t / 1e9, 100 * nbytes / t / 8e12, flops / t / 1e12))
 
-rec("atb  Z^T [Z | 1]            (K x K+1)", timeit(lambda: fa.atb(Z, Z, True, sc)), 8.0 * N * 2 * K, 2.0 * N * K * (K + 1))
+# (a matrix with itself: the rows are loaded once for both operands since round 3, and 10 of the 16 tiles are computed)
+rec("atb  Z^T [Z | 1]            (K x K+1)", timeit(lambda: fa.atb(Z, Z, True, sc)), 8.0 * N * K, 2.0 * N * K * (K + 1))
 rec("atb  X1^T [Z | 1]           (40 x K+1)", timeit(lambda: fa.atb(X1, Z, True, sc)), 8.0 * N * (d1 + K), 2.0 * N * d1 * (K + 1))
-rec("atb  X0^T [X0 | 1]          (20 x 21)", timeit(lambda: fa.atb(X0, X0, True, sc)), 8.0 * N * 2 * d0, 2.0 * N * d0 * (d0 + 1))
+rec("atb  X0^T [X0 | 1]          (20 x 21)", timeit(lambda: fa.atb(X0, X0, True, sc)), 8.0 * N * d0, 2.0 * N * d0 * (d0 + 1))
 P = torch.randn(d1, K, dtype=F64, device="cuda", generator=g); c = torch.randn(K, dtype=F64, device="cuda", generator=g)
 out = torch.empty(N, K, dtype=F64, device="cuda")
 rec("rows_gemm  out = a (X1 P + c) + b Z  (N x K)", timeit(lambda: fa.rows_gemm(X1, P, c, 0.7, Z, 0.3, out)), 8.0 * N * (d1 + 2 * K), 2.0 * N * d1 * K)
