@@ -452,7 +452,9 @@ int favae_vae_debug_ptr(favae_vae* h, int which, int layer, void** out);
 
 /* C[da][db+ones] = A^T [B | 1] over N rows: the sufficient statistics X^T Z, Z^T Z, X^T X and the column sums
  * (cA/favae.py:989 Z^T Z, :1070 (X-b)^T Z, :1091 column sums, :1135-1139 traces, :1213 X^T X).  fp64 MFMA, slabs
- * summed in a fixed order.  scratch >= favae_fa_atb_scratch_doubles(...). db may be 0 with ones=1 (column sums). */
+ * summed in a fixed order.  scratch >= favae_fa_atb_scratch_doubles(...). db may be 0 with ones=1 (column sums).
+ * B == A with db == da and ldb == lda (Z^T [Z | 1]): the rows are read once and C[:, :da] is exactly symmetric (the tiles below
+ * the diagonal are the transposes of those above; bitwise the values of the full product). */
 long long favae_fa_atb_scratch_doubles(long long N, int da, int db, int ones);
 int favae_fa_atb(const double* A, int lda, int da, const double* B, int ldb, int db, int ones, long long N, double* C,
                  double* scratch, size_t scratch_doubles, void* stream);
@@ -471,7 +473,9 @@ int favae_fa_rows_gemm(const double* X, int ldx, int d, const double* P, int ldp
                        const double* base, int ldbase, double beta, double* out, int ldo, long long N, int accumulate,
                        void* stream);
 /* Multilabel view, update_x + update_xi fused (cA/favae.py:1197-1229) with the entropy / bound sums (:1649, :1678):
- * out2[0] = sum log cov, out2[1] = sum log sig(xi) + mean*t - (mean+xi)/2.  n = N*d elements. scratch >= 4096 doubles. */
+ * out2[0] = sum log cov, out2[1] = sum log sig(xi) + mean*t - (mean+xi)/2.  n = N*d elements. scratch >= 4096 doubles.
+ * The reference's nested forms (sigmoid = exp(-log(1 + exp(-x))), lambda = exp(log(sig - 1/2) - log(2 xi)), :924-949) are evaluated
+ * as 1 / (1 + exp(-x)) and (sig - 1/2) / (2 xi): equal to a few roundings (1e-13 against the forms as written is tested). */
 int favae_fa_mult_update(const double* t, const double* zwb, double* xi, double* mean, double* cov, double tau, long long n,
                          double* out2, double* scratch, size_t scratch_doubles, void* stream);
 /* Semi-supervised multilabel view, update_t (cA/favae.py:1176-1195) + t.mean[mask] = sigmoid(X.mean)[mask] (:858-861):
