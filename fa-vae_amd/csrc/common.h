@@ -103,9 +103,16 @@ __device__ __forceinline__ void carry_store(const FlagCarry& c) {
 #ifdef __HIPCC__
 // One Adam update (torch.optim.Adam defaults: no weight decay, no amsgrad; cA/celeba_deepvanilla_vae.py:131,250) with every rounding
 // spelled out, so that the three kernels that take the step (adam_kernel, adam_wprep_kernel, the epilogue of igemm_pm<..., ADAM>)
-// give the same bits whatever the compiler would contract in each of them:
+// give the same bits whatever the compiler would contract in each of them (the __f*_rn forms of this toolchain are plain operators,
+// so contraction is switched off as well):
 //   m += (1 - b1) (g - m);  v = v b2 + (1 - b2) g g;  p -= step_size * m / (sqrt(v) / sqrt(1 - b2^t) + eps),  step_size = lr / (1 - b1^t)
+// a product that must be rounded before its consumer sees it (g * gscale in front of g - m would otherwise become one fma)
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
 __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float b1, float b2, float eps, float step_size, float bc2_sqrt) {
+#pragma clang fp contract(off)
     m = __fmaf_rn(__fsub_rn(1.f, b1), __fsub_rn(g, m), m);
     v = __fmaf_rn(g, __fmul_rn(__fsub_rn(1.f, b2), g), __fmul_rn(v, b2));
     const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);

@@ -1721,10 +1721,13 @@ extern "C" int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float
                 rc = favae_vae_fence(h, st, (void*)cs);
             }
             if (rc) break;
-            rc = favae_allreduce_f32(c, v.G + bk[b].lo, bk[b].hi - bk[b].lo, 1, (void*)cs);
+            // the SUM over the ranks; the optimiser step scales the gradient it reads by 1 / ranks (for 2, 4, 8 ranks bitwise the
+            // average RCCL forms by pre-multiplying; an averaging all-reduce costs the same between ranks, but RCCL runs it as a
+            // pass over the bucket even in a group of one, 5.5 % of the kernel time of the one-rank rehearsal)
+            rc = favae_allreduce_f32(c, v.G + bk[b].lo, bk[b].hi - bk[b].lo, 0, (void*)cs);
             if (rc) break;
-            rc = favae_adam_step_clear(v.P + bk[b].lo, v.G + bk[b].lo, v.M + bk[b].lo, v.V + bk[b].lo, bk[b].hi - bk[b].lo, lr, 0.9f,
-                                       0.999f, 1e-8f, step0 + s + 1, (void*)cs);
+            rc = favae_adam_step_clear_scaled(v.P + bk[b].lo, v.G + bk[b].lo, v.M + bk[b].lo, v.V + bk[b].lo, bk[b].hi - bk[b].lo, lr, 0.9f,
+                                              0.999f, 1e-8f, step0 + s + 1, 1.f / (float)favae_comm_size(c), (void*)cs);
             if (rc) break;
             const float* w[16]; void* wc[16]; void* wt[16]; int Co[16], taps[16], Ci[16];
             int k = 0;

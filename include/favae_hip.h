@@ -336,6 +336,10 @@ int favae_adam_step(float* p, const float* g, float* m, float* v, long long n, f
 int favae_adam_step_clear(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                           float eps, long long step, void* stream);
 
+/* favae_adam_step_clear on gscale * g (optim.step(), :250, on the averaged gradient): the data-parallel epoch all-reduces the SUM
+ * of the ranks' gradients and passes 1 / ranks.  No counterpart of its own in the reference (which trains on one device). */
+int favae_adam_step_clear_scaled(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                                 long long step, float gscale, void* stream);
 /* favae_adam_step (clear_g: + the zeroing of favae_adam_step_clear) that also writes the bf16 copy of the first `ncopy`
  * updated parameters (a layer's weights, same [Cout][tap][Cin] layout) in the same pass: the optimiser step and the
  * dtype shadow of encoder.0, whose update is the last link of a training step (optim.step(), :250). */

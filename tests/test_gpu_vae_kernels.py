@@ -291,6 +291,27 @@ def test_adam_fused_with_weight_prep(dt, Co, taps, Ci, extra):
     assert float(gb.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("ranks", [1, 2, 3, 8])
+def test_adam_on_the_summed_gradient_of_the_ranks(ranks):
+    """favae_adam_step_clear_scaled(g_sum, 1 / ranks) == favae_adam_step_clear(g_sum / ranks) bit for bit (the data-parallel epoch
+    all-reduces the sum and leaves the division to the optimiser step); gscale = 1 is favae_adam_step_clear itself."""
+    L = _L()
+    raw_ = L.raw()
+    n = 4096 + 64
+    g = torch.Generator().manual_seed(ranks)
+    p0, gs = torch.randn(n, generator=g).cuda(), (torch.randn(n, generator=g) * 0.1 * ranks).cuda()
+    m0, v0 = (torch.randn(n, generator=g) * 0.01).cuda(), (torch.rand(n, generator=g) * 1e-3).cuda()
+    sc = np.float32(1.0) / np.float32(ranks)
+    pa, ga, ma, va = p0.clone(), gs * float(sc), m0.clone(), v0.clone()
+    L.check(raw_.favae_adam_step_clear(L.ptr(pa), L.ptr(ga), L.ptr(ma), L.ptr(va), ll_(n), f_(1e-3), f_(0.9), f_(0.999), f_(1e-8), ll_(3),
+                                       L.stream_ptr()))
+    pb, gb, mb, vb = p0.clone(), gs.clone(), m0.clone(), v0.clone()
+    L.check(raw_.favae_adam_step_clear_scaled(L.ptr(pb), L.ptr(gb), L.ptr(mb), L.ptr(vb), ll_(n), f_(1e-3), f_(0.9), f_(0.999), f_(1e-8),
+                                              ll_(3), f_(float(sc)), L.stream_ptr()))
+    for a, b in ((pa, pb), (ma, mb), (va, vb), (ga, gb)):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("clear", [0, 1])
 def test_adam_with_bf16_copy_of_the_weights(clear):
     """favae_adam_step_copy (encoder.0: 64 x 9 x 3 weights + bias + BN affine) == favae_adam_step(_clear) followed by
