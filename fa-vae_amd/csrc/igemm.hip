@@ -724,6 +724,201 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
 #undef tap_kw
 
 // ---------------------------------------------------------------------------------------------------------
+// final_layer.0 forward: ConvTranspose2d(64 -> 64, 3x3, stride 2, pad 1, output_padding 1) over 32-pixel-wide rows, bf16
+// (cA/celeba_deepvanilla_vae.py:63-70).  In the scatter form of igemm_kc this layer is 4 parity classes of 1 / 2 / 2 / 4 chunks per
+// 64x64 tile: a block's whole reduction is one to four chunks, and the launch is all prologue and epilogue (230 us at batch 512
+// for 268 MB of output).  Here a block keeps all nine 64x64 tap matrices in LDS (81 KB) for its
+// lifetime and walks over units of two input rows: three rows (two + the halo row) go to LDS once, every wave takes one input row x
+// 32 output channels and accumulates the four parity classes (9 tap products of 32 x 64 x 32, 36 MFMAs) from the four shifted
+// views of the rows, and the four output rows of the unit leave through an LDS tile as whole 8 / 16 KB rows.  The BatchNorm sums
+// stay in registers (one channel per lane) until the block changes its BatchNorm group or ends.  Same products in the same order as
+// the scatter form: bit-identical output.
+// ---------------------------------------------------------------------------------------------------------
+struct Ct64Params {
+    const char* in;        // [Nb][Hi][32][64] bf16
+    const char* w;         // [64 co][9 taps][64 ci] bf16
+    const float* bias;     // [64] or null
+    char* out;             // [Nb][2 Hi][64][64] fp32 or bf16
+    const float* ep_ab;    // a[64] | b[64]: out = lrelu(a v + b), or null
+    double* red_bins;      // [groups][nbin][2][64] or null: sum v, sum v^2
+    int Nb, Hi, out_bf16, red_nbin, group_images, units, upb;
+    FlagCarry carry;
+};
+constexpr int CT_RS = 144;                          // bytes of a 64-channel bf16 row in LDS (128 + 16)
+constexpr int CT_W_BYTES = 9 * 64 * CT_RS;          // 82 944
+constexpr int CT_A_ROW = 33 * CT_RS;                // 32 pixels + a zero pixel
+constexpr int CT_A_BYTES = 3 * CT_A_ROW;            // one unit: two input rows + the halo row
+constexpr int CT_O_PX = 64 * 4 + 16;                // bytes per output pixel in the staging tile
+constexpr int CT_O_BYTES = 2 * 64 * CT_O_PX;        // two output rows
+constexpr int CT_LDS = CT_W_BYTES + 2 * CT_A_BYTES + CT_O_BYTES;   // 146 272
+
+__global__ __launch_bounds__(256) void convt64_fwd_kernel(const Ct64Params p) {
+    extern __shared__ __attribute__((aligned(16))) char ct_lds[];
+    char* const Ws = ct_lds;
+    char* const As = ct_lds + CT_W_BYTES;
+    char* const Os = As + 2 * CT_A_BYTES;
+    carry_store(p.carry);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rsel = wave >> 1, nt = wave & 1;          // input row of the unit, half of the output channels
+    const int u0 = (int)blockIdx.x * p.upb, u1 = min(p.units, u0 + p.upb);
+    if (u0 >= u1) return;
+    const int half = p.Hi >> 1, Ho = 2 * p.Hi;
+    for (int q = tid; q < 64 * 72; q += 256) {          // global [co][tap][8 pieces] -> LDS [tap][co][row of 144 B]
+        const int co = q / 72, rem = q - co * 72, tap = rem >> 3, pc = rem & 7;
+        *(uint4*)(Ws + (tap * 64 + co) * CT_RS + pc * 16) = *(const uint4*)(p.w + (size_t)q * 16);
+    }
+    if (tid < 48) {                                     // the pixel right of the row (x = 32) reads as zero
+        const int b = tid / 24, r = (tid % 24) >> 3, pc = tid & 7;
+        *(uint4*)(As + b * CT_A_BYTES + r * CT_A_ROW + 32 * CT_RS + pc * 16) = make_uint4(0, 0, 0, 0);
+    }
+    const int lpx = tid >> 3, lpc = tid & 7;            // pixel / 16-byte piece this thread stages
+    auto load_unit = [&](int u, uint4 (&v)[3]) __attribute__((always_inline)) {
+        const int n = u / half, j = u - n * half;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int y = 2 * j + i;
+            v[i] = y < p.Hi ? *(const uint4*)(p.in + ((((size_t)n * p.Hi + y) * 32 + lpx) * 64) * 2 + lpc * 16) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_unit = [&](int buf, const uint4 (&v)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *(uint4*)(As + buf * CT_A_BYTES + i * CT_A_ROW + lpx * CT_RS + lpc * 16) = v[i];
+    };
+    uint4 nx[3];
+    load_unit(u0, nx);
+    store_unit(0, nx);
+    if (u0 + 1 < u1) load_unit(u0 + 1, nx);
+    const int co = nt * 32 + (lane & 31);
+    // epilogue roles: a thread stores the 16-byte pieces (4 channels c4 .. c4+3, fixed for its lifetime) of pixels (tid >> 4) + 16 i
+    const int c4 = (tid & 15) * 4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), ea = make_float4(1.f, 1.f, 1.f, 1.f), eb = bv;
+    if (p.bias) bv = *(const float4*)(p.bias + c4);
+    if (p.ep_ab) { ea = *(const float4*)(p.ep_ab + c4); eb = *(const float4*)(p.ep_ab + 64 + c4); }
+    const int osz = p.out_bf16 ? 2 : 4;
+    // staging tile: fp32, [2 output rows][64 pixels][64 channels + pad]; the accumulator of pixel x, register r goes to pixel 2 x + px
+    char* const st_w = Os + (rsel * 64 + 8 * (lane >> 5)) * CT_O_PX + co * 4;          // + (2 (r & 3) + 16 (r >> 2) + px) * CT_O_PX
+    const char* const st_r = Os + (tid >> 4) * CT_O_PX + c4 * 4;                         // + 16 i * CT_O_PX
+    const size_t g_thr = ((size_t)(tid >> 4) * 64 + c4) * (size_t)osz;                   // this thread's offset inside an output row
+    double rs[4] = {0.0, 0.0, 0.0, 0.0}, rq[4] = {0.0, 0.0, 0.0, 0.0};
+    int cur_grp = -1;
+    auto flush = [&]() __attribute__((always_inline)) {
+        if (!p.red_bins || cur_grp < 0) return;
+        double* dst = p.red_bins + (((size_t)cur_grp * p.red_nbin + (int)(blockIdx.x % (unsigned)p.red_nbin)) * 2) * 64 + c4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {     // lanes l, l ^ 16, l ^ 32 hold the same four channels
+            double a = rs[k], b = rq[k];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (lane < 16) { unsafeAtomicAdd(dst + k, a); unsafeAtomicAdd(dst + 64 + k, b); }
+            rs[k] = rq[k] = 0.0;
+        }
+    };
+    __syncthreads();
+    for (int u = u0; u < u1; ++u) {
+        const int buf = (u - u0) & 1;
+        const char* A = As + buf * CT_A_BYTES;
+        f32x16 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        // the four shifted views (dy, dx) of the rows in the order (1,1), (1,0), (0,1), (0,0): the tap order of the scatter form
+#pragma unroll
+        for (int cb = 3; cb >= 0; --cb) {
+            const int dy = cb >> 1, dx = cb & 1;
+            const char* arow = A + (rsel + dy) * CT_A_ROW + ((lane & 31) + dx) * CT_RS + 16 * (lane >> 5);
+            Frag<bf16_t> fa[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) frag_kc(fa[kk], arow + kk * 32);
+#pragma unroll
+            for (int py = dy; py <= 1; ++py)
+#pragma unroll
+                for (int px = dx; px <= 1; ++px) {
+                    const int kh = py == 0 ? 1 : (dy ? 0 : 2), kw = px == 0 ? 1 : (dx ? 0 : 2);
+                    const char* brow = Ws + ((kh * 3 + kw) * 64 + co) * CT_RS + 16 * (lane >> 5);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        Frag<bf16_t> fb;
+                        frag_kc(fb, brow + kk * 32);
+                        mma32(acc[py * 2 + px], fa[kk], fb);
+                    }
+                }
+        }
+        const int n = u / half, j = u - n * half;
+        if (p.red_bins) {   // block-uniform
+            const int grp = p.group_images > 0 ? n / p.group_images : 0;
+            if (grp != cur_grp) { flush(); cur_grp = grp; }
+        }
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {                // output rows of parity ph of both input rows
+            if (ph) __syncthreads();                    // the readers of the first half are done with the tile
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *(float*)(st_w + (2 * (r & 3) + 16 * (r >> 2) + px) * CT_O_PX) = acc[ph * 2 + px][r];
+            __syncthreads();
+            // output rows 2 (2 j + rr) + ph, rr = 0, 1: 64 pixels x 64 channels contiguous
+            char* const g_row = p.out + ((((size_t)n * Ho + 4 * j + ph) * 64) * 64) * (size_t)osz + g_thr;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rr = i >> 2;
+                float4 v = *(const float4*)(st_r + 16 * i * CT_O_PX);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (p.red_bins) {
+                    rs[0] += v.x; rs[1] += v.y; rs[2] += v.z; rs[3] += v.w;
+                    rq[0] += (double)v.x * v.x; rq[1] += (double)v.y * v.y; rq[2] += (double)v.z * v.z; rq[3] += (double)v.w * v.w;
+                }
+                if (p.ep_ab) {
+                    v.x = fmaf(v.x, ea.x, eb.x); v.y = fmaf(v.y, ea.y, eb.y); v.z = fmaf(v.z, ea.z, eb.z); v.w = fmaf(v.w, ea.w, eb.w);
+                    v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;
+                    v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;
+                }
+                // pixel (tid >> 4) + 16 (i & 3) of output row rr: rows are 2 output rows apart
+                char* const g = g_row + ((size_t)rr * 2 * 64 * 64 + (size_t)(16 * (i & 3)) * 64) * (size_t)osz;
+                if (p.out_bf16) {
+                    uint2 o;
+                    o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+                    o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+                    *(uint2*)g = o;
+                } else {
+                    *(float4*)g = v;
+                }
+            }
+        }
+        if (u + 1 < u1) {
+            store_unit(buf ^ 1, nx);
+            if (u + 2 < u1) load_unit(u + 2, nx);
+        }
+        __syncthreads();
+    }
+    flush();
+}
+
+int convt64_fwd_launch(const void* in, const void* w, const float* bias, void* out, int Nb, int Hi, int out_bf16, const float* ep_ab,
+                       double* bins, int nbin, int group_images, hipStream_t st) {
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    FAVAE_HIP(hipGetDevice(&dev));
+    FAVAE_CHECK_ARG(dev >= 0 && dev < 64, "favae_conv_igemm: device index %d", dev);
+    if (!attr_set[dev]) {
+        FAVAE_HIP(hipFuncSetAttribute((const void*)convt64_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS));
+        attr_set[dev] = true;
+    }
+    Ct64Params p;
+    p.in = (const char*)in; p.w = (const char*)w; p.bias = bias; p.out = (char*)out; p.ep_ab = ep_ab;
+    p.red_bins = bins; p.red_nbin = bins ? nbin : 1; p.group_images = group_images;
+    p.Nb = Nb; p.Hi = Hi; p.out_bf16 = out_bf16;
+    p.units = Nb * (Hi / 2);
+    static const int blocks = getenv("FAVAE_CT64_BLOCKS") ? atoi(getenv("FAVAE_CT64_BLOCKS")) : 256;
+    p.upb = cdiv(p.units, std::max(1, std::min(blocks, p.units)));
+    p.carry = favae_take_flag_carry();
+    ProfScope prof(6, 2.0 * Nb * (2.0 * Hi) * 64 * 64.0 * 2.25 * 64, st);
+    hipLaunchKernelGGL(convt64_fwd_kernel, dim3(cdiv(p.units, p.upb)), dim3(256), CT_LDS, st, p);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // pixel-major implicit GEMM (weight gradients)
 // ---------------------------------------------------------------------------------------------------------
 struct PmParams {
@@ -1214,6 +1409,21 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
             if (red.fused) *red.fused = 1;
         }
         return thin_in_launch(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, stride, scatter, dtype, out_bf16, tr, (hipStream_t)stream);
+    }
+    // final_layer.0's shape (transposed 64 -> 64 convolution over 32-pixel rows, bf16) at 128 images or more (grouped-batch steps, eval
+    // passes): the kernel with resident tap matrices.  Measured on MI355X alone: 123 us against 183 us at 512 images (fp32 out; with
+    // the BatchNorm sums 141 against 230), 23 against 29 us at 64 images, where most of it is the start-up (81 KB of weights per
+    // block) and the training step does not change (0.852 ms either way), so the batch-64 step keeps the scatter form of igemm_kc.
+    // In the step at 8 groups: 3.19 -> 3.16 ms; reconstruction pass 42.5 -> 41.4 ms per 32 768 images.
+    // (FAVAE_CT64=0 or a forced tile: the scatter form everywhere; FAVAE_CT64=1: this kernel at any batch)
+    {
+        static const int ct64_mode = getenv("FAVAE_CT64") ? atoi(getenv("FAVAE_CT64")) : -1;
+        if (ct64_mode != 0 && (Nb >= 128 || ct64_mode == 1) && g_force_kc_tile < 0 && dtype == FAVAE_BF16 && scatter && stride == 2 && ks == 3 && Cin == 64 && Cout == 64 && Wi == 32 &&
+            Hi % 2 == 0 && !in_ab && !fin && splitk <= 1 && !(red.bins && red.mode != 1) && ((uintptr_t)out % 16) == 0 &&
+            (!ep_ab || ((uintptr_t)ep_ab % 4) == 0)) {
+            if (red.bins && red.fused) *red.fused = 1;
+            return convt64_fwd_launch(in, w, bias, out, Nb, Hi, out_bf16, ep_ab, red.bins, red.nbin, red.group_images, st);
+        }
     }
     KcParams p;
     p.in = in; p.w = w; p.bias = bias; p.out = out;

@@ -725,3 +725,62 @@ def test_weight_gradient_with_the_adam_step_in_its_epilogue(dt, kind, Nb, Cin, C
     assert torch.equal(V2, V1), ((V2 - V1).abs().max().item(), (V2 != V1).sum().item())
     assert torch.equal(P2, P1), ((P2 - P1).abs().max().item(), (P2 != P1).sum().item())
     assert torch.equal(wc2, wc1) and torch.equal(wt2, wt1)
+
+
+@pytest.mark.parametrize("mode", ["f32_out", "bf16_out_groups", "affine"])
+def test_transposed_64_to_64_convolution_with_resident_tap_matrices(mode):
+    """final_layer.0's forward shape (ConvTranspose2d 64 -> 64, 32 -> 64 pixels, cA/celeba_deepvanilla_vae.py:63-70) runs through
+    convt64_fwd_kernel (nine tap matrices resident in LDS, units of two input rows).  Against the scatter form of igemm_kc (forced
+    through favae_debug_force_tile) the output is bit-identical, plain, with the per-group BatchNorm sums of the grouped-batch mode
+    (sums to 1e-12: atomics in another order) and with the eval epilogue (affine + LeakyReLU, bf16 out); and against
+    F.conv_transpose2d on the bf16-rounded operands 1e-4.  A ragged block split (Nb * 16 units over 256 blocks) is part of every case."""
+    import ctypes
+    lib = _lib()
+    raw_ = lib.raw()
+    i_ = ctypes.c_int
+    Nb = {"f32_out": 129, "bf16_out_groups": 130, "affine": 131}[mode]   # (the kernel takes 128 images or more)
+    G = {"f32_out": 0, "bf16_out_groups": 65, "affine": 0}[mode]      # images per BatchNorm group (65: groups change inside blocks)
+    g = torch.Generator().manual_seed(Nb)
+    dt = torch.bfloat16
+    x = q(torch.randn(Nb, 64, 32, 32, generator=g), dt)
+    w = q(torch.randn(64, 64, 3, 3, generator=g) * 0.1, dt)
+    b = torch.randn(64, generator=g)
+    ab = torch.cat([torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)]).cuda()
+    xd = nhwc(x).to(dt).cuda()
+    wd = w.permute(1, 2, 3, 0).reshape(64, 9, 64).contiguous().to(dt).cuda()
+    out_dt = torch.float32 if mode == "f32_out" else torch.bfloat16
+    res = {}
+    for forced in (0, 1):
+        lib.check(raw_.favae_debug_force_tile(i_(0 if forced else -1), i_(-1)))
+        try:
+            out = torch.full((Nb, 64, 64, 64), 7.0, device="cuda").to(out_dt)
+            bins = torch.zeros(max(1, (Nb + 64) // 65) * 8 * 2 * 64, dtype=torch.float64, device="cuda")
+            fused = ctypes.c_int(0)
+            if mode == "f32_out":
+                lib.conv_igemm(xd, wd, b.cuda(), out, 3, 2, 1, 1, 1)
+            elif mode == "affine":
+                lib.check(raw_.favae_conv_igemm_affine(lib.ptr(xd), lib.ptr(wd), lib.ptr(b.cuda()), lib.ptr(out), i_(Nb), i_(32), i_(32), i_(64), i_(64),
+                                                       i_(64), i_(64), i_(3), i_(2), i_(1), i_(1), i_(lib.BF16 | lib.OUT_BF16), lib.ptr(ab), lib.stream_ptr()))
+            else:
+                lib.check(raw_.favae_conv_igemm_red_groups(lib.ptr(xd), lib.ptr(wd), lib.ptr(b.cuda()), lib.ptr(out), i_(Nb), i_(32), i_(32), i_(64),
+                                                           i_(64), i_(64), i_(64), i_(3), i_(2), i_(1), i_(1), i_(0), i_(lib.BF16 | lib.OUT_BF16),
+                                                           lib.ptr(bins), i_(8), i_(1), None, None, None, None, None, i_(G), ctypes.byref(fused),
+                                                           lib.stream_ptr()))
+                assert fused.value == 1
+            torch.cuda.synchronize()
+            res[forced] = (out.cpu(), bins.cpu())
+        finally:
+            lib.check(raw_.favae_debug_force_tile(i_(-1), i_(-1)))
+    assert torch.equal(res[0][0], res[1][0])
+    ref = nhwc(F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1))
+    if mode == "affine":
+        ref = F.leaky_relu(ref * ab[:64].cpu() + ab[64:].cpu(), 0.01)
+    assert_close(res[0][0].float(), ref, 1e-4 if mode == "f32_out" else 5e-3)
+    if mode == "bf16_out_groups":
+        s_new = res[0][1].view(-1, 8, 2, 64).sum(1)
+        s_old = res[1][1].view(-1, 8, 2, 64).sum(1)
+        assert_close(s_new, s_old, 1e-12)
+        for gi in range(2):
+            v = ref[gi * G:(gi + 1) * G].double().reshape(-1, 64)
+            assert_close(s_new[gi, 0], v.sum(0), 1e-5)
+            assert_close(s_new[gi, 1], (v * v).sum(0), 1e-5)

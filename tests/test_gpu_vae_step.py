@@ -451,9 +451,8 @@ def test_epoch_with_the_adam_step_in_the_weight_gradient_epilogue(dtype):
             # split-K atomics flip shows as 2 lr in either path; all but a few such weights agree to the last bits
             d = np.abs(a - b)
             assert d.max() <= 2.2e-4 * (N // Bn), (N, k, d.max())
-            frac = float((d > 1e-7).mean())
-            if N == 64:
-                assert frac <= (1e-2 if dtype == "f32" else 0.05), (N, k, frac)
+            if N == 64:   # (small tensors: a flipped weight or two out of 20)
+                assert int((d > 1e-7).sum()) <= max(2, int((1e-2 if dtype == "f32" else 0.05) * d.size)), (N, k, int((d > 1e-7).sum()), d.size)
 
 
 def test_uint8_resident_data_set_equals_fp32_resident():
