@@ -1079,6 +1079,15 @@ __device__ __forceinline__ void conv_out_ll_tail(const float4v acc, const float*
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // this lane: output channel j of the 4 pixels of its block
     const int j = lane & 3, p0 = blockIdx.x * 256 + wave * 64 + (lane >> 2) * 4;
+    if (!x) {   // uniform (favae_conv_out_raw, the eval decoder): the convolution output alone
+        if (j < CO) {
+            const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (p0 + i < total) raw[(size_t)(p0 + i) * CO + j] = acc[i] + bj;
+        }
+        return;
+    }
     double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     if (j < CO) {
         const float bj = bias ? bias[j] : 0.f;
@@ -2061,6 +2070,24 @@ extern "C" int favae_conv_out_ll(const void* act, const void* wk, const float* b
     }
 #undef CO_ROWS
 #undef CO_LAUNCH
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+/* final_layer.3 (Conv2d 64 -> Cout <= 4, 3x3, stride 1) alone, for the eval decoder: the convolution of favae_conv_out_ll (a wave per
+ * 64 pixels of an image row, 4x4x4 MFMAs) without the likelihood: raw [Nb][H][W][Cout] fp32.  bf16, W a multiple of 64. */
+extern "C" int favae_conv_out_raw(const void* act, const void* wk, const float* bias, int Nb, int H, int W, int Cout, float* raw, int dtype,
+                                  void* stream) {
+    FAVAE_CHECK_ARG(act && wk && raw && Nb > 0 && H > 0 && W > 0, "favae_conv_out_raw: bad argument");
+    FAVAE_CHECK_ARG(Cout >= 1 && Cout <= 4, "favae_conv_out_raw: 1..4 output channels");
+    FAVAE_CHECK_ARG(dtype == FAVAE_BF16 && W % 64 == 0, "favae_conv_out_raw: bf16 activations, image width a multiple of 64");
+    FAVAE_CHECK_ARG(((uintptr_t)act % 16) == 0 && ((uintptr_t)wk % 16) == 0 && (size_t)Nb * H * W < (1u << 31), "favae_conv_out_raw: alignment / size");
+    const int total = Nb * H * W, grid = cdiv(total, 256);
+#define CO_ROWS(CO_)                                                                                                                      \
+    hipLaunchKernelGGL((conv_out_ll_rows<CO_>), dim3(grid), dim3(256), 0, ST, (const bf16_t*)act, (const bf16_t*)wk, bias, (const float*)nullptr, H, W, \
+                       total, 0.f, raw, (bf16_t*)nullptr, (double*)nullptr, (unsigned*)nullptr, 0.0, 1.0, 1.0, (double*)nullptr, (float*)nullptr)
+    switch (Cout) { case 1: CO_ROWS(1); break; case 2: CO_ROWS(2); break; case 3: CO_ROWS(3); break; default: CO_ROWS(4); }
+#undef CO_ROWS
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

@@ -719,7 +719,12 @@ int decoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false, bool s
                             v.dtype | (v.dtype == FAVAE_BF16 ? FAVAE_OUT_BF16 : 0), st));
     }
     RC(conv_bn_chain(v, 7, 11, v.act[L_DI], B, train, st, pooled));
-    return skip_out ? FAVAE_OK : conv_fwd(v, L_OUT, v.act[11], B, st, pooled);
+    if (skip_out) return FAVAE_OK;
+    // eval passes: final_layer.3 through the row kernel of the training step (the generic GEMM pads 3 output channels to a 32-wide
+    // tile: 225 us per 512 images against ~100)   (FAVAE_FUSE_MASK bit 0x80000000: the generic GEMM, as before)
+    if (!train && !pooled && v.dtype == FAVAE_BF16 && !(v.fuse & 0x80000000u))
+        return favae_conv_out_raw(v.act[11], v.wk_out, v.P + v.L[L_OUT].b_off, B, 64, 64, v.ch, v.raw[L_OUT], v.dtype, st);
+    return conv_fwd(v, L_OUT, v.act[11], B, st, pooled);
 }
 
 int bn_bwd(Vae& v, int l, int B, void* st) {

@@ -319,6 +319,10 @@ int favae_conv_out_wprep(const void* w, void* wk, int Cout, int dtype, void* str
 int favae_conv_out_ll_finish(const double* partial, int Nb, int H, int W, int Cout, float var_x, double* rec_err, float* dbias,
                              void* stream);
 int favae_conv_out_ll_ride(const double* partial, int Nb, int H, int W, int Cout, float var_x, double* rec_err, float* dbias);
+/* The convolution of favae_conv_out_ll alone (final_layer.3 of the eval decoder, cA/celeba_deepvanilla_vae.py:71-77 under
+ * decoder() :94-99): raw [Nb][H][W][Cout] fp32 = conv3x3(act) + bias.  bf16 activations, W a multiple of 64, wk from favae_conv_out_wprep. */
+int favae_conv_out_raw(const void* act, const void* wk, const float* bias, int Nb, int H, int W, int Cout, float* raw, int dtype,
+                       void* stream);
 int favae_conv_out_ll(const void* act, const void* wk, const float* bias, const float* x, int Nb, int H, int W, int Cout,
                       float var_x, float* raw, void* draw, double* rec_err, float* dbias, double* scratch,
                       size_t scratch_doubles, int dtype, void* stream);

@@ -652,6 +652,12 @@ def test_final_conv_with_loss_in_one_launch(dt, tol, Nb, H, Co):
         assert abs(rec.item() + ll.item()) <= 1e-5 * abs(ll.item())
         assert_close(draw.float().cpu(), nhwc(y.grad), 1e-4 if dt == torch.float32 else 8e-3)
         assert_close(dbias.cpu(), b.grad, 1e-4)
+    if dt == torch.bfloat16 and H % 64 == 0:
+        # favae_conv_out_raw (the eval decoder's final_layer.3): the same convolution without the likelihood, bit for bit
+        raw2 = torch.full((Nb, H, H, Co), 5.0, device="cuda")
+        lib.check(rawl.favae_conv_out_raw(lib.ptr(ad), lib.ptr(wk), lib.ptr(bd), i_(Nb), i_(H), i_(H), i_(Co), lib.ptr(raw2), i_(lib.BF16),
+                                          lib.stream_ptr()))
+        assert torch.equal(raw2, raw)
     # FAVAE_DBIAS_DEFER: the launch leaves five sums per block; a launch of its own (finish) or the first block of the calling
     # thread's next weight-gradient launch (ride) adds them up: the same loss term and bias gradient
     rec0, dbias0 = rec.clone(), dbias.clone()
