@@ -1297,6 +1297,18 @@ int dispatch_kc(KcParams p, int classes, int target_blocks, int* fused, hipStrea
     return launch_kc<T, TR, false, 64, 64, 2, 2>(p, classes, st);
 }
 
+// tile (0: 32x128, 1: 128x32, 2: 64x64) and automatic split of the weight-gradient reduction
+inline int pm_tile_of(int Rc, int Cc) { return Rc <= 32 ? 0 : Cc <= 32 ? 1 : 2; }
+int pm_auto_splitk(int Rc, int Cc, long long K, int ks, int tile) {
+    const int BM = tile == 0 ? 32 : tile == 1 ? 128 : 64, BN = tile == 0 ? 128 : tile == 1 ? 32 : 64;
+    const int nchunk = (int)((K + BK - 1) / BK);
+    const int blocks = cdiv(Rc, BM) * cdiv(Cc, BN) * ks * ks;
+    // ~256 blocks: the weight gradients run on the side stream beside the main chain; a grid that fills the chip several
+    // times over delays the main-stream kernels more than it shortens itself (tools/prof_step.py sweep)
+    static const int pm_target = getenv("FAVAE_PM_TARGET") ? atoi(getenv("FAVAE_PM_TARGET")) : 256;
+    return std::max(1, std::min(std::min(std::max(1, nchunk / 8), std::max(1, (pm_target + blocks / 2) / blocks)), nchunk));
+}
+
 thread_local int g_pm_adam_applied = 0;   // did the last weight-gradient launch of this thread take the optimiser step in its epilogue?
 
 template <class T>
@@ -1305,18 +1317,15 @@ int dispatch_pm(PmParams p, hipStream_t st) {
     p.rider = favae_take_slab_rider();
     FAVAE_CHECK_ARG(!(p.rider.partial && (p.rider.nslab < 1 || p.rider.nslab > 65536 || p.rider.C < 1 || p.rider.C > 2048)),
                     "weight gradient: slab rider of %d slabs x %d channels", p.rider.nslab, p.rider.C);
-    int tile = p.Rc <= 32 ? 0 : p.Cc <= 32 ? 1 : 2;   // 32x128, 128x32, 64x64
+    int tile = pm_tile_of(p.Rc, p.Cc);   // 32x128, 128x32, 64x64
     if (g_force_pm_tile >= 0 && g_force_pm_tile <= 2) tile = g_force_pm_tile;
     const int BM = tile == 0 ? 32 : tile == 1 ? 128 : 64, BN = tile == 0 ? 128 : tile == 1 ? 32 : 64;
     p.ntn = cdiv(p.Cc, BN);
     const int nchunk = cdiv(p.K, BK);
     const int blocks = cdiv(p.Rc, BM) * p.ntn * p.ks * p.ks;
-    // ~256 blocks: the weight gradients run on the side stream beside the main chain; a grid that fills the chip several
-    // times over delays the main-stream kernels more than it shortens itself (tools/prof_step.py sweep)
-    static const int pm_target = getenv("FAVAE_PM_TARGET") ? atoi(getenv("FAVAE_PM_TARGET")) : 256;
     p.overwrite = p.splitk < 0;
     int sk = p.splitk > 0 ? p.splitk : p.splitk < -1 ? -p.splitk   // < -1: that many slices of a gradient the caller zeroed
-                                     : std::min(std::max(1, nchunk / 8), std::max(1, (pm_target + blocks / 2) / blocks));
+                                     : pm_auto_splitk(p.Rc, p.Cc, p.K, p.ks, tile);
     p.splitk = std::max(1, std::min(sk, nchunk));
     dim3 grid(cdiv(p.Rc, BM) * p.ntn, p.splitk, p.ks * p.ks);
     if (p.rider.partial && !p.rider.out0 && (long long)cdiv(p.rider.C, 8) > (long long)grid.x * grid.y * grid.z) {   // too few blocks to carry it: a launch of its own
@@ -1583,6 +1592,12 @@ extern "C" int favae_conv_wgrad_adam(const void* rows, int Rc, int rows_large, c
     const int rc = dtype == FAVAE_F32 ? dispatch_pm<float>(p, (hipStream_t)stream) : dispatch_pm<bf16_t>(p, (hipStream_t)stream);
     if (rc == FAVAE_OK) *applied = g_pm_adam_applied;
     return rc;
+}
+
+extern "C" int favae_conv_wgrad_auto_splitk(int Rc, int Cc, long long K, int ks) {
+    if (Rc <= 0 || Cc <= 0 || K <= 0 || ks <= 0) return 0;
+    if (g_force_pm_tile >= 0) return 0;   // (developer override active: no promise)
+    return pm_auto_splitk(Rc, Cc, K, ks, pm_tile_of(Rc, Cc));
 }
 
 extern "C" size_t favae_conv_wgrad_folded_scratch(int Nb, int Hl, int Wl, int dtype) {

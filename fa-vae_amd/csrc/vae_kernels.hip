@@ -1341,14 +1341,14 @@ template <bool CLEAR_G, bool COPY = false>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t n4, float b1, float b2, float eps,
                                                    float step_size, float bc2_sqrt, bf16_t* __restrict__ copy = nullptr,
-                                                   size_t ncopy4 = 0, float gscale = 1.f) {
+                                                   size_t ncopy4 = 0, float gscale = 1.f, size_t keep4 = 0) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         float4 P = ((float4*)p)[i], G = ((const float4*)g)[i], M = ((float4*)m)[i], V = ((float4*)v)[i];
         float* pp = (float*)&P; float* gg = (float*)&G; float* mm = (float*)&M; float* vv = (float*)&V;
 #pragma unroll
         for (int j = 0; j < 4; ++j) adam_update(pp[j], mul_rounded(gg[j], gscale), mm[j], vv[j], b1, b2, eps, step_size, bc2_sqrt);
         ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V;
-        if (CLEAR_G) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (CLEAR_G && i >= keep4) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // (keep4: a leading part the next step overwrites)
         if (COPY && i < ncopy4) {   // bf16 shadow of the leading (weight) part of the slice, same layout
             ushort4 c;
             c.x = f32_to_bf16(pp[0]); c.y = f32_to_bf16(pp[1]); c.z = f32_to_bf16(pp[2]); c.w = f32_to_bf16(pp[3]);
@@ -2149,6 +2149,19 @@ extern "C" int favae_adam_step_clear_scaled(float* p, float* g, float* m, float*
     ProfScope prof(13, 32.0 * (double)n, ST);
     hipLaunchKernelGGL(adam_kernel<true>, dim3(adam_grid((size_t)n / 4)), dim3(256), 0, ST, p, g, m, v, (size_t)n / 4, beta1, beta2, eps, step_size, bc2_sqrt,
                        (bf16_t*)nullptr, (size_t)0, gscale);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_adam_step_clear_from(float* p, float* g, float* m, float* v, long long n, long long keep, float lr, float beta1,
+                                          float beta2, float eps, long long step, void* stream) {
+    FAVAE_CHECK_ARG(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "favae_adam_step_clear_from: bad argument (n must be a multiple of 4)");
+    FAVAE_CHECK_ARG(keep >= 0 && keep <= n && keep % 4 == 0, "favae_adam_step_clear_from: keep (a multiple of 4, <= n)");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    ProfScope prof(13, 32.0 * (double)n - 4.0 * (double)keep, ST);
+    hipLaunchKernelGGL(adam_kernel<true>, dim3(adam_grid((size_t)n / 4)), dim3(256), 0, ST, p, g, m, v, (size_t)n / 4, beta1, beta2, eps, step_size, bc2_sqrt,
+                       (bf16_t*)nullptr, (size_t)0, 1.f, (size_t)keep / 4);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

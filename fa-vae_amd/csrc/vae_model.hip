@@ -185,6 +185,7 @@ struct Vae {
     unsigned beside;    // ensure_streams: pairs of streams measured to run on hardware queues of their own (bits: see there)
     int stream_score;   // ensure_streams: 21 = all three side streams run beside the main stream and each other
     bool join_pending; bool dg_all;
+    bool wg_keeps[NL];   // the weight gradient of the layer is stored whole by every step of this executor (unsplit GEMM): no zeroing
     bool dp_epoch;   // steps of favae_vae_train_epoch_dp: gradients cleared by the bucket-wise Adam, joins through the communication stream
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
     bool rk_done;   // stage 6 of this step already ran the reparameterisation backward (fused launch)
@@ -931,7 +932,9 @@ int adam_layer(Vae& v, int l, void* st, const Ada& a, int half) {
         // encoder.0 (no input gradient, so no transposed shadow): its update ends the step, the bf16 copy rides along
         return favae_adam_step_copy(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, a.lr, a.b1, a.b2, a.eps, a.step,
                                     a.epoch ? 1 : 0, c, (long long)L.Cout * L.taps * L.Cin, st);
-    if (a.epoch) RC(favae_adam_step_clear(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, a.lr, a.b1, a.b2, a.eps, a.step, st));
+    if (a.epoch && v.wg_keeps[l] && !(v.fuse & 0x20000000u))   // (FAVAE_FUSE_MASK bit 0x20000000: zero the whole slice, as before)
+        RC(favae_adam_step_clear_from(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, L.b_off - L.w_off, a.lr, a.b1, a.b2, a.eps, a.step, st));
+    else if (a.epoch) RC(favae_adam_step_clear(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, a.lr, a.b1, a.b2, a.eps, a.step, st));
     else RC(favae_adam_step(v.P + lo, v.G + lo, v.M + lo, v.V + lo, hi - lo, a.lr, a.b1, a.b2, a.eps, a.step, st));
     if (c || t) RC(favae_weight_prep(v.P + L.w_off, c, t, L.Cout, L.taps, L.Cin, v.dtype, st));
     if (l == L_OUT) RC(favae_conv_out_wprep(c ? (const void*)c : (const void*)(v.P + L.w_off), v.wk_out, v.ch, v.dtype, st));
@@ -1126,6 +1129,17 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     v.join2 = false;
     v.rk_done = false;
     v.ev_fence_ok = false;
+    // Layers whose weight-gradient GEMM runs unsplit at the largest batch of this executor (and then at every smaller one: the split
+    // grows with the pixel count) overwrite their slice of the gradient arena in every step, so the optimiser step of an epoch
+    // need not zero it (4 of the 32 bytes per weight it moves; encoder.4, decoder.0, decoder.1: 10.6 M of 12.8 M parameters).
+    // Executors of the grouped-batch mode (Bmax > 64) keep the zeroing: their tail steps and group steps split differently.
+    for (int l = 0; l < NL; ++l) {
+        const Layer& L = v.L[l];
+        v.wg_keeps[l] = false;
+        if (batch_max > 64 || l == 0 || l == L_OUT || (L.kind != CONV_S2 && L.kind != CONVT_S2)) continue;
+        const int hs = L.kind == CONVT_S2 ? L.Hin : L.Hout;
+        v.wg_keeps[l] = favae_conv_wgrad_auto_splitk(L.Cout, L.Cin, (long long)batch_max * hs * hs, 3) == 1;
+    }
     v.x_folded = false;
     v.inline_tail = false;
     v.fold_sel = 0;

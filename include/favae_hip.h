@@ -344,6 +344,12 @@ int favae_adam_step_clear(float* p, float* g, float* m, float* v, long long n, f
  * of the ranks' gradients and passes 1 / ranks.  No counterpart of its own in the reference (which trains on one device). */
 int favae_adam_step_clear_scaled(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                                  long long step, float gscale, void* stream);
+/* favae_adam_step_clear that leaves g[0 .. keep) as it is (the training epoch: a weight gradient that the next step's GEMM overwrites
+ * whole needs no zeroing; the bias / BatchNorm gradients behind it are accumulated into and do).  No counterpart in the reference. */
+int favae_adam_step_clear_from(float* p, float* g, float* m, float* v, long long n, long long keep, float lr, float beta1, float beta2,
+                               float eps, long long step, void* stream);
+/* The number of slices favae_conv_wgrad picks for splitk <= 0 (1: the launch stores its result, no accumulation into dw). */
+int favae_conv_wgrad_auto_splitk(int Rc, int Cc, long long K, int ks);
 /* favae_adam_step (clear_g: + the zeroing of favae_adam_step_clear) that also writes the bf16 copy of the first `ncopy`
  * updated parameters (a layer's weights, same [Cout][tap][Cin] layout) in the same pass: the optimiser step and the
  * dtype shadow of encoder.0, whose update is the last link of a training step (optim.step(), :250). */

@@ -312,6 +312,30 @@ def test_adam_on_the_summed_gradient_of_the_ranks(ranks):
         assert torch.equal(a, b)
 
 
+def test_adam_that_leaves_an_overwritten_gradient_prefix():
+    """favae_adam_step_clear_from == favae_adam_step_clear with g[0 .. keep) left as it is (a weight gradient that the next step's
+    unsplit GEMM stores whole); favae_conv_wgrad_auto_splitk names those launches: enc.4 / dec.0 / dec.1 / enc.3 at batch 64 run
+    unsplit, enc.1 / enc.2 / dec.2 / dec.3 split their pixel reduction."""
+    L = _L()
+    raw_ = L.raw()
+    n, keep = 4096 + 64, 4096
+    g = torch.Generator().manual_seed(5)
+    p0, g0 = torch.randn(n, generator=g).cuda(), (torch.randn(n, generator=g) * 0.1).cuda()
+    m0, v0 = (torch.randn(n, generator=g) * 0.01).cuda(), (torch.rand(n, generator=g) * 1e-3).cuda()
+    pa, ga, ma, va = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    L.check(raw_.favae_adam_step_clear(L.ptr(pa), L.ptr(ga), L.ptr(ma), L.ptr(va), ll_(n), f_(1e-3), f_(0.9), f_(0.999), f_(1e-8), ll_(3),
+                                       L.stream_ptr()))
+    pb, gb, mb, vb = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    L.check(raw_.favae_adam_step_clear_from(L.ptr(pb), L.ptr(gb), L.ptr(mb), L.ptr(vb), ll_(n), ll_(keep), f_(1e-3), f_(0.9), f_(0.999),
+                                            f_(1e-8), ll_(3), L.stream_ptr()))
+    for a, b in ((pa, pb), (ma, mb), (va, vb)):
+        assert torch.equal(a, b)
+    assert torch.equal(gb[:keep], g0[:keep]) and float(gb[keep:].abs().max()) == 0.0
+    sk = lambda co, ci, k: raw_.favae_conv_wgrad_auto_splitk(i_(co), i_(ci), ll_(k), i_(3))
+    assert [sk(1024, 512, 64 * 4), sk(512, 1024, 64 * 4), sk(256, 512, 64 * 16), sk(512, 256, 64 * 16)] == [1, 1, 1, 1]
+    assert min(sk(128, 64, 64 * 256), sk(256, 128, 64 * 64), sk(128, 256, 64 * 64), sk(64, 128, 64 * 256)) > 1
+
+
 @pytest.mark.parametrize("clear", [0, 1])
 def test_adam_with_bf16_copy_of_the_weights(clear):
     """favae_adam_step_copy (encoder.0: 64 x 9 x 3 weights + bias + BN affine) == favae_adam_step(_clear) followed by
