@@ -337,17 +337,12 @@ struct Carver {
 };
 
 void choose_storage(Vae& v) {
-    // Optional (FAVAE_BF16_RAW=1, bf16 executor only): the conv output (raw) and the activation gradient (dact) of the BN
-    // layers with >= 4 M elements per batch are stored as bf16; the BN statistics / backward sums still come from the
-    // fp32 accumulators of the producing GEMM.  Off by default: measured on MI355X it shortens the step by 0.3 % only
-    // (these tensors live in the 256 MB Infinity Cache between producer and consumer, so halving their bytes buys little),
-    // which does not pay for the extra rounding.
-    const char* e = getenv("FAVAE_BF16_RAW");
-    const bool off = v.dtype != FAVAE_BF16 || !(e && e[0] == '1');
-    for (int l = 0; l < NL; ++l) {
-        const size_t n = (size_t)v.rows(l, v.Bmax) * v.L[l].Cout;
-        v.raw_bf[l] = v.dact_bf[l] = !off && v.L[l].bn && n >= ((size_t)1 << 22);
-    }
+    // Batch-64 executors keep the conv outputs (raw) and activation gradients (dact) in fp32: stored as bf16 for the layers with
+    // >= 4 M elements per batch (round 2, FAVAE_BF16_RAW) the step was 0.3 % shorter only -- these tensors live in the 256 MB
+    // Infinity Cache between producer and consumer -- which did not pay for the extra rounding; the switch was removed at the end of
+    // round 3 (the launches added since were never taught that storage at batch 64, and it was no faster: 0.852 against 0.845 ms).
+    const bool off = true;
+    for (int l = 0; l < NL; ++l) v.raw_bf[l] = v.dact_bf[l] = false;
     // Grouped-batch mode (bf16 executor with Bmax > 64): at G = 8 the conv outputs and activation gradients of a step are 4 GB, far
     // beyond the 256 MB Infinity Cache, and the step is bound by their HBM traffic (40 B per BatchNorm element and step; final_layer.0
     // alone is half of it).  The activation gradients (dact) of every BatchNorm layer and the conv outputs (raw) of the DECODER side
