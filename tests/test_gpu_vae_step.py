@@ -507,6 +507,20 @@ def test_epoch_that_leaves_overwritten_weight_gradients_unzeroed():
     assert float(g1["enc.4.0.weight"].abs().max()) == 0.0 and float(g0["enc.4.0.weight"].abs().max()) > 0.0
 
 
+def test_every_fuse_mask_switch_reproduces_the_default_path():
+    """Each FAVAE_FUSE_MASK switch of the executor toggled on its own (27 switches, bf16 and fp32; tools/sweep_fuse_bits.py): a
+    3-step epoch, update_x and the reconstruction sums must agree with the default path (first step 2e-3, later steps and the eval
+    passes within the run-to-run spread), so that no measured-and-kept alternative goes stale behind the default."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("sweep_fuse_bits", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                  "tools", "sweep_fuse_bits.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = mod.sweep(verbose=False)
+    assert not bad, bad
+
+
 def test_uint8_resident_data_set_equals_fp32_resident():
     """8-bit images (values k / 255, what the trainers' ToTensor loader yields) stay resident as uint8: a quarter of the HBM.
     The gathered batches are bit-identical to those of the fp32 copy (correctly rounded k / 255 on the device), so a training
