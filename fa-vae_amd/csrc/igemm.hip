@@ -1250,6 +1250,13 @@ int launch_kc(KcParams p, int classes, hipStream_t st) {
     return FAVAE_OK;
 }
 
+// split of the reduction where the tile grid alone cannot fill the chip (dispatch_kc and favae_conv_igemm_auto_splitk)
+inline int kc_auto_splitk(int blocks, int nchunk, int target_blocks) {
+    int sk = 1;
+    if (2 * blocks < target_blocks) sk = std::min(std::max(1, nchunk / 4), (target_blocks + blocks / 2) / blocks);
+    return std::max(1, std::min(sk, nchunk));
+}
+
 template <class T, bool TR>
 int dispatch_kc(KcParams p, int classes, int target_blocks, int* fused, hipStream_t st) {
     const bool slow = (p.Cin % BK) != 0;
@@ -1268,7 +1275,7 @@ int dispatch_kc(KcParams p, int classes, int target_blocks, int* fused, hipStrea
     const bool prezeroed = p.splitk < 0;   // caller guarantees out == 0 (one pooled memset per step, vae_model.hip)
     int sk = 1;
     if (p.splitk > 0) sk = p.splitk;
-    else if (2 * blocks < target_blocks) sk = std::min(std::max(1, nchunk / 4), (target_blocks + blocks / 2) / blocks);
+    else sk = kc_auto_splitk(blocks, nchunk, target_blocks);
     p.splitk = std::max(1, std::min(sk, nchunk));
     if (p.out_bf16) p.splitk = 1;   // a bf16 result cannot be accumulated across blocks
     // the per-channel epilogue sums exist in the staged 64x64 epilogue of unsplit reductions only
@@ -1477,6 +1484,20 @@ extern "C" int favae_conv_igemm(const void* in, const void* w, const float* bias
                                 int dtype, void* stream) {
     const RedArgs none{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     return conv_igemm_impl(in, w, bias, out, Nb, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad, scatter, splitk, dtype, none, stream);
+}
+
+/* The number of reduction slices favae_conv_igemm picks for splitk <= 0 (1: every output element is stored once; > 1: accumulated with
+ * atomics into an output that is zero).  0 while a developer override of the tile is active. */
+extern "C" int favae_conv_igemm_auto_splitk(int Nb, int Ho, int Wo, int Cin, int Cout, int ks, int stride, int scatter) {
+    if (Nb <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || ks <= 0 || g_force_kc_tile >= 0) return 0;
+    const bool slow = (Cin % BK) != 0, tr = scatter != 0;
+    int classes = 1, HoC = Ho, WoC = Wo;
+    if (scatter && stride == 2) { classes = 4; HoC = Ho / 2; WoC = Wo / 2; }
+    const bool narrow_n = !slow && Cout <= 32 && !tr;
+    const int BM = narrow_n ? 128 : 64, BN = narrow_n ? 32 : 64;
+    const int nchunk = slow ? cdiv(ks * ks * Cin, BK) : ks * ks * (Cin / BK);
+    const int blocks = cdiv(Nb * HoC * WoC, BM) * cdiv(Cout, BN) * classes;
+    return kc_auto_splitk(blocks, nchunk, 512);
 }
 
 extern "C" int favae_conv_igemm_red(const void* in, const void* w, const float* bias, float* out, int Nb, int Hi, int Wi,

@@ -367,13 +367,26 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
     // reduction, i.e. the small ones; everything in [zero_lo, zero_lo + zero_bytes) is cleared once per training step
     const size_t pool_max = (size_t)1 << 20;   // elements
     v.zero_lo = (char*)c.take(0);
+    // A convolution layer's tensors stay out of the pool where the launch that produces them runs unsplit at this executor's batch
+    // (it stores every element; at batch 64: raw of encoder.2 / decoder.1 and the gradients flowing into them, 16.8 of the 36 MB of
+    // the per-step memset).  A smaller batch (the tail of an epoch) may split after all: the launch is then told that its output
+    // is not zeroed and clears it itself.  (FAVAE_FUSE_MASK bit 0x2000000: everything small in the pool, as before)
+    const char* fenv = getenv("FAVAE_FUSE_MASK");   // (v.fuse is read after the workspace is laid out)
+    const bool pool_all = fenv && (strtoul(fenv, nullptr, 0) & 0x2000000u) != 0;
+    auto is_conv = [&](int l) { return l >= 0 && l < NL && (v.L[l].kind == CONV_S2 || v.L[l].kind == CONVT_S2); };
     for (int l = 0; l < NL; ++l) {
-        const size_t n = (size_t)v.rows(l, B) * v.L[l].Cout;
+        const Layer& L = v.L[l];
+        const size_t n = (size_t)v.rows(l, B) * L.Cout;
         v.raw_pooled[l] = v.dact_pooled[l] = n <= pool_max;
-        if (n <= pool_max) {
-            v.raw[l] = (float*)c.take(n * 4);
-            v.dact[l] = (float*)c.take(n * 4);
+        if (n <= pool_max && !pool_all && is_conv(l)) {
+            if (favae_conv_igemm_auto_splitk(B, L.Hout, L.Hout, L.Cin, L.Cout, 3, 2, L.kind == CONVT_S2) == 1) v.raw_pooled[l] = false;
+            if (is_conv(l + 1)) {   // dact[l] is the input gradient of layer l + 1: scatter form for a convolution, gather form for a transposed one
+                const Layer& N = v.L[l + 1];
+                if (favae_conv_igemm_auto_splitk(B, N.Hin, N.Hin, N.Cout, N.Cin, 3, 2, N.kind == CONV_S2) == 1) v.dact_pooled[l] = false;
+            }
         }
+        if (v.raw_pooled[l]) v.raw[l] = (float*)c.take(n * 4);
+        if (v.dact_pooled[l]) v.dact[l] = (float*)c.take(n * 4);
     }
     v.dz = (float*)c.take((size_t)B * v.z * 4);
     // grouped-batch mode (Bmax > 64: up to Bmax / 64 BatchNorm groups per step): every BatchNorm layer has bins, per group
@@ -391,10 +404,8 @@ void carve(Vae& v, char* base, size_t cap, size_t* need) {
     }
     for (int l = 0; l < NL; ++l) {
         const size_t n = (size_t)v.rows(l, B) * v.L[l].Cout;
-        if (n > pool_max) {
-            v.raw[l] = (float*)c.take(n * (v.raw_bf[l] ? 2 : 4));
-            v.dact[l] = (float*)c.take(n * (v.dact_bf[l] ? 2 : 4));
-        }
+        if (!v.raw_pooled[l]) v.raw[l] = (float*)c.take(n * (v.raw_bf[l] ? 2 : 4));
+        if (!v.dact_pooled[l]) v.dact[l] = (float*)c.take(n * (v.dact_bf[l] ? 2 : 4));
         v.act[l] = (char*)c.take(n * v.esz);
         v.draw[l] = (char*)c.take(n * v.esz);
         v.mean[l] = (float*)c.take((size_t)Gmax * v.L[l].Cout * 4);

@@ -348,6 +348,9 @@ int favae_adam_step_clear_scaled(float* p, float* g, float* m, float* v, long lo
  * whole needs no zeroing; the bias / BatchNorm gradients behind it are accumulated into and do).  No counterpart in the reference. */
 int favae_adam_step_clear_from(float* p, float* g, float* m, float* v, long long n, long long keep, float lr, float beta1, float beta2,
                                float eps, long long step, void* stream);
+/* The number of reduction slices favae_conv_igemm picks for splitk <= 0 (1: every output element is stored once, the output need not be
+ * zero; > 1: fp32 atomics into a zeroed output).  The executor keeps only the outputs of launches that split in its per-step memset. */
+int favae_conv_igemm_auto_splitk(int Nb, int Ho, int Wo, int Cin, int Cout, int ks, int stride, int scatter);
 /* The number of slices favae_conv_wgrad picks for splitk <= 0 (1: the launch stores its result, no accumulation into dw). */
 int favae_conv_wgrad_auto_splitk(int Rc, int Cc, long long K, int ks);
 /* favae_adam_step (clear_g: + the zeroing of favae_adam_step_clear) that also writes the bf16 copy of the first `ncopy`

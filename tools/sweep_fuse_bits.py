@@ -11,7 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "fa-vae_amd")):
     sys.path.insert(0, p)
 
 BITS = [1, 2, 4, 8, 16, 32, 64, 128, 0x100, 0x200, 0x800, 0x1000, 0x2000, 0x4000, 0x8000, 0x10000, 0x20000, 0x40000, 0x80000, 0x100000,
-        0x400000, 0x4000000, 0x8000000, 0x10000000, 0x20000000, 0x40000000, 0x80000000]
+        0x400000, 0x2000000, 0x4000000, 0x8000000, 0x10000000, 0x20000000, 0x40000000, 0x80000000]
 
 
 def run(mask, dtype, n=192, z=20):
