@@ -343,6 +343,15 @@ void choose_storage(Vae& v) {
     // round 3 (the launches added since were never taught that storage at batch 64, and it was no faster: 0.852 against 0.845 ms).
     const bool off = true;
     for (int l = 0; l < NL; ++l) v.raw_bf[l] = v.dact_bf[l] = false;
+    // One exception (end of round 3): the gradient w.r.t. final_layer.0's activation, 16.8 M elements per batch and half of all
+    // BatchNorm-backward bytes, is stored as bf16: folded_dgrad_kernel writes and the BatchNorm backward reads 34 instead of 67 MB,
+    // step 0.843 -> 0.827 ms on the same box (tools/sweep_store.sh; the other large layers and the conv outputs on top of it: no
+    // further gain).  The two BatchNorm-backward sums still come from the fp32 accumulators of the producing launch, and the
+    // grouped-batch mode has stored every activation gradient this way since it exists.  FAVAE_DACT11_BF16=0: fp32, as before.
+    {
+        const char* e = getenv("FAVAE_DACT11_BF16");
+        if (v.dtype == FAVAE_BF16 && !(e && e[0] == '0')) v.dact_bf[11] = true;
+    }
     // Grouped-batch mode (bf16 executor with Bmax > 64): at G = 8 the conv outputs and activation gradients of a step are 4 GB, far
     // beyond the 256 MB Infinity Cache, and the step is bound by their HBM traffic (40 B per BatchNorm element and step; final_layer.0
     // alone is half of it).  The activation gradients (dact) of every BatchNorm layer and the conv outputs (raw) of the DECODER side

@@ -11,7 +11,9 @@ Rounding points (csrc/vae_model.hip, bf16 executor with exact ends):
   * the gradient w.r.t. every conv / linear output (draw): stored as bf16, read by both the weight and the input gradient;
   * encoder.0: forward on the unrounded image, weight gradient on the bf16 image (the hi plane of the folded batch);
   * fc heads: forward from the unrounded encoder.4 activation with fp32 weights, gradients through the bf16 activation / shadow;
-  * conv outputs (raw), activation gradients (dact), BatchNorm statistics, loss: fp32 (fp64 for the KL and the sums)."""
+  * the gradient w.r.t. final_layer.0's activation (dact of the largest layer): stored as bf16 (its BatchNorm-backward sums are taken
+    from the unrounded values in the producing launch; the emulation takes them from the rounded ones);
+  * conv outputs (raw), the other activation gradients (dact), BatchNorm statistics, loss: fp32 (fp64 for the KL and the sums)."""
 import torch
 import torch.nn.functional as F
 
@@ -85,6 +87,7 @@ def loss_terms_bf16(P, B, images, mu_P, tau, var_x, beta, eps):
         x, _ = _bn_act(rb(raw), P, B, pre)
     raw = F.conv_transpose2d(x, rf(P["final_layer.0.weight"]), P["final_layer.0.bias"], stride=2, padding=1, output_padding=1)
     x, _ = _bn_act(rb(raw), P, B, "final_layer")
+    x = rb(x)   # the gradient w.r.t. final_layer.0's activation (dact[11]) is stored as bf16
     rec = torch.sigmoid(rb(F.conv2d(x, rf(P["final_layer.3.weight"]), P["final_layer.3.bias"], padding=1)))
     std_P = torch.sqrt(torch.ones_like(mu_P) * (1 / tau))
     rec_err = -vt.gaussian_ll(images, rec, var_x)
