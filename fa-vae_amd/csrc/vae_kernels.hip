@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void bn_lrelu_fwd_bins(const RT* __restrict__ 
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          T* __restrict__ act, float* __restrict__ mean, float* __restrict__ invstd,
                                                          float* __restrict__ run_mean, float* __restrict__ run_var, size_t nvec,
-                                                         int C, double R, float eps, float mom) {
+                                                         int C, double R, float eps, float mom, float* __restrict__ ab_out = nullptr) {
     __shared__ double sm[256], tot[512];
     __shared__ float ab[512];
     bins_total(bins, nbin, C, sm, tot);
@@ -399,6 +399,7 @@ __global__ __launch_bounds__(256) void bn_lrelu_fwd_bins(const RT* __restrict__ 
         if (blockIdx.x == 0) {
             mean[tid] = (float)m;
             invstd[tid] = is;
+            if (ab_out) { ab_out[tid] = a; ab_out[C + tid] = ab[C + tid]; }   // the (a | b) the backward pass takes the LeakyReLU slope from
             if (run_mean) {
                 const double unb = R > 1 ? var * R / (R - 1) : var;
                 run_mean[tid] = (1.f - mom) * run_mean[tid] + mom * (float)m;
@@ -463,8 +464,11 @@ struct BnBwdApplyF {
     // bins != NULL: the two sums come from the epilogue of the GEMM that produced dact (igemm.hip, red_mode 2) instead of
     // BnBwdRedF; every block adds the bins of its channel tile, the first slab also writes dgamma / dbeta
     const double* bins; int nbin; float *dgamma, *dbeta;
+    // ab != NULL: the (a | b) of the forward pass (favae_bn_train_fwd_bins_ab): the LeakyReLU slope is the sign of raw * a + b, the
+    // forward pass's own expression, and the stored activation is not read (2 of the 12 bytes per element)
+    const float* ab = nullptr;
     static constexpr bool BLOCK_INIT = true;
-    struct Ctx { float mu[4], is[4], gi[4], k1[4], k2[4]; };
+    struct Ctx { float mu[4], is[4], gi[4], k1[4], k2[4], fa[4], fb[4]; };
     __device__ void block_init(double* sm, double* btot, int CT) const {
         if (!bins) return;   // uniform
         const int tid = threadIdx.x, n2 = 2 * CT, v = tid % n2, part = tid / n2, parts = RED_THREADS / n2;
@@ -487,6 +491,7 @@ struct BnBwdApplyF {
     __device__ void init(Ctx& k, int c0, const double* bt) const {
         for (int j = 0; j < 4 && c0 + j < C; ++j) {
             k.mu[j] = mean[c0 + j]; k.is[j] = invstd[c0 + j]; k.gi[j] = gamma[c0 + j] * invstd[c0 + j];
+            if (ab) { k.fa[j] = ab[c0 + j]; k.fb[j] = ab[C + c0 + j]; }
             if (bins) { k.k1[j] = (float)bt[2 * j] * invR; k.k2[j] = (float)bt[2 * j + 1] * invR; }
             else { k.k1[j] = s1s2[c0 + j] * invR; k.k2[j] = s1s2[C + c0 + j] * invR; }
         }
@@ -494,9 +499,14 @@ struct BnBwdApplyF {
     template <int VW> __device__ void row(const Ctx& k, int r, int c0, double (*acc)[VW]) const {
         const size_t i = (size_t)r * C + c0;
         float a[VW], d[VW], x[VW], g[VW];
-        VecLoad<T, VW>::ld(act + i, a);
         VecLoad<DT, VW>::ld(dact + i, d);
         VecLoad<RT, VW>::ld(raw + i, x);
+        if (ab) {   // uniform
+#pragma unroll
+            for (int j = 0; j < VW; ++j) a[j] = x[j] * k.fa[j] + k.fb[j];
+        } else {
+            VecLoad<T, VW>::ld(act + i, a);
+        }
 #pragma unroll
         for (int j = 0; j < VW; ++j) {
             const float dd = d[j] * (a[j] > 0.f ? 1.f : 0.01f);
@@ -1736,9 +1746,9 @@ extern "C" int favae_bn_train_fwd_keep32(const float* raw, const float* gamma, c
 }
 extern "C" int favae_bn_train_fwd_keep32_ok(long long R, int C) { return owner_applicable(R, C) ? 1 : 0; }
 
-extern "C" int favae_bn_train_fwd_bins(const void* raw, const double* bins, int nbins, const float* gamma, const float* beta,
+static int bn_train_fwd_bins_impl(const void* raw, const double* bins, int nbins, const float* gamma, const float* beta,
                                        void* act, float* mean, float* invstd, float* run_mean, float* run_var, long long R,
-                                       int C, float eps, float momentum, int dtype, void* stream) {
+                                       int C, float eps, float momentum, int dtype, float* ab_out, void* stream) {
     FAVAE_CHECK_ARG(raw && bins && gamma && beta && act && mean && invstd && R > 0 && R < (1LL << 31) && nbins >= 1,
                     "favae_bn_train_fwd_bins: bad argument");
     FAVAE_CHECK_ARG(bins_applicable(C), "favae_bn_train_fwd_bins: C = %d not supported (64, 128, 256 ...)", C);
@@ -1754,16 +1764,27 @@ extern "C" int favae_bn_train_fwd_bins(const void* raw, const double* bins, int 
 #define FB_ARGS bins, nbins, gamma, beta
     if (DT_BASE(dtype) == FAVAE_F32)
         hipLaunchKernelGGL((bn_lrelu_fwd_bins<float, float>), dim3((unsigned)grid), dim3(256), 0, ST, (const float*)raw, FB_ARGS, (float*)act,
-                           mean, invstd, run_mean, run_var, nvec, C, (double)R, eps, momentum);
+                           mean, invstd, run_mean, run_var, nvec, C, (double)R, eps, momentum, ab_out);
     else if (RAW_IS_BF16(dtype))
         hipLaunchKernelGGL((bn_lrelu_fwd_bins<bf16_t, bf16_t>), dim3((unsigned)grid), dim3(256), 0, ST, (const bf16_t*)raw, FB_ARGS, (bf16_t*)act,
-                           mean, invstd, run_mean, run_var, nvec, C, (double)R, eps, momentum);
+                           mean, invstd, run_mean, run_var, nvec, C, (double)R, eps, momentum, ab_out);
     else
         hipLaunchKernelGGL((bn_lrelu_fwd_bins<bf16_t, float>), dim3((unsigned)grid), dim3(256), 0, ST, (const float*)raw, FB_ARGS, (bf16_t*)act,
-                           mean, invstd, run_mean, run_var, nvec, C, (double)R, eps, momentum);
+                           mean, invstd, run_mean, run_var, nvec, C, (double)R, eps, momentum, ab_out);
 #undef FB_ARGS
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
+}
+extern "C" int favae_bn_train_fwd_bins(const void* raw, const double* bins, int nbins, const float* gamma, const float* beta,
+                                       void* act, float* mean, float* invstd, float* run_mean, float* run_var, long long R,
+                                       int C, float eps, float momentum, int dtype, void* stream) {
+    return bn_train_fwd_bins_impl(raw, bins, nbins, gamma, beta, act, mean, invstd, run_mean, run_var, R, C, eps, momentum, dtype, nullptr, stream);
+}
+extern "C" int favae_bn_train_fwd_bins_ab(const void* raw, const double* bins, int nbins, const float* gamma, const float* beta,
+                                          void* act, float* mean, float* invstd, float* ab, float* run_mean, float* run_var, long long R,
+                                          int C, float eps, float momentum, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(ab, "favae_bn_train_fwd_bins_ab: null ab");
+    return bn_train_fwd_bins_impl(raw, bins, nbins, gamma, beta, act, mean, invstd, run_mean, run_var, R, C, eps, momentum, dtype, ab, stream);
 }
 
 template <class T, class RT, class DT>
@@ -1789,36 +1810,51 @@ static int bn_bwd_impl(const void* dact_, const void* act_, const void* raw_, co
 template <class T, class RT, class DT>
 static int bn_bwd_bins_impl(const void* dact, const void* act, const void* raw, const float* mean, const float* invstd,
                             const float* gamma, const double* bins, int nbins, void* draw, float* dgamma, float* dbeta,
-                            float* dbias, long long R, int C, double* scratch, size_t cap, hipStream_t st, bool defer) {
-    // algorithmic bytes: dact + raw + act read, draw written
-    ProfScope prof(7, (double)R * C * (sizeof(DT) + sizeof(RT) + 2 * sizeof(T)), st);
+                            float* dbias, long long R, int C, double* scratch, size_t cap, hipStream_t st, bool defer, const float* ab) {
+    // algorithmic bytes: dact + raw (+ act) read, draw written
+    ProfScope prof(7, (double)R * C * (sizeof(DT) + sizeof(RT) + (ab ? 1 : 2) * sizeof(T)), st);
     if (defer)
         return run_colreduce<1>(R, C, scratch, cap,
                                 BnBwdApplyF<T, RT, DT, true>{(const DT*)dact, (const T*)act, (const RT*)raw, mean, invstd, gamma, nullptr, (T*)draw,
-                                                             C, (float)(1.0 / (double)R), nullptr, bins, nbins, dgamma, dbeta}, st);
+                                                             C, (float)(1.0 / (double)R), nullptr, bins, nbins, dgamma, dbeta, ab}, st);
     return run_colreduce<1>(R, C, scratch, cap,
                             BnBwdApplyF<T, RT, DT>{(const DT*)dact, (const T*)act, (const RT*)raw, mean, invstd, gamma, nullptr, (T*)draw, C,
-                                                   (float)(1.0 / (double)R), dbias, bins, nbins, dgamma, dbeta}, st);
+                                                   (float)(1.0 / (double)R), dbias, bins, nbins, dgamma, dbeta, ab}, st);
 }
 
-extern "C" int favae_bn_lrelu_bwd_bins(const void* dact, const void* act, const void* raw, const float* mean,
+static int bn_lrelu_bwd_bins_any(const void* dact, const void* act, const void* raw, const float* mean,
                                        const float* invstd, const float* gamma, const double* bins, int nbins, void* draw,
                                        float* dgamma, float* dbeta, float* dbias, long long R, int C, double* scratch,
-                                       size_t scratch_doubles, int dtype, void* stream) {
-    FAVAE_CHECK_ARG(dact && act && raw && mean && invstd && gamma && bins && draw && dgamma && dbeta && scratch && nbins >= 1,
+                                       size_t scratch_doubles, int dtype, const float* ab, void* stream) {
+    FAVAE_CHECK_ARG(dact && (act || ab) && raw && mean && invstd && gamma && bins && draw && dgamma && dbeta && scratch && nbins >= 1,
                     "favae_bn_lrelu_bwd_bins: null pointer");
     FAVAE_CHECK_ARG(R > 0 && R < (1LL << 31) && C > 0, "favae_bn_lrelu_bwd_bins: bad shape");
     FAVAE_CHECK_ARG(DT_BASE(dtype) == FAVAE_F32 || DT_BASE(dtype) == FAVAE_BF16, "favae_bn_lrelu_bwd_bins: dtype");
     FAVAE_CHECK_ARG(!((RAW_IS_BF16(dtype) || DACT_IS_BF16(dtype)) && (DT_BASE(dtype) != FAVAE_BF16 || C % 4 != 0)),
                     "favae_bn_lrelu_bwd_bins: FAVAE_RAW_BF16 / FAVAE_DACT_BF16 need FAVAE_BF16 and C %% 4 == 0");
     const bool defer = (dtype & FAVAE_DBIAS_DEFER) != 0;   // scratch keeps the per-slab column sums, dbias is not written
-#define BB_ARGS dact, act, raw, mean, invstd, gamma, bins, nbins, draw, dgamma, dbeta, dbias, R, C, scratch, scratch_doubles, ST, defer
+#define BB_ARGS dact, act, raw, mean, invstd, gamma, bins, nbins, draw, dgamma, dbeta, dbias, R, C, scratch, scratch_doubles, ST, defer, ab
     if (DT_BASE(dtype) == FAVAE_F32) return bn_bwd_bins_impl<float, float, float>(BB_ARGS);
     if (RAW_IS_BF16(dtype) && DACT_IS_BF16(dtype)) return bn_bwd_bins_impl<bf16_t, bf16_t, bf16_t>(BB_ARGS);
     if (RAW_IS_BF16(dtype)) return bn_bwd_bins_impl<bf16_t, bf16_t, float>(BB_ARGS);
     if (DACT_IS_BF16(dtype)) return bn_bwd_bins_impl<bf16_t, float, bf16_t>(BB_ARGS);
     return bn_bwd_bins_impl<bf16_t, float, float>(BB_ARGS);
 #undef BB_ARGS
+}
+extern "C" int favae_bn_lrelu_bwd_bins(const void* dact, const void* act, const void* raw, const float* mean,
+                                       const float* invstd, const float* gamma, const double* bins, int nbins, void* draw,
+                                       float* dgamma, float* dbeta, float* dbias, long long R, int C, double* scratch,
+                                       size_t scratch_doubles, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(act, "favae_bn_lrelu_bwd_bins: null pointer");
+    return bn_lrelu_bwd_bins_any(dact, act, raw, mean, invstd, gamma, bins, nbins, draw, dgamma, dbeta, dbias, R, C, scratch, scratch_doubles, dtype,
+                                 nullptr, stream);
+}
+extern "C" int favae_bn_lrelu_bwd_bins_ab(const void* dact, const void* raw, const float* mean, const float* invstd, const float* gamma,
+                                          const float* ab, const double* bins, int nbins, void* draw, float* dgamma, float* dbeta, float* dbias,
+                                          long long R, int C, double* scratch, size_t scratch_doubles, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(ab, "favae_bn_lrelu_bwd_bins_ab: null ab");
+    return bn_lrelu_bwd_bins_any(dact, nullptr, raw, mean, invstd, gamma, bins, nbins, draw, dgamma, dbeta, dbias, R, C, scratch, scratch_doubles, dtype,
+                                 ab, stream);
 }
 
 extern "C" int favae_bn_lrelu_bwd(const void* dact, const void* act, const void* raw, const float* mean,

@@ -185,6 +185,7 @@ struct Vae {
     unsigned beside;    // ensure_streams: pairs of streams measured to run on hardware queues of their own (bits: see there)
     int stream_score;   // ensure_streams: 21 = all three side streams run beside the main stream and each other
     bool join_pending; bool dg_all;
+    bool ab_live[NL];    // this step's forward pass published (a | b) of the layer's BatchNorm: the backward pass takes the LeakyReLU slope from raw * a + b
     bool wg_keeps[NL];   // the weight gradient of the layer is stored whole by every step of this executor (unsplit GEMM): no zeroing
     bool dp_epoch;   // steps of favae_vae_train_epoch_dp: gradients cleared by the bucket-wise Adam, joins through the communication stream
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
@@ -641,8 +642,18 @@ int bn_fwd(Vae& v, int l, int B, bool train, void* st) {
         v.bn_published[l] = v.stats_fused[l] = false;
         return favae_bn_lrelu_fwd_ab(v.raw[l], v.ab[l], v.act[l], R, L.Cout, v.dtype, st);
     }
+    if (train && B <= 64) v.ab_live[l] = false;
     if (train && v.stats_fused[l]) {
         v.stats_fused[l] = false;
+        // final_layer.0 (16.8 M elements per batch): the backward pass does without the stored activation, twice 34 MB per step
+        // (the input gradient of final_layer.3 with the BatchNorm-backward sums, and the BatchNorm backward itself): step 0.831 ->
+        // 0.8255 ms.  The same for the other layers with epilogue sums (58 MB more, through favae_conv_igemm_red_groups with one
+        // group) measured slower again: 0.824 with this layer alone, 0.825 with decoder.3 and encoder.0, 0.829 with all.
+        if (l == 11 && v.dtype == FAVAE_BF16 && !(v.fuse & 0x10000000u)) {
+            v.ab_live[l] = true;
+            return favae_bn_train_fwd_bins_ab(v.raw[l], v.sbins[l], bins_for(R), v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l], v.invstd[l],
+                                              v.ab[l], v.BUF + L.rm_off, v.BUF + L.rv_off, R, L.Cout, 1e-5f, 0.1f, dt, st);
+        }
         return favae_bn_train_fwd_bins(v.raw[l], v.sbins[l], bins_for(R), v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l],
                                        v.invstd[l], v.BUF + L.rm_off, v.BUF + L.rv_off, R, L.Cout, 1e-5f, 0.1f, dt, st);
     }
@@ -768,6 +779,12 @@ int bn_bwd(Vae& v, int l, int B, void* st) {
         // launch of its own would sit on the main chain when the tail of the step runs there)
         const bool defer = !(v.fuse & 0x400000u) && v.dbp[l] && slabs >= 1 && slabs <= DBP_SLABS && !(l == 0 && !v.x_folded);
         v.dbias_slabs[l] = defer ? slabs : 0;
+        if (v.ab_live[l])
+            return favae_bn_lrelu_bwd_bins_ab(v.dact[l], v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.ab[l], v.gbins[l], bins_for(v.rows(l, B)),
+                                              v.draw[l], v.G + L.g_off, v.G + L.be_off, v.G + L.b_off, v.rows(l, B), L.Cout,
+                                              defer ? v.dbp[l] : v.scratch, defer ? (size_t)DBP_SLABS * L.Cout : v.scratch_doubles,
+                                              v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0) | (v.dact_bf[l] ? FAVAE_DACT_BF16 : 0) |
+                                                  (defer ? FAVAE_DBIAS_DEFER : 0), st);
         return favae_bn_lrelu_bwd_bins(v.dact[l], v.act[l], v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off, v.gbins[l],
                                        bins_for(v.rows(l, B)), v.draw[l], v.G + L.g_off, v.G + L.be_off, v.G + L.b_off,
                                        v.rows(l, B), L.Cout, defer ? v.dbp[l] : v.scratch, defer ? (size_t)DBP_SLABS * L.Cout : v.scratch_doubles,
@@ -1006,7 +1023,8 @@ int dgrad(Vae& v, int l, float* out, int B, void* st, bool out_zeroed, bool out_
         const int G = B > 64 ? B / 64 : 1;
         double* bins = B > 64 ? v.gbins[o] : ((v.fuse & 4u) ? gbins64(v, o) : nullptr);
         RC(favae_conv_folded_dgrad(v.fold, v.Wf(L_OUT), out, (long long)B * L.Hin * L.Hin, 9 * L.Cout, L.Cin, bins, bins_for(v.rows(o, B > 64 ? 64 : B)),
-                                   v.act[o], v.raw[o], v.mean[o], v.invstd[o], B > 64 ? v.gab(o) : nullptr, G, dt | (v.raw_bf[o] ? FAVAE_RAW_BF16 : 0), st));
+                                   v.act[o], v.raw[o], v.mean[o], v.invstd[o], B > 64 ? v.gab(o) : (v.ab_live[o] ? v.ab[o] : nullptr), G,
+                                   dt | (v.raw_bf[o] ? FAVAE_RAW_BF16 : 0), st));
         v.grad_fused[o] = bins != nullptr;
         return FAVAE_OK;
     }
@@ -1148,6 +1166,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     // grows with the pixel count) overwrite their slice of the gradient arena in every step, so the optimiser step of an epoch
     // need not zero it (4 of the 32 bytes per weight it moves; encoder.4, decoder.0, decoder.1: 10.6 M of 12.8 M parameters).
     // Executors of the grouped-batch mode (Bmax > 64) keep the zeroing: their tail steps and group steps split differently.
+    for (int l = 0; l < NL; ++l) v.ab_live[l] = false;
     for (int l = 0; l < NL; ++l) {
         const Layer& L = v.L[l];
         v.wg_keeps[l] = false;

@@ -250,6 +250,16 @@ int favae_bn_lrelu_bwd_bins(const void* dact, const void* act, const void* raw, 
                             const float* gamma, const double* bins, int nbins, void* draw, float* dgamma, float* dbeta,
                             float* dbias, long long R, int C, double* scratch, size_t scratch_doubles, int dtype,
                             void* stream);
+/* The pair that does without the stored activation in the backward pass: favae_bn_train_fwd_bins_ab also publishes ab [2 C] = (a | b),
+ * a = invstd * gamma, b = beta - mean * a (act = lrelu(raw * a + b)); favae_bn_lrelu_bwd_bins_ab takes the LeakyReLU slope from the sign
+ * of raw * a + b, the forward pass's own expression, instead of reading act (nn.LeakyReLU backward, cA/celeba_deepvanilla_vae.py:30,
+ * under loss.backward() :249).  Otherwise as favae_bn_train_fwd_bins / favae_bn_lrelu_bwd_bins. */
+int favae_bn_train_fwd_bins_ab(const void* raw, const double* bins, int nbins, const float* gamma, const float* beta, void* act, float* mean,
+                               float* invstd, float* ab, float* run_mean, float* run_var, long long R, int C, float eps, float momentum,
+                               int dtype, void* stream);
+int favae_bn_lrelu_bwd_bins_ab(const void* dact, const void* raw, const float* mean, const float* invstd, const float* gamma, const float* ab,
+                               const double* bins, int nbins, void* draw, float* dgamma, float* dbeta, float* dbias, long long R, int C,
+                               double* scratch, size_t scratch_doubles, int dtype, void* stream);
 /* the two halves of FAVAE_DBIAS_DEFER: the slab count of favae_bn_lrelu_bwd_bins for (R, C) (host arithmetic only), and
  * dbias[c] = sum over the slabs, in slab order, of partial[slab][c]. */
 int favae_bn_lrelu_bwd_slabs(long long R, int C);

@@ -355,6 +355,67 @@ def test_epilogue_sums_feed_batchnorm_backward(dt, tol, kind, Nb, Cin, Cout, H):
     assert_close(draw1.float().cpu(), draw0.float().cpu(), 1e-6 if dt == torch.float32 else 8e-3)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,C,dact_bf", [(64 * 64 * 8, 64, False), (64 * 64 * 8, 64, True), (3000, 128, False)])
+def test_batchnorm_backward_without_the_stored_activation(dt, R, C, dact_bf):
+    """favae_bn_train_fwd_bins_ab publishes (a | b) of the forward pass; favae_bn_lrelu_bwd_bins_ab takes the LeakyReLU slope from the
+    sign of raw * a + b instead of reading the stored activation (final_layer.0 in the batch-64 step).  The published pair is
+    invstd * gamma | beta - mean * a, the activation is lrelu(raw * a + b), and the backward pass gives bit for bit what
+    favae_bn_lrelu_bwd_bins gives from the stored activation (the same expression decides the slope in both passes)."""
+    import ctypes
+    if dact_bf and dt != torch.bfloat16:
+        pytest.skip("bf16 activation gradients belong to the bf16 executor")
+    lib = _lib()
+    rawl = lib.raw()
+    i_, ll_, f_, sz_ = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_size_t
+    g = torch.Generator().manual_seed(R + C)
+    raw = (torch.randn(R, C, generator=g) * 2 + 0.3)
+    raw[::7] *= 1e-4                                     # plenty of values near the kink
+    raw = raw.cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.01).cuda()
+    bins = torch.zeros(8, 2, C, dtype=torch.float64, device="cuda")
+    bins[3, 0] = raw.double().sum(0)
+    bins[5, 1] = (raw.double() ** 2).sum(0)
+    act = torch.empty(R, C, device="cuda", dtype=dt)
+    mean, invstd, ab = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(2 * C, device="cuda")
+    code = lib.dtype_code(act)
+    lib.check(rawl.favae_bn_train_fwd_bins_ab(lib.ptr(raw), lib.ptr(bins), i_(8), lib.ptr(gamma), lib.ptr(beta), lib.ptr(act), lib.ptr(mean),
+                                              lib.ptr(invstd), lib.ptr(ab), lib.ptr(None), lib.ptr(None), ll_(R), i_(C), f_(1e-5), f_(0.1), i_(code),
+                                              lib.stream_ptr()))
+    a_ref = invstd * gamma
+    assert_close(ab[:C].cpu(), a_ref.cpu(), 1e-7)
+    assert_close(ab[C:].cpu(), (beta - mean * a_ref).cpu(), 1e-6)
+    y = F.leaky_relu(raw * ab[:C] + ab[C:], 0.01)
+    assert_close(act.float().cpu(), y.cpu(), 1e-6 if dt == torch.float32 else 8e-3)
+    dact = torch.randn(R, C, generator=g).cuda()
+    if dact_bf:
+        dact = dact.to(torch.bfloat16)
+    gb = torch.zeros(4, 2, C, dtype=torch.float64, device="cuda")
+    dd = dact.double() * torch.where(act.double() > 0, 1.0, 0.01)
+    xh = (raw.double() - mean.double()) * invstd.double()
+    gb[1, 0], gb[2, 1] = dd.sum(0), (dd * xh).sum(0)
+    scratch = torch.zeros(2 * 1024 * 64 + 4096, dtype=torch.float64, device="cuda")
+    flags = code | (lib.DACT_BF16 if dact_bf else 0)
+    out = []
+    for with_ab in (False, True):
+        draw = torch.empty(R, C, device="cuda", dtype=dt)
+        dg, db, dbias = (torch.zeros(C, device="cuda") for _ in range(3))
+        if with_ab:
+            lib.check(rawl.favae_bn_lrelu_bwd_bins_ab(lib.ptr(dact), lib.ptr(raw), lib.ptr(mean), lib.ptr(invstd), lib.ptr(gamma), lib.ptr(ab),
+                                                      lib.ptr(gb), i_(4), lib.ptr(draw), lib.ptr(dg), lib.ptr(db), lib.ptr(dbias), ll_(R), i_(C),
+                                                      lib.ptr(scratch), sz_(scratch.numel()), i_(flags), lib.stream_ptr()))
+        else:
+            lib.check(rawl.favae_bn_lrelu_bwd_bins(lib.ptr(dact), lib.ptr(act), lib.ptr(raw), lib.ptr(mean), lib.ptr(invstd), lib.ptr(gamma),
+                                                   lib.ptr(gb), i_(4), lib.ptr(draw), lib.ptr(dg), lib.ptr(db), lib.ptr(dbias), ll_(R), i_(C),
+                                                   lib.ptr(scratch), sz_(scratch.numel()), i_(flags), lib.stream_ptr()))
+        torch.cuda.synchronize()
+        out.append((draw.cpu(), dg.cpu(), db.cpu(), dbias.cpu()))
+    for u, w in zip(out[0], out[1]):
+        assert torch.equal(u, w)
+    ref = (gamma.double() * invstd.double()) * (dd - dd.sum(0) / R - xh * (dd * xh).sum(0) / R)
+    assert_close(out[1][0].float(), ref.float().cpu(), 1e-5 if dt == torch.float32 else 8e-3)
+
+
 @pytest.mark.parametrize("dt,tol", DT)
 @pytest.mark.parametrize("R,C", [(2048, 64), (16384, 128), (5000, 32), (262144, 64)])
 def test_bias_gradient_finished_by_a_second_launch(dt, tol, R, C):
