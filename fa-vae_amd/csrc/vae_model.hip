@@ -352,6 +352,11 @@ void choose_storage(Vae& v) {
     {
         const char* e = getenv("FAVAE_DACT11_BF16");
         if (v.dtype == FAVAE_BF16 && !(e && e[0] == '0')) v.dact_bf[11] = true;
+        // and, with that in place, the conv outputs of decoder.3 and final_layer.0 (4.2 + 16.8 M elements, read three times each: forward
+        // BatchNorm, backward sums, BatchNorm backward): 0.827 -> 0.820 ms (final_layer.0 alone 0.823); their BatchNorm statistics
+        // still come from the fp32 accumulators.  FAVAE_RAW1011_BF16=0: fp32.
+        const char* e2 = getenv("FAVAE_RAW1011_BF16");
+        if (v.dtype == FAVAE_BF16 && !(e2 && e2[0] == '0')) v.raw_bf[10] = v.raw_bf[11] = true;
     }
     // Grouped-batch mode (bf16 executor with Bmax > 64): at G = 8 the conv outputs and activation gradients of a step are 4 GB, far
     // beyond the 256 MB Infinity Cache, and the step is bound by their HBM traffic (40 B per BatchNorm element and step; final_layer.0

@@ -13,7 +13,8 @@ Rounding points (csrc/vae_model.hip, bf16 executor with exact ends):
   * fc heads: forward from the unrounded encoder.4 activation with fp32 weights, gradients through the bf16 activation / shadow;
   * the gradient w.r.t. final_layer.0's activation (dact of the largest layer): stored as bf16 (its BatchNorm-backward sums are taken
     from the unrounded values in the producing launch; the emulation takes them from the rounded ones);
-  * conv outputs (raw), the other activation gradients (dact), BatchNorm statistics, loss: fp32 (fp64 for the KL and the sums)."""
+  * the conv outputs (raw) of decoder.3 and final_layer.0: stored as bf16, their BatchNorm statistics from the unrounded values;
+  * the other conv outputs (raw) and activation gradients (dact), BatchNorm statistics, loss: fp32 (fp64 for the KL and the sums)."""
 import torch
 import torch.nn.functional as F
 
@@ -54,10 +55,19 @@ def _value_of(exact, through):
     return through + (exact - through).detach()
 
 
-def _bn_act(raw, P, B, pre, store=True):
+def _bn_act(raw, P, B, pre, store=True, raw_bf=False):
     B[pre + ".1.num_batches_tracked"] += 1
-    y = F.batch_norm(raw, B[pre + ".1.running_mean"], B[pre + ".1.running_var"], P[pre + ".1.weight"], P[pre + ".1.bias"], True,
-                     vt.BN_MOM, vt.BN_EPS)
+    if raw_bf:
+        # the conv output is stored as bf16, its statistics come from the unrounded values: normalise the rounded values with the
+        # statistics of the exact ones (affine in the input: y(r) = y(x) + (r - x) * gamma / sqrt(var + eps))
+        y0 = F.batch_norm(raw, B[pre + ".1.running_mean"], B[pre + ".1.running_var"], P[pre + ".1.weight"], P[pre + ".1.bias"], True,
+                          vt.BN_MOM, vt.BN_EPS)
+        var = raw.detach().var(dim=(0, 2, 3), unbiased=False)
+        scale = (P[pre + ".1.weight"].detach() / torch.sqrt(var + vt.BN_EPS)).view(1, -1, 1, 1)
+        y = y0 + ((_r(raw) - raw) * scale).detach()
+    else:
+        y = F.batch_norm(raw, B[pre + ".1.running_mean"], B[pre + ".1.running_var"], P[pre + ".1.weight"], P[pre + ".1.bias"], True,
+                         vt.BN_MOM, vt.BN_EPS)
     y = F.leaky_relu(y, vt.LRELU)
     return (rf(y), y) if store else (y, y)
 
@@ -84,9 +94,9 @@ def loss_terms_bf16(P, B, images, mu_P, tau, var_x, beta, eps):
     for i in range(4):
         pre = "dec.%d" % i
         raw = F.conv_transpose2d(x, rf(P[pre + ".0.weight"]), P[pre + ".0.bias"], stride=2, padding=1, output_padding=1)
-        x, _ = _bn_act(rb(raw), P, B, pre)
+        x, _ = _bn_act(rb(raw), P, B, pre, raw_bf=(i == 3))
     raw = F.conv_transpose2d(x, rf(P["final_layer.0.weight"]), P["final_layer.0.bias"], stride=2, padding=1, output_padding=1)
-    x, _ = _bn_act(rb(raw), P, B, "final_layer")
+    x, _ = _bn_act(rb(raw), P, B, "final_layer", raw_bf=True)
     x = rb(x)   # the gradient w.r.t. final_layer.0's activation (dact[11]) is stored as bf16
     rec = torch.sigmoid(rb(F.conv2d(x, rf(P["final_layer.3.weight"]), P["final_layer.3.bias"], padding=1)))
     std_P = torch.sqrt(torch.ones_like(mu_P) * (1 / tau))
