@@ -25,8 +25,8 @@ template <class T> __device__ __forceinline__ void st4(T* p, float a, float b, f
 template <> __device__ __forceinline__ void st4<float>(float* p, float a, float b, float c, float d) { *(float4*)p = make_float4(a, b, c, d); }
 template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
     uint2 u;
-    u.x = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
-    u.y = (unsigned)f32_to_bf16(c) | ((unsigned)f32_to_bf16(d) << 16);
+    u.x = pack_bf16x2(a, b);
+    u.y = pack_bf16x2(c, d);
     *(uint2*)p = u;
 }
 

@@ -44,11 +44,29 @@ typedef __attribute__((ext_vector_type(4))) double f64x4;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 
-// round-to-nearest-even; NaN stays NaN (quiet)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+// round-to-nearest-even; NaN stays NaN (quiet).  The integer form (7 VALU instructions), kept as the definition the hardware
+// conversion is tested against (favae_debug_bf16_convert)
+__device__ __forceinline__ bf16_t f32_to_bf16_sw(float f) {
     unsigned u = __float_as_uint(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
     return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+#ifdef FAVAE_SW_BF16
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return f32_to_bf16_sw(f); }
+#else
+// gfx950's v_cvt_pk_bf16_f32 (one instruction; the compiler emits it for the conversion to __bf16)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+#endif
+// two values in one 32-bit word (a in the low half): one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+#ifdef FAVAE_SW_BF16
+    return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+#else
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+#endif
 }
 
 template <class T> __device__ __forceinline__ float to_f32(T v);

@@ -177,8 +177,8 @@ template <> __device__ __forceinline__ uint4 bn_act_vec<bf16_t>(const uint4* raw
         float y0 = fmaf(__uint_as_float(raw[h].x), a.x, b.x), y1 = fmaf(__uint_as_float(raw[h].y), a.y, b.y);
         float y2 = fmaf(__uint_as_float(raw[h].z), a.z, b.z), y3 = fmaf(__uint_as_float(raw[h].w), a.w, b.w);
         y0 = y0 > 0.f ? y0 : 0.01f * y0; y1 = y1 > 0.f ? y1 : 0.01f * y1; y2 = y2 > 0.f ? y2 : 0.01f * y2; y3 = y3 > 0.f ? y3 : 0.01f * y3;
-        o[2 * h] = (unsigned)f32_to_bf16(y0) | ((unsigned)f32_to_bf16(y1) << 16);
-        o[2 * h + 1] = (unsigned)f32_to_bf16(y2) | ((unsigned)f32_to_bf16(y3) << 16);
+        o[2 * h] = pack_bf16x2(y0, y1);
+        o[2 * h + 1] = pack_bf16x2(y2, y3);
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
@@ -545,8 +545,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
                 }
                 if (p.out_bf16) {
                     uint2 u;
-                    u.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
-                    u.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+                    u.x = pack_bf16x2(v.x, v.y);
+                    u.y = pack_bf16x2(v.z, v.w);
                     *(uint2*)((bf16_t*)p.out + opix * p.Cout + n) = u;
                 } else {
                     *(float4*)(p.out + opix * p.Cout + n) = v;
@@ -877,8 +877,8 @@ __global__ __launch_bounds__(256) void convt64_fwd_kernel(const Ct64Params p) {
                 char* const g = g_row + ((size_t)rr * 2 * 64 * 64 + (size_t)(16 * (i & 3)) * 64) * (size_t)osz;
                 if (p.out_bf16) {
                     uint2 o;
-                    o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
-                    o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+                    o.x = pack_bf16x2(v.x, v.y);
+                    o.y = pack_bf16x2(v.z, v.w);
                     *(uint2*)g = o;
                 } else {
                     *(float4*)g = v;

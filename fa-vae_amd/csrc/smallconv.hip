@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256) void conv_thin_in(const T* __restrict__ in, co
                 }
                 if (out_bf16) {
                     uint2 u;
-                    u.x = (unsigned)f32_to_bf16(r4.x) | ((unsigned)f32_to_bf16(r4.y) << 16);
-                    u.y = (unsigned)f32_to_bf16(r4.z) | ((unsigned)f32_to_bf16(r4.w) << 16);
+                    u.x = pack_bf16x2(r4.x, r4.y);
+                    u.y = pack_bf16x2(r4.z, r4.w);
                     *(uint2*)((bf16_t*)out + (size_t)(pix_w0 + pr) * CO + hb + c4) = u;
                 } else {
                     *(float4*)(out + (size_t)(pix_w0 + pr) * CO + hb + c4) = r4;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void folded_dgrad_kernel(const bf16_t* __restr
             const int p = p0 + (i & 3) + 8 * (i >> 2) + 4 * h;
             if (p < P) {
                 const size_t e = (goff + p) * 64 + 2 * r;
-                if (OUT_BF) *(unsigned*)((bf16_t*)out_ + e) = (unsigned)f32_to_bf16(c0[i]) | ((unsigned)f32_to_bf16(c1[i]) << 16);
+                if (OUT_BF) *(unsigned*)((bf16_t*)out_ + e) = pack_bf16x2(c0[i], c1[i]);
                 else *(float2*)((float*)out_ + e) = make_float2(c0[i], c1[i]);
                 if (RED) {
                     float a_e = __uint_as_float(pa2[i] << 16), a_o = __uint_as_float(pa2[i] & 0xffff0000u);

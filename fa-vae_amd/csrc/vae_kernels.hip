@@ -228,8 +228,8 @@ template <> struct VecLoad<bf16_t, 4> {
     }
     static __device__ __forceinline__ void st(bf16_t* p, const float* o) {
         uint2 u;
-        u.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
-        u.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+        u.x = pack_bf16x2(o[0], o[1]);
+        u.y = pack_bf16x2(o[2], o[3]);
         *(uint2*)p = u;
     }
 };
@@ -290,8 +290,8 @@ template <> __device__ __forceinline__ void store4<float>(float* p, float a, flo
 }
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
     uint2 u;
-    u.x = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
-    u.y = (unsigned)f32_to_bf16(c) | ((unsigned)f32_to_bf16(d) << 16);
+    u.x = pack_bf16x2(a, b);
+    u.y = pack_bf16x2(c, d);
     *(uint2*)p = u;
 }
 template <class T> __device__ __forceinline__ float4 load4(const T* p);
@@ -2147,6 +2147,21 @@ extern "C" int favae_sigmoid_sse(const float* raw, const float* y, long long n, 
 extern "C" int favae_sigmoid_sse_u8(const float* raw, const unsigned char* y, long long n, double* acc3, double* scratch,
                                     size_t scratch_doubles, void* stream) {
     return sigmoid_sse_impl(raw, y, 1, n, acc3, scratch, scratch_doubles, stream);
+}
+
+__global__ void bf16_convert_kernel(const float* __restrict__ x, bf16_t* __restrict__ hw, bf16_t* __restrict__ sw, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        hw[i] = f32_to_bf16(x[i]);
+        sw[i] = f32_to_bf16_sw(x[i]);
+    }
+}
+/* Test hook: the fp32 -> bf16 conversion every kernel of the library uses (gfx950's conversion instruction) next to the integer
+ * round-to-nearest-even form it replaced. */
+extern "C" int favae_debug_bf16_convert(const float* x, void* hw, void* sw, long long n, void* stream) {
+    FAVAE_CHECK_ARG(x && hw && sw && n > 0, "favae_debug_bf16_convert: bad argument");
+    hipLaunchKernelGGL(bf16_convert_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, ST, x, (bf16_t*)hw, (bf16_t*)sw, (size_t)n);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
 }
 
 extern "C" int favae_sigmoid(const float* raw, float* out, long long n, void* stream) {

@@ -204,6 +204,9 @@ int favae_prof_collect(double* out48);
  * kernels (0 = 64x64, 1 = 128x32) and of the weight-gradient kernels (0..2 = 32x128, 128x32, 64x64); -1 restores the
  * built-in choice.  Process-wide, not thread-safe. */
 int favae_debug_force_tile(int kc_tile, int pm_tile);
+/* Test hook (no counterpart in the reference): n floats through the library's fp32 -> bf16 conversion (hw: gfx950's conversion
+ * instruction, what every kernel uses) and through the integer round-to-nearest-even form (sw). */
+int favae_debug_bf16_convert(const float* x, void* hw, void* sw, long long n, void* stream);
 
 /* ---- conv VAE: HBM-bound kernels ----------------------------------------------------------------------------- */
 

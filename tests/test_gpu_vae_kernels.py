@@ -336,6 +336,30 @@ def test_adam_that_leaves_an_overwritten_gradient_prefix():
     assert min(sk(128, 64, 64 * 256), sk(256, 128, 64 * 64), sk(128, 256, 64 * 64), sk(64, 128, 64 * 256)) > 1
 
 
+def test_bf16_conversion_is_round_to_nearest_even():
+    """The conversion every kernel uses (gfx950's v_cvt_pk_bf16_f32) against the integer round-to-nearest-even form and against
+    torch's: every finite value class (all 65 536 upper halves x ties / just below / just above, subnormals, infinities, signed
+    zeros) bit for bit; NaN stays NaN."""
+    L = _L()
+    raw_ = L.raw()
+    hi = torch.arange(0, 65536, dtype=torch.int64)
+    lows = torch.tensor([0x0000, 0x0001, 0x7fff, 0x8000, 0x8001, 0xffff, 0x1234, 0xfedc], dtype=torch.int64)
+    bits = ((hi[:, None] << 16) | lows[None, :]).reshape(-1)
+    bits = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits).to(torch.int32)
+    x = bits.view(torch.float32).cuda()
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([x, (torch.randn(1 << 20, generator=g) * torch.exp(torch.randn(1 << 20, generator=g) * 20)).cuda()])
+    hw = torch.zeros(x.numel(), dtype=torch.bfloat16, device="cuda")
+    sw = torch.zeros_like(hw)
+    L.check(raw_.favae_debug_bf16_convert(L.ptr(x), L.ptr(hw), L.ptr(sw), ll_(x.numel()), L.stream_ptr()))
+    ref = x.to(torch.bfloat16)
+    finite = torch.isfinite(x) | torch.isinf(x)
+    h, s, r = hw.view(torch.int16), sw.view(torch.int16), ref.view(torch.int16)
+    assert torch.equal(h[finite], s[finite]) and torch.equal(h[finite], r[finite])
+    nan = torch.isnan(x)
+    assert bool(torch.isnan(hw[nan].float()).all()) and bool(torch.isnan(sw[nan].float()).all())
+
+
 @pytest.mark.parametrize("clear", [0, 1])
 def test_adam_with_bf16_copy_of_the_weights(clear):
     """favae_adam_step_copy (encoder.0: 64 x 9 x 3 weights + bias + BN affine) == favae_adam_step(_clear) followed by
