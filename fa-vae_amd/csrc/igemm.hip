@@ -123,6 +123,10 @@ struct KcParams {
     float* out;
     int Nb, Hi, Wi, Cin, Ho, Wo, Cout;
     int ks, stride, pad, ldw, splitk, M, ntn, HoC, WoC;
+    // log2 of HoC * WoC and of WoC where both are powers of two (every layer of this network), else -1: a row index splits into
+    // (image, y, x) with shifts; the integer divisions were ~35 instructions each, 8-16 per thread of a block whose whole
+    // reduction is a few hundred
+    int hw_shift, woc_shift;
     int out_bf16;   // store the result as bf16 (unsplit reductions only)
     // > 0: blocks are dealt to the 8 XCDs round-robin in launch order, so block b of the launch computes tile
     // (b % 8) * xcd_chunk + b / 8: every XCD works on one contiguous run of tiles, and the tiles that share activation rows
@@ -210,6 +214,23 @@ template <bool TR> __device__ __forceinline__ int tap_k(bool s2, int pp, int i) 
 // (LDS write -> barrier -> LDS read -> MFMA runs serially, ~0.5 us per chunk measured); a second group of waves per tile
 // doubles the waves per SIMD without atomics or more tiles.
 // FI: fused input (see KcParams::in_bins): BatchNorm + LeakyReLU of the producing layer applied to the A operand on the fly.
+// row index m of a launch -> image nb, output position (yy, xx) of its (parity-class) grid
+#define KC_SPLIT_M(m_, nb_, yy_, xx_)                                                                              \
+    do {                                                                                                           \
+        if (p.hw_shift >= 0) {                                                                                     \
+            nb_ = (m_) >> p.hw_shift;                                                                              \
+            const int rem_ = (m_) & ((1 << p.hw_shift) - 1);                                                       \
+            yy_ = rem_ >> p.woc_shift;                                                                             \
+            xx_ = rem_ & ((1 << p.woc_shift) - 1);                                                                 \
+        } else {                                                                                                   \
+            const int hw_ = p.HoC * p.WoC;                                                                         \
+            nb_ = (m_) / hw_;                                                                                      \
+            const int rem_ = (m_) - nb_ * hw_;                                                                     \
+            yy_ = rem_ / p.WoC;                                                                                    \
+            xx_ = rem_ - yy_ * p.WoC;                                                                              \
+        }                                                                                                          \
+    } while (0)
+
 template <class T, int BM, int BN, int WM, int WN, bool TR, bool SLOW, int KG = 1, bool FI = false>
 __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
     constexpr int VE = 16 / sizeof(T);
@@ -268,11 +289,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
         const int r = (tid + i * 256) / VPR, m = m0 + r;
         a_ok[i] = m < p.M && (tid + i * 256) < NVA;
         const int mm = a_ok[i] ? m : 0;
-        const int hw = p.HoC * p.WoC;
-        a_n[i] = mm / hw;
-        const int rem = mm - a_n[i] * hw;
-        a_y[i] = rem / p.WoC;
-        a_x[i] = rem - a_y[i] * p.WoC;
+        KC_SPLIT_M(mm, a_n[i], a_y[i], a_x[i]);
     }
     KC_STAMP(30);
     const int vecA = tid % VPR;  // same for every i because 256 % VPR == 0
@@ -311,8 +328,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
     [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_in, rs_w;
     [[maybe_unused]] int ld_t = 0, ld_cc = 0;   // tap / channel chunk of the next load (advanced by KG per load)
     if constexpr (!SLOW) {
-        const int hw = p.HoC * p.WoC;
-        const int img0 = m0 / hw;   // first image of this tile (block-uniform)
+        const int img0 = p.hw_shift >= 0 ? (m0 >> p.hw_shift) : m0 / (p.HoC * p.WoC);   // first image of this tile (block-uniform)
         const size_t img_bytes = (size_t)p.Hi * p.Wi * p.Cin * ESZ_IN;
         rs_in = buf_rsrc((const char*)p.in + (size_t)img0 * img_bytes, (size_t)(p.Nb - img0) * img_bytes);
         rs_w = buf_rsrc(p.w, (size_t)p.Cout * p.ldw * sizeof(T));
@@ -528,8 +544,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
                 if (m >= p.M || n >= p.Cout) continue;
                 size_t opix = (size_t)m;
                 if (TR) {
-                    const int hw = p.HoC * p.WoC;
-                    const int nb = m / hw, rem = m - nb * hw, yy = rem / p.WoC, xx = rem - yy * p.WoC;
+                    int nb, yy, xx;
+                    KC_SPLIT_M(m, nb, yy, xx);
                     opix = ((size_t)nb * p.Ho + (yy * p.stride + py)) * p.Wo + (xx * p.stride + px);
                 }
                 float4 v = *(const float4*)(tile0 + row * TS + c4);
@@ -700,8 +716,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
             if (m >= p.M) continue;
             size_t opix = (size_t)m;
             if (TR) {
-                const int hw = p.HoC * p.WoC;
-                const int nb = m / hw, rem = m - nb * hw, yy = rem / p.WoC, xx = rem - yy * p.WoC;
+                int nb, yy, xx;
+                KC_SPLIT_M(m, nb, yy, xx);
                 opix = ((size_t)nb * p.Ho + (yy * p.stride + py)) * p.Wo + (xx * p.stride + px);
             }
 #pragma unroll
@@ -722,6 +738,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kc(const KcParams p) {
 
 #undef tap_kh
 #undef tap_kw
+#undef KC_SPLIT_M
 
 // ---------------------------------------------------------------------------------------------------------
 // final_layer.0 forward: ConvTranspose2d(64 -> 64, 3x3, stride 2, pad 1, output_padding 1) over 32-pixel-wide rows, bf16
@@ -1466,6 +1483,11 @@ int conv_igemm_impl(const void* in, const void* w, const float* bias, float* out
     if (scatter && stride == 2) { classes = 4; p.HoC = Ho / 2; p.WoC = Wo / 2; }
     else { p.HoC = Ho; p.WoC = Wo; }
     p.M = Nb * p.HoC * p.WoC;
+    p.hw_shift = p.woc_shift = -1;
+    {
+        const int hw = p.HoC * p.WoC;
+        if ((hw & (hw - 1)) == 0 && (p.WoC & (p.WoC - 1)) == 0) { p.hw_shift = __builtin_ctz((unsigned)hw); p.woc_shift = __builtin_ctz((unsigned)p.WoC); }
+    }
     p.ntn = 1;
     p.red_group_rows = red.group_images > 0 ? red.group_images * p.HoC * p.WoC : 0;
     if (p.red_group_rows) FAVAE_CHECK_ARG(p.red_group_rows % 64 == 0 && !fin, "favae_conv_igemm_red_groups: a group must be a multiple of 64 rows");
