@@ -1351,14 +1351,16 @@ template <bool CLEAR_G, bool COPY = false>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t n4, float b1, float b2, float eps,
                                                    float step_size, float bc2_sqrt, bf16_t* __restrict__ copy = nullptr,
-                                                   size_t ncopy4 = 0, float gscale = 1.f, size_t keep4 = 0) {
+                                                   size_t ncopy4 = 0, float gscale = 1.f, size_t keep4 = 0, size_t keepb_lo4 = 0,
+                                                   size_t keepb_hi4 = 0) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         float4 P = ((float4*)p)[i], G = ((const float4*)g)[i], M = ((float4*)m)[i], V = ((float4*)v)[i];
         float* pp = (float*)&P; float* gg = (float*)&G; float* mm = (float*)&M; float* vv = (float*)&V;
 #pragma unroll
         for (int j = 0; j < 4; ++j) adam_update(pp[j], mul_rounded(gg[j], gscale), mm[j], vv[j], b1, b2, eps, step_size, bc2_sqrt);
         ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V;
-        if (CLEAR_G && i >= keep4) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // (keep4: a leading part the next step overwrites)
+        // (keep4: a leading part the next step overwrites; [keepb_lo4, keepb_hi4): a second such range)
+        if (CLEAR_G && i >= keep4 && !(i >= keepb_lo4 && i < keepb_hi4)) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (COPY && i < ncopy4) {   // bf16 shadow of the leading (weight) part of the slice, same layout
             ushort4 c;
             c.x = f32_to_bf16(pp[0]); c.y = f32_to_bf16(pp[1]); c.z = f32_to_bf16(pp[2]); c.w = f32_to_bf16(pp[3]);
@@ -2213,6 +2215,23 @@ extern "C" int favae_adam_step_clear_from(float* p, float* g, float* m, float* v
     ProfScope prof(13, 32.0 * (double)n - 4.0 * (double)keep, ST);
     hipLaunchKernelGGL(adam_kernel<true>, dim3(adam_grid((size_t)n / 4)), dim3(256), 0, ST, p, g, m, v, (size_t)n / 4, beta1, beta2, eps, step_size, bc2_sqrt,
                        (bf16_t*)nullptr, (size_t)0, 1.f, (size_t)keep / 4);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+/* favae_adam_step_clear_scaled that leaves g[keep_lo[k] .. keep_hi[k]) as they are, k = 0, 1 (a bucket of the data-parallel epoch:
+ * the weight-gradient slices that the next step's unsplit GEMMs overwrite; the first range must start at 0, either may be empty). */
+extern "C" int favae_adam_step_clear_scaled_keep(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                                                 float eps, long long step, float gscale, long long keep0_hi, long long keep1_lo,
+                                                 long long keep1_hi, void* stream) {
+    FAVAE_CHECK_ARG(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "favae_adam_step_clear_scaled_keep: bad argument (n must be a multiple of 4)");
+    FAVAE_CHECK_ARG(keep0_hi >= 0 && keep0_hi <= n && keep0_hi % 4 == 0 && keep1_lo >= 0 && keep1_lo <= keep1_hi && keep1_hi <= n && keep1_lo % 4 == 0 &&
+                        keep1_hi % 4 == 0, "favae_adam_step_clear_scaled_keep: ranges (multiples of 4 inside [0, n])");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    ProfScope prof(13, 32.0 * (double)n - 4.0 * (double)(keep0_hi + keep1_hi - keep1_lo), ST);
+    hipLaunchKernelGGL(adam_kernel<true>, dim3(adam_grid((size_t)n / 4)), dim3(256), 0, ST, p, g, m, v, (size_t)n / 4, beta1, beta2, eps, step_size, bc2_sqrt,
+                       (bf16_t*)nullptr, (size_t)0, gscale, (size_t)keep0_hi / 4, (size_t)keep1_lo / 4, (size_t)keep1_hi / 4);
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

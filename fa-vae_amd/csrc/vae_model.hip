@@ -1784,8 +1784,20 @@ extern "C" int favae_vae_train_epoch_dp(favae_vae* h, favae_comm* c, const float
             // pass over the bucket even in a group of one, 5.5 % of the kernel time of the one-rank rehearsal)
             rc = favae_allreduce_f32(c, v.G + bk[b].lo, bk[b].hi - bk[b].lo, 0, (void*)cs);
             if (rc) break;
-            rc = favae_adam_step_clear_scaled(v.P + bk[b].lo, v.G + bk[b].lo, v.M + bk[b].lo, v.V + bk[b].lo, bk[b].hi - bk[b].lo, lr, 0.9f,
-                                              0.999f, 1e-8f, step0 + s + 1, 1.f / (float)favae_comm_size(c), (void*)cs);
+            {
+                // weight slices of this bucket that every step's unsplit weight-gradient GEMM overwrites are not zeroed (see wg_keeps):
+                // the leading one and the largest of the others
+                long long k0 = 0, k1lo = 0, k1hi = 0;
+                if (!(v.fuse & 0x20000000u))
+                    for (int l = bk[b].l0; l <= bk[b].l1; ++l) {
+                        if (!v.wg_keeps[l]) continue;
+                        const long long lo_ = v.L[l].w_off - bk[b].lo, hi_ = v.L[l].b_off - bk[b].lo;
+                        if (lo_ == 0) k0 = hi_;
+                        else if (hi_ - lo_ > k1hi - k1lo) { k1lo = lo_; k1hi = hi_; }
+                    }
+                rc = favae_adam_step_clear_scaled_keep(v.P + bk[b].lo, v.G + bk[b].lo, v.M + bk[b].lo, v.V + bk[b].lo, bk[b].hi - bk[b].lo, lr, 0.9f,
+                                                       0.999f, 1e-8f, step0 + s + 1, 1.f / (float)favae_comm_size(c), k0, k1lo, k1hi, (void*)cs);
+            }
             if (rc) break;
             const float* w[16]; void* wc[16]; void* wt[16]; int Co[16], taps[16], Ci[16];
             int k = 0;

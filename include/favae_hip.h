@@ -357,6 +357,10 @@ int favae_adam_step_clear(float* p, float* g, float* m, float* v, long long n, f
  * of the ranks' gradients and passes 1 / ranks.  No counterpart of its own in the reference (which trains on one device). */
 int favae_adam_step_clear_scaled(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                                  long long step, float gscale, void* stream);
+/* favae_adam_step_clear_scaled that leaves g[0 .. keep0_hi) and g[keep1_lo .. keep1_hi) as they are (a gradient bucket of the data-parallel
+ * epoch: the weight slices that the next step's unsplit weight-gradient GEMMs overwrite).  No counterpart in the reference. */
+int favae_adam_step_clear_scaled_keep(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                                      long long step, float gscale, long long keep0_hi, long long keep1_lo, long long keep1_hi, void* stream);
 /* favae_adam_step_clear that leaves g[0 .. keep) as it is (the training epoch: a weight gradient that the next step's GEMM overwrites
  * whole needs no zeroing; the bias / BatchNorm gradients behind it are accumulated into and do).  No counterpart in the reference. */
 int favae_adam_step_clear_from(float* p, float* g, float* m, float* v, long long n, long long keep, float lr, float beta1, float beta2,

@@ -331,6 +331,15 @@ def test_adam_that_leaves_an_overwritten_gradient_prefix():
     for a, b in ((pa, pb), (ma, mb), (va, vb)):
         assert torch.equal(a, b)
     assert torch.equal(gb[:keep], g0[:keep]) and float(gb[keep:].abs().max()) == 0.0
+    pc, gc, mc, vc = p0.clone(), g0.clone(), m0.clone(), v0.clone()   # two kept ranges, gradient scaled by 1 (the data-parallel bucket form)
+    L.check(raw_.favae_adam_step_clear_scaled_keep(L.ptr(pc), L.ptr(gc), L.ptr(mc), L.ptr(vc), ll_(n), f_(1e-3), f_(0.9), f_(0.999), f_(1e-8),
+                                                   ll_(3), f_(1.0), ll_(1024), ll_(2048), ll_(3072), L.stream_ptr()))
+    for a, b in ((pa, pc), (ma, mc), (va, vc)):
+        assert torch.equal(a, b)
+    kept = torch.zeros(n, dtype=torch.bool, device="cuda")
+    kept[:1024] = True
+    kept[2048:3072] = True
+    assert torch.equal(gc[kept], g0[kept]) and float(gc[~kept].abs().max()) == 0.0
     sk = lambda co, ci, k: raw_.favae_conv_wgrad_auto_splitk(i_(co), i_(ci), ll_(k), i_(3))
     assert [sk(1024, 512, 64 * 4), sk(512, 1024, 64 * 4), sk(256, 512, 64 * 16), sk(512, 256, 64 * 16)] == [1, 1, 1, 1]
     assert min(sk(128, 64, 64 * 256), sk(256, 128, 64 * 64), sk(128, 256, 64 * 64), sk(64, 128, 64 * 256)) > 1
