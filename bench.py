@@ -135,7 +135,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra (untimed) iteration that splits VAE and FA time")
-    ap.add_argument("--groups", type=int, default=8, help="BatchNorm groups per step of the grouped-batch figure in secondary.grouped (0: skip)")
+    ap.add_argument("--groups", type=str, default="8,16", help="BatchNorm groups per step of the grouped-batch figures: the first of the list goes to "
+                    "secondary.grouped, every one to secondary.grouped_sweep (0: skip)")
     a = ap.parse_args()
 
     if os.environ.get("FAVAE_HANG_DUMP"):                # debugging aid: dump all Python stacks after N seconds and exit
@@ -259,38 +260,43 @@ def main():
     # secondary.grouped: the labelled grouped-batch mode of the VAE step (G BatchNorm groups of 64 per optimiser step, the step of a
     # G-rank data-parallel run on one GPU; NOT the reference's trajectory, never `value`): two epochs over the same resident images
     # through a second executor, the second one timed
-    grouped = None
-    if not a.no_secondary and a.groups > 1 and ws == 1:
+    grouped, grouped_sweep = None, []
+    group_list = [int(x) for x in str(a.groups).split(",") if x.strip() and int(x) > 1]
+    if not a.no_secondary and group_list and ws == 1:
         from favae_hip.engine import VaeEngine
         vae = model.img_vae[0]
         data = vae._resident(vae._source())
-        ge = VaeEngine(a.latent, 3, batch_max=64 * a.groups, dtype=a.dtype)
-        ge.load_state_dict({k: v.detach().cpu() for k, v in vae.state_dict().items()})
-        gb = 64 * a.groups
-        nst = ge.epoch_steps(a.n, gb)
-        gm = torch.zeros(nst, 2, dtype=torch.float64, device="cuda")
-        gprior = torch.zeros(a.n, a.latent, dtype=torch.float64, device="cuda")
-        gt = None
-        for _ in range(2):
-            perm = torch.randperm(a.n).to(torch.int32).cuda()
-            eps = torch.randn(a.n, a.latent).cuda()
-            torch.cuda.synchronize()
-            ts = time.time()
-            ge.train_epoch(data, perm, eps, gprior, 1.0, 1.0, 0.01, 1e-5, gb, gm)
-            torch.cuda.synchronize()
-            gt = time.time() - ts
-        ge.poll_error()
         peak_g = 2500.0 if a.dtype == "bf16" else 157.3
         gflop_img = 2.0 * (3 * (197_591_040 + 12_288 * a.latent) - 1_769_472) / 1e9
-        grouped = {"config": {"groups": a.groups, "batch": gb, "bn_group": 64, "steps_per_epoch": nst},
+        for groups in group_list:
+            ge = VaeEngine(a.latent, 3, batch_max=64 * groups, dtype=a.dtype)
+            ge.load_state_dict({k: v.detach().cpu() for k, v in vae.state_dict().items()})
+            gb = 64 * groups
+            nst = ge.epoch_steps(a.n, gb)
+            gm = torch.zeros(nst, 2, dtype=torch.float64, device="cuda")
+            gprior = torch.zeros(a.n, a.latent, dtype=torch.float64, device="cuda")
+            gt = None
+            for _ in range(2):
+                perm = torch.randperm(a.n).to(torch.int32).cuda()
+                eps = torch.randn(a.n, a.latent).cuda()
+                torch.cuda.synchronize()
+                ts = time.time()
+                ge.train_epoch(data, perm, eps, gprior, 1.0, 1.0, 0.01, 1e-5, gb, gm)
+                torch.cuda.synchronize()
+                gt = time.time() - ts
+            ge.poll_error()
+            rec = {"config": {"groups": groups, "batch": gb, "bn_group": 64, "steps_per_epoch": nst},
                    "samples_per_s": a.n / gt, "ms_per_step": 1e3 * gt / nst, "gflop_per_step": gflop_img * gb,
                    "tflops": gflop_img * a.n / gt / 1e3, "mfma_frac": gflop_img * a.n / gt / 1e3 / peak_g,
-                   "loss_last_step": float(gm[-1].sum().item()),
-                   "note": "one timed epoch of favae_vae_train_epoch at batch 64 x groups (BatchNorm statistics per group of 64, mean loss over "
-                           "the batch, one Adam step per batch: the step of a `groups`-rank data-parallel run); same flop convention as `step`; "
-                           "compare with secondary.vae_trainloop_samples_per_s (batch 64)"}
-        del ge, gm, gprior
-        torch.cuda.empty_cache()
+                   "loss_last_step": float(gm[-1].sum().item())}
+            grouped_sweep.append(rec)
+            if grouped is None:
+                grouped = dict(rec)
+                grouped["note"] = ("one timed epoch of favae_vae_train_epoch at batch 64 x groups (BatchNorm statistics per group of 64, mean loss over "
+                                   "the batch, one Adam step per batch: the step of a `groups`-rank data-parallel run); same flop convention as `step`; "
+                                   "compare with secondary.vae_trainloop_samples_per_s (batch 64)")
+            del ge, gm, gprior
+            torch.cuda.empty_cache()
 
     if rank == 0:
         n_global = n_total
@@ -354,6 +360,7 @@ def main():
         if secondary is not None:
             if grouped is not None:
                 secondary["grouped"] = grouped
+                secondary["grouped_sweep"] = grouped_sweep
             out["secondary"] = secondary
         if ws == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.n, a.latent, a.kc)

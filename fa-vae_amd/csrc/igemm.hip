@@ -958,6 +958,36 @@ struct PmParams {
     float ad_b1, ad_b2, ad_eps, ad_step, ad_bc2s;
 };
 
+// The small reduction a weight-gradient launch carries for the step (SlabRider, common.h): 8 channels x 32 slab parts per block, the
+// parts added in LDS in a fixed order.  `lds`: 2 KB of the block's LDS, free again on return; `lin`: the block's linear index.
+__device__ __forceinline__ void pm_rider(const SlabRider& rider, char* lds, int tid, unsigned lin) {
+    if (!rider.partial) return;                  // uniform
+    if (lin * 8 >= (unsigned)rider.C) return;    // block-uniform
+    double* rs = (double*)lds;                   // [32][8]
+    const int ch = tid & 7, part = tid >> 3, c = (int)lin * 8 + ch;
+    double t = 0.0;
+    if (c < rider.C) {
+        for (int k0 = part; k0 < rider.nslab; k0 += 32 * 8) {   // 8 independent loads in flight
+            double x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int k = k0 + 32 * q; x[q] = k < rider.nslab ? rider.partial[(size_t)k * rider.C + c] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += x[q];
+        }
+    }
+    rs[part * 8 + ch] = t;
+    __syncthreads();
+    if (tid < 8 && c < rider.C) {
+        double u = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) u += rs[k * 8 + tid];
+        if (!rider.out0) rider.out[c] = (float)u;
+        else if (c == 0) *rider.out0 = rider.off0 + rider.scale0 * u;
+        else if (c - 1 < rider.nout) rider.out[c - 1] = (float)u;
+    }
+    __syncthreads();   // (the caller reuses the LDS)
+}
+
 // LEAN: both channel counts fill 16-byte vectors and both operands are below 2 GB.  The operands come through buffer
 // descriptors: the small-grid operand's descriptor is moved to the chunk (scalar arithmetic), so its per-lane offset is a
 // constant and the tail of the reduction falls off the end of the descriptor; the gathered operand's offset is rebuilt per chunk
@@ -981,34 +1011,7 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
 
     carry_store(p.carry);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (p.rider.partial) {   // uniform: 8 channels x 32 slab parts per block, the parts added in LDS in a fixed order
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if (lin * 8 < (unsigned)p.rider.C) {   // block-uniform
-            double* rs = (double*)lds;          // [32][8]
-            const int ch = tid & 7, part = tid >> 3, c = (int)lin * 8 + ch;
-            double t = 0.0;
-            if (c < p.rider.C) {
-                for (int k0 = part; k0 < p.rider.nslab; k0 += 32 * 8) {   // 8 independent loads in flight
-                    double x[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { const int k = k0 + 32 * q; x[q] = k < p.rider.nslab ? p.rider.partial[(size_t)k * p.rider.C + c] : 0.0; }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) t += x[q];
-                }
-            }
-            rs[part * 8 + ch] = t;
-            __syncthreads();
-            if (tid < 8 && c < p.rider.C) {
-                double u = 0.0;
-#pragma unroll 8
-                for (int k = 0; k < 32; ++k) u += rs[k * 8 + tid];
-                if (!p.rider.out0) p.rider.out[c] = (float)u;
-                else if (c == 0) *p.rider.out0 = p.rider.off0 + p.rider.scale0 * u;
-                else if (c - 1 < p.rider.nout) p.rider.out[c - 1] = (float)u;
-            }
-            __syncthreads();   // (the stages below reuse the LDS)
-        }
-    }
+    pm_rider(p.rider, lds, tid, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
     const int wm = wave / WN, wn = wave % WN;
     // Blocks are dealt to the 8 XCDs round-robin in launch order.  With xcd_units > 0 block b takes work unit
     // (b % 8) * xcd_units + b / 8, and the units are ordered tap-fastest: the nine taps of one (tile, slice) read the same pixels of
@@ -1249,6 +1252,227 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// weight gradient of a stride-2 3x3 layer, all nine taps from ONE pass over the operands (bf16, channel tiles of 64 x 64)
+// ---------------------------------------------------------------------------------------------------------
+// igemm_pm gives every tap a block of its own: nine blocks read the same 64 small-grid pixels and, shifted, the same large-grid
+// pixels: 16 KB from L2 per 64-pixel chunk and tap for 4 MFMAs per wave (32 FLOP per byte).  Beyond batch 64 the operands no longer
+// stay in the caches between the taps and the launch runs at the rate of those re-reads (final_layer.0 at 512 images: 1.2 GB
+// fetched for 335 MB of operands, 116 TFLOP/s).  Here a block keeps nine accumulator tiles (144 registers per lane) and reads a
+// chunk once: the 64 small-grid pixels (rows iy0 .. iy0 + NR - 1 of one image, NR = 64 / Ws) and the patch of the large grid they
+// meet, rows 2 iy0 - 1 .. 2 (iy0 + NR - 1) + 1, columns -1 .. 2 Ws - 1: 36 MFMAs per wave and chunk on 48 KB.
+// Patch image in LDS: per large-grid row two planes (even / odd columns: tap kx walks ONE plane at unit stride), a plane =
+// Ws + 2 slots of 128 bytes (64 channels), slot s = (x >> 1) + 1; odd-plane slot 0 is column -1 (zeros, written once).  The two
+// 64-byte halves of a slot are swapped where bit 1 of s is set, which puts the four consecutive slots one ds_read_b64_tr_b16
+// half-wave touches on the four quarters of the 256-byte bank row (same reasoning as pm_swz).
+template <int LW>
+struct W9 {
+    static constexpr int WS = 1 << LW, NR = 64 >> LW, NPR = 2 * NR + 1, WL = 2 * WS, PS = WS + 2;
+    static constexpr int PLANE = PS * 128, PATCH = NPR * 2 * PLANE, SBYTES = 64 * 128, STAGE = SBYTES + PATCH;
+    static constexpr int NVL = NPR * WL * 8, VL = (NVL + 255) / 256;
+};
+
+template <int LW, bool R_LARGE>
+__global__ __launch_bounds__(256) void wgrad9_kernel(const PmParams p) {
+    using G = W9<LW>;
+    using T = bf16_t;
+    extern __shared__ __attribute__((aligned(16))) char lds9[];
+    carry_store(p.carry);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+    pm_rider(p.rider, lds9, tid, lin);
+    // column -1 of every patch row, both stages
+    for (int i = tid; i < 2 * G::NPR * 8; i += 256) {
+        const int st = i / (G::NPR * 8), pr = (i >> 3) % G::NPR, v = i & 7;
+        *(uint4*)(lds9 + st * G::STAGE + G::SBYTES + (pr * 2 + 1) * G::PLANE + v * 16) = make_uint4(0, 0, 0, 0);
+    }
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_units) {   // the tiles of one slice of the reduction read the same pixels: one XCD, one L2 (see igemm_pm)
+        const unsigned w = (lin & 7u) * (unsigned)p.xcd_units + (lin >> 3);
+        bx = w % gridDim.x;
+        by = w / gridDim.x;
+    }
+    const int r0 = (int)(bx / p.ntn) * 64, c0 = (int)(bx % p.ntn) * 64;
+    const int nchunk = p.K >> 6;
+    const int per = (nchunk + p.splitk - 1) / p.splitk;
+    const int c_begin = (int)by * per, c_end = min(nchunk, c_begin + per);
+    if (c_begin >= c_end) return;
+
+    const void* sp = R_LARGE ? p.cp : p.rp;
+    const void* lp = R_LARGE ? p.rp : p.cp;
+    const int Cs = R_LARGE ? p.Cc : p.Rc, Cl = R_LARGE ? p.Rc : p.Cc;
+    const int s0 = R_LARGE ? c0 : r0, l0 = R_LARGE ? r0 : c0;
+    const unsigned row_bytes = (unsigned)(p.Wl * Cl) * 2u;
+    const __amdgpu_buffer_rsrc_t rl = buf_rsrc(lp, (size_t)p.Nb * p.Hl * p.Wl * Cl * sizeof(T));
+
+    // per-thread constants of the loads and of their places in LDS
+    unsigned s_off[2], l_off[G::VL];
+    int s_lds[2], l_lds[G::VL];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int v = tid + i * 256, prow = v >> 3, cv = v & 7;
+        s_off[i] = (unsigned)((prow * Cs + s0 + cv * 8) * 2);
+        s_lds[i] = pm_off<T>(prow, cv, 128);
+    }
+    unsigned pr0_mask = 0;   // bit j: vector j lies in patch row 0 (large-grid row 2 iy0 - 1)
+#pragma unroll
+    for (int j = 0; j < G::VL; ++j) {
+        const int v = tid + j * 256;
+        const int pr = v >> (LW + 4), x = (v >> 3) & (G::WL - 1), cv = v & 7, s = (x >> 1) + 1;
+        const bool in = G::NVL % 256 == 0 || v < G::NVL;
+        if (pr == 0) pr0_mask |= 1u << j;
+        // offset from the start of large-grid row 2 iy0 (patch row 1); patch row 0 is addressed from one row earlier
+        l_off[j] = in ? (unsigned)(((max(pr, 1) - 1) * p.Wl + x) * Cl + l0 + cv * 8) * 2u : BUF_OOB;
+        l_lds[j] = G::SBYTES + (pr * 2 + (x & 1)) * G::PLANE + s * 128 + ((((cv >> 2) ^ ((s >> 1) & 1)) << 2) | (cv & 3)) * 16;
+    }
+    // two chunks in flight in registers (a chunk is 48 KB per block: with one, the loads of chunk c + 1 had the ~1 us of chunk c's
+    // MFMAs to arrive and the loop waited on them: 3.3 us per chunk at 512 images)
+    uint4 vs[2][2], vl[2][G::VL];
+    auto load = [&](int chunk, uint4 (&ws)[2], uint4 (&wl)[G::VL]) __attribute__((always_inline)) {
+        const int pix0 = chunk << 6;
+        const __amdgpu_buffer_rsrc_t rs = buf_rsrc((const char*)sp + (size_t)pix0 * Cs * sizeof(T), (size_t)(p.K - pix0) * Cs * sizeof(T));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ws[i] = buf_ld16(rs, s_off[i], 0u);
+        const int n = pix0 >> p.hw_shift, iy0 = (pix0 & ((1 << p.hw_shift) - 1)) >> LW;
+        const unsigned base1 = (unsigned)((n * p.Hl + 2 * iy0) * p.Wl * Cl) * 2u;       // row 2 iy0
+        const unsigned base0 = iy0 ? base1 - row_bytes : BUF_OOB;                       // row 2 iy0 - 1: above the image for iy0 = 0
+#pragma unroll
+        for (int j = 0; j < G::VL; ++j) wl[j] = buf_ld16(rl, buf_off_add(l_off[j], ((pr0_mask >> j) & 1u) ? base0 : base1), 0u);
+    };
+
+    // fragment addresses (the same for every chunk): lane (r, h) of k-step kk needs small-grid pixels k = 16 kk + 8 h + q + {0, 4},
+    // q = (lane & 15) >> 2; pixel k = (ry, ix) meets patch row 2 ry + ky, plane (kx != 1), slot ix + (kx != 0)
+    const int q = (lane & 15) >> 2;
+    const int lane_part = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+    const int lt = R_LARGE ? wm : wn;       // 32-channel half of the large-grid operand's tile this wave works on
+    int fbase[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int k = kk * 16 + 8 * (lane >> 5) + q, ry = k >> LW, ix = k & (G::WS - 1);
+        fbase[kk] = G::SBYTES + (4 * ry) * G::PLANE + ix * 128 + lane_part;
+    }
+    const int swz0 = ((lt ^ ((q >> 1) & 1)) * 64), swz1 = ((lt ^ (((q + 1) >> 1) & 1)) * 64);   // slot ix (ix = q mod 4) / slot ix + 1
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    load(c_begin, vs[0], vl[0]);
+    if (c_begin + 1 < c_end) load(c_begin + 1, vs[1], vl[1]);
+    for (int c = c_begin; c < c_end; c += 2) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int cc = c + d;
+            if (cc < c_end) {   // block-uniform
+                // (two stages: a wave writes stage d again only after the barrier of the iteration in between)
+                char* stage = lds9 + d * G::STAGE;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) *(uint4*)(stage + s_lds[i]) = vs[d][i];
+#pragma unroll
+                for (int j = 0; j < G::VL; ++j)
+                    if (G::NVL % 256 == 0 || tid + j * 256 < G::NVL) *(uint4*)(stage + l_lds[j]) = vl[d][j];
+                __syncthreads();
+                if (cc + 2 < c_end) load(cc + 2, vs[d], vl[d]);
+                // (requesting the ten fragments of k-step kk + 1 before the nine MFMAs of k-step kk, behind scheduling barriers, changed
+                // nothing: the loop runs at the rate the operands arrive; what is left of a launch is the atomic epilogue)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    Frag<T> fs;
+                    frag_pm(fs, stage, 128, kk * 16, (R_LARGE ? wn : wm) * 32, lane);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int ky = t / 3, kx = t % 3;
+                        const char* a = stage + fbase[kk] + (2 * ky + (kx != 1 ? 1 : 0)) * G::PLANE + (kx != 0 ? 128 : 0) + (kx != 0 ? swz1 : swz0);
+                        union { s16x4 s[2]; bf16x8 b; } u;
+                        u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+                        u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 512));
+                        Frag<T> fl;
+                        fl.v = u.b;
+                        if (R_LARGE) mma32(acc[t], fl, fs); else mma32(acc[t], fs, fl);
+                    }
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = r0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = c0 + wn * 32 + (lane & 31);
+            float* dst = p.dw + ((size_t)row * 9 + t) * p.Cst + col;
+            if (p.splitk > 1) atomicAdd(dst, acc[t][r]); else if (p.overwrite) *dst = acc[t][r]; else *dst += acc[t][r];
+        }
+}
+
+// blocks of a wgrad9 launch: ~target over the tiles, every block at least `minch` chunks
+inline int w9_splitk(int tiles, int nchunk, int target, int minch) {
+    return std::max(1, std::min(std::max(1, (target + tiles / 2) / tiles), std::max(1, nchunk / minch)));
+}
+
+thread_local int g_pm_adam_applied = 0;   // did the last weight-gradient launch of this thread take the optimiser step in its epilogue?
+
+// wgrad9_kernel where it applies and pays, else *taken = 0 and nothing is launched.  `old_sk`: igemm_pm's split of this reduction;
+// `caller_splitk`: the splitk argument of the call (0 / -1: the library chooses).
+// FAVAE_WG9: 0 never, 1 (default) launches over at least FAVAE_WG9_MINNB (128) images -- at batch 64 the operands stay cached between
+// the taps and nine times the atomic volume costs more than the re-reads (measured per layer, tools/bench_gemm.py) --, 2 wherever the
+// shape allows.
+int launch_w9(PmParams p, int old_sk, int caller_splitk, int* taken, hipStream_t st) {
+    *taken = 0;
+    static const int mode = getenv("FAVAE_WG9") ? atoi(getenv("FAVAE_WG9")) : 1;
+    static const int target = getenv("FAVAE_WG9_TARGET") ? atoi(getenv("FAVAE_WG9_TARGET")) : 256;
+    static const int minch = getenv("FAVAE_WG9_MINCH") ? atoi(getenv("FAVAE_WG9_MINCH")) : 8;
+    static const int minnb = getenv("FAVAE_WG9_MINNB") ? atoi(getenv("FAVAE_WG9_MINNB")) : 128;
+    const bool shape_ok = p.ks == 3 && p.stride == 2 && p.pad == 1 && (p.r_large != 0) != (p.c_large != 0) && p.Rc % 64 == 0 && p.Cc % 64 == 0 &&
+                          p.Rst == p.Rc && p.Cst == p.Cc && p.Hs == p.Ws && (p.Ws == 8 || p.Ws == 16 || p.Ws == 32) && p.Hl == 2 * p.Hs &&
+                          p.Wl == 2 * p.Ws && (size_t)p.Nb * p.Hl * p.Wl * (size_t)std::max(p.Rc, p.Cc) * 2 < (size_t)0x7FFFFFF0;
+    const bool forced = g_force_pm_tile == 9;   // favae_debug_force_tile: wherever the shape allows
+    if (!((mode || forced) && (g_force_pm_tile < 0 || forced) && shape_ok && old_sk > 1 && (caller_splitk == 0 || caller_splitk == -1) &&
+          (mode == 2 || forced || p.Nb >= minnb)))
+        return FAVAE_OK;
+    const int tiles = (p.Rc / 64) * (p.Cc / 64), nchunk = p.K / 64;
+    p.ntn = p.Cc / 64;
+    p.splitk = w9_splitk(tiles, nchunk, target, minch);
+    const unsigned total = (unsigned)tiles * (unsigned)p.splitk;
+    if (p.rider.partial && !p.rider.out0 && (unsigned)cdiv(p.rider.C, 8) > total) {   // too few blocks to carry it: a launch of its own
+        const int rc = favae_bn_dbias_finish(p.rider.partial, p.rider.nslab, p.rider.C, p.rider.out, st);
+        if (rc != FAVAE_OK) return rc;
+        p.rider.partial = nullptr;
+    }
+    p.xcd_units = (tiles > 1 && total % 8 == 0 && total >= 64) ? (int)(total / 8) : 0;
+    p.hw_shift = __builtin_ctz((unsigned)(p.Hs * p.Ws));
+    p.ws_shift = __builtin_ctz((unsigned)p.Ws);
+    p.ad_p = nullptr;
+    g_pm_adam_applied = 0;
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    FAVAE_HIP(hipGetDevice(&dev));
+    FAVAE_CHECK_ARG(dev >= 0 && dev < 64, "favae_conv_wgrad: device index %d", dev);
+    if (!attr_set[dev]) {
+        FAVAE_HIP(hipFuncSetAttribute((const void*)wgrad9_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W9<5>::STAGE));
+        FAVAE_HIP(hipFuncSetAttribute((const void*)wgrad9_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W9<5>::STAGE));
+        FAVAE_HIP(hipFuncSetAttribute((const void*)wgrad9_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W9<4>::STAGE));
+        FAVAE_HIP(hipFuncSetAttribute((const void*)wgrad9_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W9<4>::STAGE));
+        FAVAE_HIP(hipFuncSetAttribute((const void*)wgrad9_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W9<3>::STAGE));
+        FAVAE_HIP(hipFuncSetAttribute((const void*)wgrad9_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W9<3>::STAGE));
+        attr_set[dev] = true;
+    }
+    ProfScope prof(5, 2.0 * p.Rc * (double)p.Cc * p.K * 9, st);
+    const dim3 grid(tiles, p.splitk);
+#define W9_LAUNCH(LW_)                                                                                                 \
+    do {                                                                                                               \
+        if (p.r_large) hipLaunchKernelGGL((wgrad9_kernel<LW_, true>), grid, dim3(256), 2 * W9<LW_>::STAGE, st, p);     \
+        else hipLaunchKernelGGL((wgrad9_kernel<LW_, false>), grid, dim3(256), 2 * W9<LW_>::STAGE, st, p);              \
+    } while (0)
+    if (p.Ws == 32) W9_LAUNCH(5); else if (p.Ws == 16) W9_LAUNCH(4); else W9_LAUNCH(3);
+#undef W9_LAUNCH
+    FAVAE_LAUNCH_CHECK();
+    *taken = 1;
+    return FAVAE_OK;
+}
+
 template <class T, bool TR, bool SLOW, int BM, int BN, int WM, int WN, int KG = 1, bool FI = false>
 int launch_kc(KcParams p, int classes, hipStream_t st) {
     dim3 grid(cdiv(p.M, BM) * p.ntn, p.splitk, classes);
@@ -1333,8 +1557,6 @@ int pm_auto_splitk(int Rc, int Cc, long long K, int ks, int tile) {
     return std::max(1, std::min(std::min(std::max(1, nchunk / 8), std::max(1, (pm_target + blocks / 2) / blocks)), nchunk));
 }
 
-thread_local int g_pm_adam_applied = 0;   // did the last weight-gradient launch of this thread take the optimiser step in its epilogue?
-
 template <class T>
 int dispatch_pm(PmParams p, hipStream_t st) {
     p.carry = favae_take_flag_carry();
@@ -1347,9 +1569,15 @@ int dispatch_pm(PmParams p, hipStream_t st) {
     p.ntn = cdiv(p.Cc, BN);
     const int nchunk = cdiv(p.K, BK);
     const int blocks = cdiv(p.Rc, BM) * p.ntn * p.ks * p.ks;
+    const int orig_splitk = p.splitk;
     p.overwrite = p.splitk < 0;
     int sk = p.splitk > 0 ? p.splitk : p.splitk < -1 ? -p.splitk   // < -1: that many slices of a gradient the caller zeroed
                                      : pm_auto_splitk(p.Rc, p.Cc, p.K, p.ks, tile);
+    if constexpr (sizeof(T) == 2) {   // all nine taps from one pass over the operands, where that pays
+        int taken = 0;
+        const int rc = launch_w9(p, std::max(1, std::min(sk, nchunk)), orig_splitk, &taken, st);
+        if (rc != FAVAE_OK || taken) return rc;
+    }
     p.splitk = std::max(1, std::min(sk, nchunk));
     dim3 grid(cdiv(p.Rc, BM) * p.ntn, p.splitk, p.ks * p.ks);
     if (p.rider.partial && !p.rider.out0 && (long long)cdiv(p.rider.C, 8) > (long long)grid.x * grid.y * grid.z) {   // too few blocks to carry it: a launch of its own

@@ -201,8 +201,9 @@ int favae_conv_folded_dgrad(const void* fold, const void* w, void* out, long lon
 int favae_prof_enable(int enabled, int stride);
 int favae_prof_collect(double* out48);
 /* Developer hook for tile tuning (tools/tune_gemm.py; no reference counterpart): force the tile of the gather-form
- * kernels (0 = 64x64, 1 = 128x32) and of the weight-gradient kernels (0..2 = 32x128, 128x32, 64x64); -1 restores the
- * built-in choice.  Process-wide, not thread-safe. */
+ * kernels (0 = 64x64, 1 = 128x32) and of the weight-gradient kernels (0..2 = 32x128, 128x32, 64x64; 9 = the all-taps kernel
+ * wherever its shape conditions hold, whatever the size of the reduction); -1 restores the built-in choice.  Process-wide, not
+ * thread-safe. */
 int favae_debug_force_tile(int kc_tile, int pm_tile);
 /* Test hook (no counterpart in the reference): n floats through the library's fp32 -> bf16 conversion (hw: gfx950's conversion
  * instruction, what every kernel uses) and through the integer round-to-nearest-even form (sw). */

@@ -167,6 +167,47 @@ def test_convT_s2_weight_gradient(dt, tol, Nb, Cin, Cout, H):
     assert_close(dw.cpu(), ref, tol)
 
 
+@pytest.mark.parametrize("kind,Nb,Cin,Cout,H", [("convT", 8, 64, 64, 32), ("convT", 5, 64, 64, 32), ("convT", 8, 128, 64, 16), ("convT", 16, 256, 128, 8),
+                                                ("conv", 8, 64, 128, 32), ("conv", 16, 128, 256, 16), ("conv", 3, 64, 64, 64)])
+def test_weight_gradient_with_all_nine_taps_in_one_block(kind, Nb, Cin, Cout, H):
+    """wgrad9_kernel (one pass over the operands for the nine taps of a stride-2 layer, csrc/igemm.hip), forced through
+    favae_debug_force_tile(-1, 9), against autograd of the layer (celeba_deepvanilla_vae.py:31-35, 55-60, 69-75 with loss.backward() :249)
+    on the same bf16-rounded operands, and against igemm_pm on the same call (same products, another order of the fp32 sums).
+    H: input height of the layer; the small grid of the gradient is H / 2 (conv) or H (transposed) and must be 8, 16 or 32 wide."""
+    import ctypes
+    lib = _lib()
+    dt, tol = torch.bfloat16, 1e-4
+    g = torch.Generator().manual_seed(91 + Cin + Nb)
+    x = q(torch.randn(Nb, Cin, H, H, generator=g), dt)
+    if kind == "conv":
+        w = torch.randn(Cout, Cin, 3, 3, generator=g, requires_grad=True)
+        dy = q(torch.randn(Nb, Cout, H // 2, H // 2, generator=g), dt)
+        F.conv2d(x, w, None, stride=2, padding=1).backward(dy)
+        ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, 9, Cin)
+        args = (nhwc(dy).to(dt).cuda(), 0, nhwc(x).to(dt).cuda(), 1)
+        geo = (Nb, H // 2, H // 2, H, H, 3, 2, 1)
+    else:
+        w = torch.randn(Cin, Cout, 3, 3, generator=g, requires_grad=True)
+        dy = q(torch.randn(Nb, Cout, 2 * H, 2 * H, generator=g), dt)
+        F.conv_transpose2d(x, w, None, stride=2, padding=1, output_padding=1).backward(dy)
+        ref = w.grad.permute(1, 2, 3, 0).reshape(Cout, 9, Cin)
+        args = (nhwc(dy).to(dt).cuda(), 1, nhwc(x).to(dt).cuda(), 0)
+        geo = (Nb, H, H, 2 * H, 2 * H, 3, 2, 1)
+    raw_ = lib.raw()
+    out = {}
+    try:
+        for name, force in (("pm", 2), ("w9", 9)):
+            lib.check(raw_.favae_debug_force_tile(ctypes.c_int(-1), ctypes.c_int(force)))
+            dw = torch.full((Cout, 9, Cin), 0.5, device="cuda")       # splitk 0: the gradient is ADDED to what dw holds
+            lib.conv_wgrad(*args, dw, *geo, 0)
+            out[name] = dw.cpu() - 0.5
+    finally:
+        lib.check(raw_.favae_debug_force_tile(ctypes.c_int(-1), ctypes.c_int(-1)))
+    assert_close(out["w9"], ref, tol)
+    scale = float(ref.abs().max())
+    assert float((out["w9"] - out["pm"]).abs().max()) <= 2e-5 * scale + 1e-6     # fp32 sums of the same products in another order (+ the 0.5 offset's rounding)
+
+
 @pytest.mark.parametrize("dt,tol", DT)
 def test_final_conv_and_linear_weight_gradient(dt, tol):
     lib = _lib()

@@ -4,7 +4,10 @@ sys.path.insert(0, '/root/repo/fa-vae_amd')
 import torch
 from favae_hip import lib
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == 'bf16') else torch.float32
-B = 64
+import os, ctypes
+B = int(os.environ.get('B', '64'))       # images per launch
+if os.environ.get('FORCE_PM'):          # favae_debug_force_tile for the weight gradients (2: igemm_pm 64x64, 9: all-taps kernel)
+    lib.raw().favae_debug_force_tile(ctypes.c_int(-1), ctypes.c_int(int(os.environ['FORCE_PM'])))
 dev = 'cuda'
 def t(*s, d=dt): return torch.randn(*s, device=dev).to(d)
 def timeit(fn, reps=30):
@@ -16,7 +19,6 @@ def timeit(fn, reps=30):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
 rows = []
-import os
 SPLITK = int(os.environ.get('SPLITK', '0'))    # 0: the library's choice, 1: unsplit reductions
 ONLY = os.environ.get('ONLY')       # run only the layers whose name contains this (for rocprofv3 --pmc passes)
 def conv(name, Cin, Cout, Hi, Ho, ks, stride, scatter, taps_eff):
