@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void gbn_fwd_kernel(const RT* __restrict__ raw
         }
     }
     __syncthreads();
+    if (!act) return;   // uniform: the statistics only (a consumer applies a, b itself)
     const size_t nvec = (size_t)Rg * C / 4, base = (size_t)g * Rg * C;
     const int c = (tid * 4) % C;
     const float a0 = ab[c], a1 = ab[c + 1], a2 = ab[c + 2], a3 = ab[c + 3];
@@ -237,15 +238,16 @@ extern "C" int favae_gbn_sums(const void* y, const void* act, const void* raw, c
 
 /* BatchNorm2d(train) + LeakyReLU forward of G groups from bins [G][nbins][2][C]: act (dtype) and mean / invstd [G][C]; the running
  * statistics take the average over the groups of the batch statistics (what averaging the ranks' running statistics gives in
- * the data-parallel run).  C <= 1024, a multiple of 4 that divides 1024.  raw fp32, or bf16 with FAVAE_RAW_BF16. */
+ * the data-parallel run).  C <= 1024, a multiple of 4 that divides 1024.  raw fp32, or bf16 with FAVAE_RAW_BF16.  act == NULL (with ab): the
+ * statistics only, for a consumer that applies (a | b) at its operand load (favae_conv_out_ll_bn). */
 extern "C" int favae_gbn_fwd(const void* raw, const double* bins, int nbins, const float* gamma, const float* beta, void* act, float* mean,
                              float* invstd, float* ab, float* run_mean, float* run_var, int G, long long Rg, int C, float eps, float momentum,
                              int dtype, void* stream) {
-    FAVAE_CHECK_ARG(raw && bins && gamma && beta && act && mean && invstd && nbins >= 1 && G >= 1 && Rg >= 1 && Rg < (1LL << 30), "favae_gbn_fwd: bad argument");
+    FAVAE_CHECK_ARG(raw && bins && gamma && beta && (act || ab) && mean && invstd && nbins >= 1 && G >= 1 && Rg >= 1 && Rg < (1LL << 30), "favae_gbn_fwd: bad argument");
     FAVAE_CHECK_ARG(C >= 4 && C <= 1024 && 1024 % C == 0, "favae_gbn_fwd: C = %d must divide 1024", C);
     FAVAE_CHECK_ARG(GB_BASE(dtype) == FAVAE_F32 || GB_BASE(dtype) == FAVAE_BF16, "favae_gbn_fwd: dtype");
     FAVAE_CHECK_ARG(!(GB_RAWBF(dtype) && GB_BASE(dtype) != FAVAE_BF16), "favae_gbn_fwd: FAVAE_RAW_BF16 needs FAVAE_BF16");
-    dim3 grid(gbn_grid(Rg, C), G);
+    dim3 grid(act ? gbn_grid(Rg, C) : 1, G);   // act == NULL: mean / invstd / ab / running statistics only
 #define GF_LAUNCH(T, RT) hipLaunchKernelGGL((gbn_fwd_kernel<T, RT>), grid, dim3(256), 0, ST, (const RT*)raw, bins, nbins, gamma, beta, (T*)act, mean, invstd, ab, (int)Rg, C, eps)
     if (GB_BASE(dtype) == FAVAE_F32) GF_LAUNCH(float, float);
     else if (GB_RAWBF(dtype)) GF_LAUNCH(bf16_t, bf16_t);

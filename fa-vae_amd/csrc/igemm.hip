@@ -956,6 +956,11 @@ struct PmParams {
     float *ad_p, *ad_m, *ad_v;
     void *ad_wc, *ad_wt;
     float ad_b1, ad_b2, ad_eps, ad_step, ad_bc2s;
+    // CAB instantiation (bf16, lean, 32x128 tiles, neither operand gathered, K a multiple of 64): the column operand is the conv output in
+    // front of a BatchNorm(train) + LeakyReLU and the activation lrelu(x * a + b), rounded to bf16 as the BatchNorm kernels store it, is
+    // formed when a chunk goes to LDS.  c_ab [groups][2][Cc] = (a | b) per BatchNorm group of c_ab_group_pix reduction elements (0: one group).
+    const float* c_ab = nullptr;
+    int c_ab_group_pix = 0;
 };
 
 // The small reduction a weight-gradient launch carries for the step (SlabRider, common.h): 8 channels x 32 slab parts per block, the
@@ -994,8 +999,9 @@ __device__ __forceinline__ void pm_rider(const SlabRider& rider, char* lds, int 
 // from shifts (power-of-two feature maps) and halo pixels get an out-of-range offset.  Out-of-range loads return zeros: no
 // select per vector.  (The general form below spent ~100 instructions per vector on two integer divisions, clamps and 64-bit
 // products, against two MFMAs per chunk and wave: issue-bound, like igemm_kc before its addressing was hoisted.)
-template <class T, int BM, int BN, int WM, int WN, bool LEAN, bool ADAM = false>
+template <class T, int BM, int BN, int WM, int WN, bool LEAN, bool ADAM = false, bool CAB = false>
 __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
+    static_assert(!CAB || (LEAN && sizeof(T) == 2 && 256 % (BN / 8) == 0), "operand-load BatchNorm: bf16, lean loads, a fixed channel piece per thread");
     constexpr int VE = 16 / sizeof(T);
     constexpr int PADB = sizeof(T) == 2 ? 0 : 16;   // bf16: swizzled rows without padding (frag_pm); fp32: 16 bytes of padding
     constexpr int RSR = BM * sizeof(T) + PADB, RSC = BN * sizeof(T) + PADB;
@@ -1153,6 +1159,15 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    [[maybe_unused]] float cab_a[8], cab_b[8];
+    [[maybe_unused]] int cab_g = -1;
+    [[maybe_unused]] const int cab_ch = c0 + (tid % VPR_C) * VE;          // (256 % VPR_C == 0: the same piece for every vector of the thread)
+    [[maybe_unused]] const bool cab_live = cab_ch < p.Cc;
+    if constexpr (CAB) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { cab_a[j] = 0.f; cab_b[j] = 0.f; }
+    }
+
     uint4 vr[D][VR], vc[D][VC];
     unsigned vm[D];
 #pragma unroll
@@ -1166,6 +1181,17 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
             if (cc < c_end) {   // block-uniform
                 char* ldsR = lds + buf * STAGE;
                 char* ldsC = ldsR + BK * RSR;
+                if constexpr (CAB) {   // (a, b) of this thread's 8 channels for the BatchNorm group of chunk cc (chunks never straddle groups)
+                    const int g = p.c_ab_group_pix > 0 ? (cc * BK) / p.c_ab_group_pix : 0;
+                    if (g != cab_g) {   // block-uniform
+                        cab_g = g;
+                        if (cab_live) {
+                            const float* ab = p.c_ab + (size_t)g * 2 * p.Cc + cab_ch;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { cab_a[j] = ab[j]; cab_b[j] = ab[p.Cc + j]; }
+                        }
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < VR; ++i) {
                     const int v = tid + i * 256;
@@ -1174,7 +1200,24 @@ __global__ __launch_bounds__(256) void igemm_pm(const PmParams p) {
 #pragma unroll
                 for (int i = 0; i < VC; ++i) {
                     const int v = tid + i * 256;
-                    if (NVC % 256 == 0 || v < NVC) *(uint4*)(ldsC + pm_off<T>(v / VPR_C, v % VPR_C, RSC)) = LEAN ? vc[d][i] : keep_if((vm[d] >> (16 + i)) & 1u, vc[d][i]);
+                    if constexpr (CAB) {
+                        uint4 t = vc[d][i];
+                        if (cab_live) {   // (padding channels beyond Cc stay zero)
+                            unsigned w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                float y0 = __uint_as_float(w4[k] << 16) * cab_a[2 * k] + cab_b[2 * k];
+                                float y1 = __uint_as_float(w4[k] & 0xffff0000u) * cab_a[2 * k + 1] + cab_b[2 * k + 1];
+                                y0 = y0 > 0.f ? y0 : 0.01f * y0;
+                                y1 = y1 > 0.f ? y1 : 0.01f * y1;
+                                w4[k] = pack_bf16x2(y0, y1);
+                            }
+                            t = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                        }
+                        if (NVC % 256 == 0 || v < NVC) *(uint4*)(ldsC + pm_off<T>(v / VPR_C, v % VPR_C, RSC)) = t;
+                    } else {
+                        if (NVC % 256 == 0 || v < NVC) *(uint4*)(ldsC + pm_off<T>(v / VPR_C, v % VPR_C, RSC)) = LEAN ? vc[d][i] : keep_if((vm[d] >> (16 + i)) & 1u, vc[d][i]);
+                    }
                 }
                 __syncthreads();
                 if (cc + D < c_end) vm[d] = load_any(cc + D, vr[d], vc[d]);
@@ -1422,7 +1465,10 @@ thread_local int g_pm_adam_applied = 0;   // did the last weight-gradient launch
 int launch_w9(PmParams p, int old_sk, int caller_splitk, int* taken, hipStream_t st) {
     *taken = 0;
     static const int mode = getenv("FAVAE_WG9") ? atoi(getenv("FAVAE_WG9")) : 1;
-    static const int target = getenv("FAVAE_WG9_TARGET") ? atoi(getenv("FAVAE_WG9_TARGET")) : 256;
+    // ~96 blocks: a block holds 101 KB of LDS and 4 x 340 registers per lane, so a CU that runs one has little room for the blocks of
+    // the main chain's kernels; with one on every CU the BatchNorm passes of the grouped step ran 4-7x slower than alone.  Same-box sweep
+    // at 8 groups: 256 blocks 3.045 ms per step, 192 2.978, 128 2.896, 96 2.870, 64 3.012, 32 3.445 (the weight gradients become the chain).
+    static const int target = getenv("FAVAE_WG9_TARGET") ? atoi(getenv("FAVAE_WG9_TARGET")) : 96;
     static const int minch = getenv("FAVAE_WG9_MINCH") ? atoi(getenv("FAVAE_WG9_MINCH")) : 8;
     static const int minnb = getenv("FAVAE_WG9_MINNB") ? atoi(getenv("FAVAE_WG9_MINNB")) : 128;
     const bool shape_ok = p.ks == 3 && p.stride == 2 && p.pad == 1 && (p.r_large != 0) != (p.c_large != 0) && p.Rc % 64 == 0 && p.Cc % 64 == 0 &&
@@ -1609,6 +1655,15 @@ int dispatch_pm(PmParams p, hipStream_t st) {
     if (p.ad_p) {
         g_pm_adam_applied = 1;
         hipLaunchKernelGGL((igemm_pm<T, 64, 64, 2, 2, true, true>), grid, dim3(256), 0, st, p);
+    }
+    else if (p.c_ab) {
+        if constexpr (sizeof(T) == 2) {
+            FAVAE_CHECK_ARG(tile == 0 && lean && !p.r_large && !p.c_large && p.K % BK == 0 && (p.c_ab_group_pix == 0 || p.c_ab_group_pix % BK == 0),
+                            "weight gradient with the BatchNorm of its column operand at the load: 32-row tile, lean loads, K and the group size multiples of 64");
+            hipLaunchKernelGGL((igemm_pm<T, 32, 128, 1, 4, true, false, true>), grid, dim3(256), 0, st, p);
+        } else {
+            FAVAE_CHECK_ARG(false, "weight gradient with the BatchNorm of its column operand at the load: bf16 only");
+        }
     }
     else if (tile == 0) PM_LAUNCH(32, 128, 1, 4);
     else if (tile == 1) PM_LAUNCH(128, 32, 4, 1);
@@ -1944,6 +1999,26 @@ extern "C" int favae_conv_wgrad_prefolded(const void* rows, int Rc, int Rst, con
     p.Nb = 1; p.Hs = 1; p.Ws = (int)K; p.Hl = 1; p.Wl = (int)K; p.ks = 1; p.stride = 1; p.pad = 0; p.splitk = splitk; p.ntn = 1; p.K = (int)K;
     p.ad_p = nullptr;
     return dtype == FAVAE_F32 ? dispatch_pm<float>(p, (hipStream_t)stream) : dispatch_pm<bf16_t>(p, (hipStream_t)stream);
+}
+
+/* favae_conv_wgrad_prefolded whose column operand is the conv output cols_raw [K][Cc] (bf16) in front of a BatchNorm2d(train) + LeakyReLU
+ * (final_layer.1/.2 in front of final_layer.3, celeba_deepvanilla_vae.py:72-76): the activation lrelu(x * a + b), rounded to bf16, is formed at
+ * the operand load from ab [groups][2][Cc] (a | b per BatchNorm group of group_rows rows of cols_raw; 0: one group).  bf16, Rc <= 32, K and
+ * group_rows multiples of 64. */
+extern "C" int favae_conv_wgrad_prefolded_bn(const void* rows, int Rc, int Rst, const void* cols_raw, int Cc, int Cst, const float* ab,
+                                             long long group_rows, float* dw, long long K, int splitk, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(rows && cols_raw && dw && ab, "favae_conv_wgrad_prefolded_bn: null pointer");
+    FAVAE_CHECK_ARG(K > 0 && K < (1ll << 31) && Rc > 0 && Rc <= 32 && Cc > 0 && Rst >= 1 && Rst <= Rc && Cst >= 1 && Cst <= Cc, "favae_conv_wgrad_prefolded_bn: bad shape");
+    FAVAE_CHECK_ARG(dtype == FAVAE_BF16 && Rc % 8 == 0 && Cc % 8 == 0, "favae_conv_wgrad_prefolded_bn: bf16, channel counts that fill 16-byte vectors");
+    FAVAE_CHECK_ARG(K % 64 == 0 && group_rows >= 0 && group_rows % 64 == 0 && group_rows < (1ll << 31), "favae_conv_wgrad_prefolded_bn: K and group_rows multiples of 64");
+    FAVAE_CHECK_ARG(((uintptr_t)rows % 16) == 0 && ((uintptr_t)cols_raw % 16) == 0, "favae_conv_wgrad_prefolded_bn: 16-byte alignment");
+    FAVAE_CHECK_ARG(g_force_pm_tile < 0 || g_force_pm_tile == 0, "favae_conv_wgrad_prefolded_bn: the developer tile override excludes this form");
+    PmParams p;
+    p.rp = rows; p.cp = cols_raw; p.dw = dw; p.Rc = Rc; p.Cc = Cc; p.Rst = Rst; p.Cst = Cst; p.r_large = 0; p.c_large = 0;
+    p.Nb = 1; p.Hs = 1; p.Ws = (int)K; p.Hl = 1; p.Wl = (int)K; p.ks = 1; p.stride = 1; p.pad = 0; p.splitk = splitk; p.ntn = 1; p.K = (int)K;
+    p.ad_p = nullptr;
+    p.c_ab = ab; p.c_ab_group_pix = (int)group_rows;
+    return dispatch_pm<bf16_t>(p, (hipStream_t)stream);
 }
 
 extern "C" int favae_conv_wgrad_folded(const void* rows, int Rc, const void* cols, int Cc, float* dw, int Nb, int Hs, int Ws,

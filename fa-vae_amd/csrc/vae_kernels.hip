@@ -1233,12 +1233,16 @@ __global__ __launch_bounds__(256) void conv_out_ll(const T* __restrict__ act, co
 // the 66-pixel input segment of a kernel row is loaded once, coalesced (whole 128-B lines, 1 KB per instruction instead of
 // 64 separate lines), parked in LDS, and read back per lane for the three horizontal taps.  Rows outside the image are
 // skipped as a whole, columns outside are zero in LDS.
-template <int CO>
+// AB: `act` holds the conv output in front of the layer's BatchNorm (bf16) and the activation lrelu(raw * a + b), rounded to bf16 as the
+// BatchNorm kernels store it, is formed when a segment is loaded; in_ab [groups][2][64] = (a | b) per BatchNorm group of group_images
+// images (0: one group).  The activation tensor is then never written: at 512 images that pass was 106 us and 536 MB per step.
+template <int CO, bool AB = false>
 __global__ __launch_bounds__(256) void conv_out_ll_rows(const bf16_t* __restrict__ act, const bf16_t* __restrict__ wk,
                                                         const float* __restrict__ bias, const float* __restrict__ x, int H, int W,
                                                         int total, float inv_var_B, float* __restrict__ raw, bf16_t* __restrict__ draw,
                                                         double* __restrict__ partial, unsigned* __restrict__ ticket, double D,
-                                                        double var_x, double B, double* __restrict__ rec_err, float* __restrict__ dbias) {
+                                                        double var_x, double B, double* __restrict__ rec_err, float* __restrict__ dbias,
+                                                        const float* __restrict__ in_ab = nullptr, int group_images = 0) {
     constexpr int SEG = 66, RV = 9;                    // pixels per segment, uint4 per LDS pixel row (8 data + 1 pad)
     constexpr int NQ = (SEG * 8 + 63) / 64;            // coalesced 16-B loads per lane and segment
     __shared__ __attribute__((aligned(16))) bf16_t wl[9 * 16 * 4 * 4];
@@ -1252,6 +1256,12 @@ __global__ __launch_bounds__(256) void conv_out_ll_rows(const bf16_t* __restrict
     const bool live = blockIdx.x * 256 + wave * 64 < total;
     const int n = pw0 / (H * W), rem = pw0 - n * H * W, y = rem / W, x0 = rem - y * W;
     uint4* rb = rowbuf[wave];
+    [[maybe_unused]] float fa[8], fb[8];   // AB: (a, b) of this lane's 8 channels (part = lane & 7 for every load of the lane)
+    if constexpr (AB) {
+        const float* g_ab = in_ab + (size_t)(group_images > 0 ? n / group_images : 0) * 128 + (lane & 7) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { fa[j] = g_ab[j]; fb[j] = g_ab[64 + j]; }
+    }
     auto load_seg = [&](int kh, uint4 (&v)[NQ]) -> bool {
         const int iy = y - 1 + kh;
         if (iy < 0 || iy >= H) return false;           // wave-uniform
@@ -1260,7 +1270,17 @@ __global__ __launch_bounds__(256) void conv_out_ll_rows(const bf16_t* __restrict
         for (int q = 0; q < NQ; ++q) {
             const int e = lane + 64 * q, px = e >> 3, part = e & 7, gx = x0 - 1 + px;
             const bool ok = e < SEG * 8 && gx >= 0 && gx < W;
-            const uint4 t = src[(size_t)min(max(gx, 0), W - 1) * 8 + part];
+            uint4 t = src[(size_t)min(max(gx, 0), W - 1) * 8 + part];
+            if constexpr (AB) {
+                unsigned w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float y0 = lrelu(__uint_as_float(w4[k] << 16) * fa[2 * k] + fb[2 * k]);
+                    const float y1 = lrelu(__uint_as_float(w4[k] & 0xffff0000u) * fa[2 * k + 1] + fb[2 * k + 1]);
+                    w4[k] = pack_bf16x2(y0, y1);
+                }
+                t = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
             v[q] = make_uint4(ok ? t.x : 0u, ok ? t.y : 0u, ok ? t.z : 0u, ok ? t.w : 0u);
         }
         return true;
@@ -1751,15 +1771,15 @@ extern "C" int favae_bn_train_fwd_keep32_ok(long long R, int C) { return owner_a
 static int bn_train_fwd_bins_impl(const void* raw, const double* bins, int nbins, const float* gamma, const float* beta,
                                        void* act, float* mean, float* invstd, float* run_mean, float* run_var, long long R,
                                        int C, float eps, float momentum, int dtype, float* ab_out, void* stream) {
-    FAVAE_CHECK_ARG(raw && bins && gamma && beta && act && mean && invstd && R > 0 && R < (1LL << 31) && nbins >= 1,
+    FAVAE_CHECK_ARG(raw && bins && gamma && beta && (act || ab_out) && mean && invstd && R > 0 && R < (1LL << 31) && nbins >= 1,
                     "favae_bn_train_fwd_bins: bad argument");
     FAVAE_CHECK_ARG(bins_applicable(C), "favae_bn_train_fwd_bins: C = %d not supported (64, 128, 256 ...)", C);
     FAVAE_CHECK_ARG(DT_BASE(dtype) == FAVAE_F32 || DT_BASE(dtype) == FAVAE_BF16, "favae_bn_train_fwd_bins: dtype");
     FAVAE_CHECK_ARG(!(RAW_IS_BF16(dtype) && DT_BASE(dtype) != FAVAE_BF16), "favae_bn_train_fwd_bins: FAVAE_RAW_BF16 needs FAVAE_BF16");
-    const size_t nvec = (size_t)R * C / 4;
+    const size_t nvec = act ? (size_t)R * C / 4 : 0;   // act == NULL: the statistics only (one block)
     int c4 = C / 4, gg = c4, t = 256;
     while (t) { const int r = gg % t; gg = t; t = r; }
-    const int mult = c4 / gg;
+    const int mult = act ? c4 / gg : 1;
     static const int grid_cap = getenv("FAVAE_BNF_GRID") ? atoi(getenv("FAVAE_BNF_GRID")) : 1024;   // every block sums the bins itself: fewer, longer blocks (2048 -> 1024: -0.7 % step time)
     long long grid = (long long)std::min<size_t>(grid_cap, (nvec + 255) / 256);
     grid = std::max<long long>(mult, grid / mult * mult);
@@ -2108,6 +2128,37 @@ extern "C" int favae_conv_out_ll(const void* act, const void* wk, const float* b
     }
 #undef CO_ROWS
 #undef CO_LAUNCH
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+/* favae_conv_out_ll whose input is the conv output `raw_in` [Nb][H][W][64] (bf16) in front of final_layer.1/.2 (BatchNorm2d(train) + LeakyReLU,
+ * celeba_deepvanilla_vae.py:72-73): the activation lrelu(raw_in * a + b), rounded to bf16, is formed at the operand load from ab
+ * [groups][2][64] (a | b per BatchNorm group of group_images images; 0: one group), so the activation tensor need not exist.  bf16, W a multiple of 64. */
+extern "C" int favae_conv_out_ll_bn(const void* raw_in, const float* ab, int group_images, const void* wk, const float* bias, const float* x, int Nb,
+                                    int H, int W, int Cout, float var_x, float* raw, void* draw, double* rec_err, float* dbias, double* scratch,
+                                    size_t scratch_doubles, int dtype, void* stream) {
+    FAVAE_CHECK_ARG(raw_in && ab && wk && x && raw && draw && rec_err && scratch && Nb > 0 && H > 0 && W > 0 && var_x > 0 && group_images >= 0,
+                    "favae_conv_out_ll_bn: bad argument");
+    FAVAE_CHECK_ARG(Cout >= 1 && Cout <= 4, "favae_conv_out_ll_bn: 1..4 output channels");
+    FAVAE_CHECK_ARG((dtype & ~FAVAE_DBIAS_DEFER) == FAVAE_BF16 && W % 64 == 0, "favae_conv_out_ll_bn: bf16, image width a multiple of 64");
+    FAVAE_CHECK_ARG(((uintptr_t)raw_in % 16) == 0 && ((uintptr_t)wk % 16) == 0 && ((uintptr_t)ab % 16) == 0 && (size_t)Nb * H * W < (1u << 31),
+                    "favae_conv_out_ll_bn: alignment / size");
+    const int total = Nb * H * W, grid = cdiv(total, 256);
+    FAVAE_CHECK_ARG((size_t)grid * 5 <= scratch_doubles, "favae_conv_out_ll_bn: scratch too small (%zu < %zu doubles)", scratch_doubles, (size_t)grid * 5);
+    unsigned* ticket = nullptr;
+    const bool defer = (dtype & FAVAE_DBIAS_DEFER) != 0;
+    if (!defer) {
+        int trc = ticket_base(1, &ticket);
+        if (trc) return trc;
+    }
+    const float ivb = 1.f / (var_x * (float)Nb);
+    const double D = (double)H * W * Cout;
+#define CO_ROWS(CO_)                                                                                                                        \
+    hipLaunchKernelGGL((conv_out_ll_rows<CO_, true>), dim3(grid), dim3(256), 0, ST, (const bf16_t*)raw_in, (const bf16_t*)wk, bias, x, H, W, total, \
+                       ivb, raw, (bf16_t*)draw, scratch, ticket, D, (double)var_x, (double)Nb, rec_err, dbias, ab, group_images)
+    switch (Cout) { case 1: CO_ROWS(1); break; case 2: CO_ROWS(2); break; case 3: CO_ROWS(3); break; default: CO_ROWS(4); }
+#undef CO_ROWS
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;
 }

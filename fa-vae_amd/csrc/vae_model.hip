@@ -187,6 +187,10 @@ struct Vae {
     bool join_pending; bool dg_all;
     bool ab_live[NL];    // this step's forward pass published (a | b) of the layer's BatchNorm: the backward pass takes the LeakyReLU slope from raw * a + b
     bool wg_keeps[NL];   // the weight gradient of the layer is stored whole by every step of this executor (unsplit GEMM): no zeroing
+    // final_layer.0's activation is not materialised by the training step: final_layer.3's forward (favae_conv_out_ll_bn) and weight gradient
+    // (favae_conv_wgrad_prefolded_bn) apply the BatchNorm + LeakyReLU to raw[11] at their operand loads, the backward pass takes the slope
+    // from raw * a + b.  act11_skip_ok: this step may do so (set before the decoder's forward pass); act11_raw: it did.
+    bool act11_skip_ok, act11_raw;
     bool dp_epoch;   // steps of favae_vae_train_epoch_dp: gradients cleared by the bucket-wise Adam, joins through the communication stream
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
     bool rk_done;   // stage 6 of this step already ran the reparameterisation backward (fused launch)
@@ -638,10 +642,13 @@ int bn_fwd(Vae& v, int l, int B, bool train, void* st) {
     const Layer& L = v.L[l];
     const long long R = v.rows(l, B);
     const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0);
+    if (l == 11) v.act11_raw = false;
     if (train && B > 64 && v.stats_fused[l]) {   // grouped-batch mode
         v.stats_fused[l] = false;
-        return favae_gbn_fwd(v.raw[l], v.sbins[l], bins_for(v.rows(l, 64)), v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l], v.invstd[l],
-                             v.ab[l], v.BUF + L.rm_off, v.BUF + L.rv_off, B / 64, v.rows(l, 64), L.Cout, 1e-5f, 0.1f, dt, st);
+        const bool skip = l == 11 && v.act11_skip_ok && v.ab[l] && v.raw_bf[l];
+        if (skip) v.act11_raw = true;
+        return favae_gbn_fwd(v.raw[l], v.sbins[l], bins_for(v.rows(l, 64)), v.P + L.g_off, v.P + L.be_off, skip ? nullptr : v.act[l], v.mean[l],
+                             v.invstd[l], v.ab[l], v.BUF + L.rm_off, v.BUF + L.rv_off, B / 64, v.rows(l, 64), L.Cout, 1e-5f, 0.1f, dt, st);
     }
     if (train && v.bn_published[l]) {   // the producing GEMM finished the statistics (mean, invstd, running stats, a | b)
         v.bn_published[l] = v.stats_fused[l] = false;
@@ -656,8 +663,10 @@ int bn_fwd(Vae& v, int l, int B, bool train, void* st) {
         // group) measured slower again: 0.824 with this layer alone, 0.825 with decoder.3 and encoder.0, 0.829 with all.
         if (l == 11 && v.dtype == FAVAE_BF16 && !(v.fuse & 0x10000000u)) {
             v.ab_live[l] = true;
-            return favae_bn_train_fwd_bins_ab(v.raw[l], v.sbins[l], bins_for(R), v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l], v.invstd[l],
-                                              v.ab[l], v.BUF + L.rm_off, v.BUF + L.rv_off, R, L.Cout, 1e-5f, 0.1f, dt, st);
+            const bool skip = v.act11_skip_ok && v.raw_bf[l];
+            if (skip) v.act11_raw = true;
+            return favae_bn_train_fwd_bins_ab(v.raw[l], v.sbins[l], bins_for(R), v.P + L.g_off, v.P + L.be_off, skip ? nullptr : v.act[l], v.mean[l],
+                                              v.invstd[l], v.ab[l], v.BUF + L.rm_off, v.BUF + L.rv_off, R, L.Cout, 1e-5f, 0.1f, dt, st);
         }
         return favae_bn_train_fwd_bins(v.raw[l], v.sbins[l], bins_for(R), v.P + L.g_off, v.P + L.be_off, v.act[l], v.mean[l],
                                        v.invstd[l], v.BUF + L.rm_off, v.BUF + L.rv_off, R, L.Cout, 1e-5f, 0.1f, dt, st);
@@ -999,6 +1008,9 @@ int wgrad_launch(Vae& v, int l, const void* in, int B, void* st) {
         // (256 slices of the 65536-pixel reduction, the automatic choice: 64 to 1024 measured the same or slower)
         return favae_conv_wgrad_prefolded(v.draw[0], L.Cout, L.Cout, v.fold0, 32, 9 * L.Cin, dw, (long long)B * L.Hout * L.Hout, -1, v.dtype, st);
     }
+    if (l == L_OUT && v.out_folded && v.act11_raw)   // `in` (final_layer.0's activation) does not exist this step: its BatchNorm + LeakyReLU at the load
+        return favae_conv_wgrad_prefolded_bn(v.fold, 32, 9 * L.Cout, v.raw[11], L.Cin, L.Cin, B > 64 ? v.gab(11) : v.ab[11],
+                                             B > 64 ? (long long)64 * L.Hout * L.Hout : 0, dw, (long long)B * L.Hout * L.Hout, -1, v.dtype, st);
     if (l == L_OUT && v.out_folded)   // the output gradient was folded on the caller's stream (train_stages, stage 0): its input gradient reads it too
         return favae_conv_wgrad_prefolded(v.fold, 32, 9 * L.Cout, in, L.Cin, L.Cin, dw, (long long)B * L.Hout * L.Hout, -1, v.dtype, st);
     if ((v.fuse & 64u) && v.ch <= 3 && (l == 0 || l == L_OUT))   // image-sized channel count on one side: one GEMM over folded taps
@@ -1172,6 +1184,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     // need not zero it (4 of the 32 bytes per weight it moves; encoder.4, decoder.0, decoder.1: 10.6 M of 12.8 M parameters).
     // Executors of the grouped-batch mode (Bmax > 64) keep the zeroing: their tail steps and group steps split differently.
     for (int l = 0; l < NL; ++l) v.ab_live[l] = false;
+    v.act11_skip_ok = v.act11_raw = false;
     for (int l = 0; l < NL; ++l) {
         const Layer& L = v.L[l];
         v.wg_keeps[l] = false;
@@ -1370,7 +1383,12 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
         else
             RC(favae_reparam_kl_fwd(v.raw[L_FC], eps, prior, idx, tau, B, v.z, v.zlat, v.stdq, metrics2_out + 1, v.dtype, st));
         const bool out_ll = (v.fuse & 0x100u) != 0;
+        // (FAVAE_ACT11=1: final_layer.0's activation is written and read back, as before; the batch-64 BatchNorm backward without the sums
+        // from the input-gradient launch, FAVAE_FUSE_MASK bit 4 off, reads the activation)
+        static const bool act11_keep = getenv("FAVAE_ACT11") && atoi(getenv("FAVAE_ACT11")) == 1;
+        v.act11_skip_ok = !act11_keep && out_ll && v.dtype == FAVAE_BF16 && !(v.fuse & 0x10000000u) && (B > 64 || ((v.fuse & 4u) && gbins64(v, 11))) && (v.fuse & 64u) && v.ch <= 3 && !(v.fuse & 0x8000000u) && v.L[11].Cout == 64;
         RC(decoder_fwd(v, B, true, st, true, out_ll, decin));
+        v.act11_skip_ok = false;
         const long long D = (long long)64 * 64 * v.ch;
         if (out_ll) {   // final conv + sigmoid + log-likelihood + gradient + bias gradient in one launch
             // epochs: the loss term and the bias gradient are needed by nobody on the main chain; their sums over the launch's
@@ -1378,6 +1396,11 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             // (FAVAE_FUSE_MASK bit 0x4000000: inside this launch, as before)
             const bool defer = epoch && v.overlap && (v.fuse & 64u) && v.ch <= 3 && !(v.fuse & 0x4000000u);
             if (defer) { v.ll_B = B; v.ll_var = var_x; v.ll_out = metrics2_out; }
+            if (v.act11_raw)
+                RC(favae_conv_out_ll_bn(v.raw[11], B > 64 ? v.gab(11) : v.ab[11], B > 64 ? 64 : 0, v.wk_out, v.P + v.L[L_OUT].b_off, v.xf, B, 64, 64, v.ch,
+                                        var_x, v.raw[L_OUT], v.draw[L_OUT], metrics2_out, v.G + v.L[L_OUT].b_off, defer ? v.llp : v.scratch,
+                                        defer ? (size_t)((B * 64 * 64 + 255) / 256) * 5 : v.scratch_doubles, v.dtype | (defer ? FAVAE_DBIAS_DEFER : 0), st));
+            else
             RC(favae_conv_out_ll(v.act[11], v.wk_out, v.P + v.L[L_OUT].b_off, v.xf, B, 64, 64, v.ch, var_x, v.raw[L_OUT], v.draw[L_OUT],
                                  metrics2_out, v.G + v.L[L_OUT].b_off, defer ? v.llp : v.scratch,
                                  defer ? (size_t)((B * 64 * 64 + 255) / 256) * 5 : v.scratch_doubles, v.dtype | (defer ? FAVAE_DBIAS_DEFER : 0), st));

@@ -171,6 +171,12 @@ int favae_conv_fold_taps(const void* src, void* dst, size_t dst_bytes, int Nb, i
                          int stride, int shifted, int dtype, void* stream);
 int favae_conv_wgrad_prefolded(const void* rows, int Rc, int Rst, const void* cols, int Cc, int Cst, float* dw, long long K,
                                int splitk, int dtype, void* stream);
+/* favae_conv_wgrad_prefolded whose column operand is the conv output cols_raw [K][Cc] (bf16) in front of a BatchNorm2d(train) + LeakyReLU
+ * (final_layer.1/.2 in front of final_layer.3, celeba_deepvanilla_vae.py:72-76; the gradient loss.backward() :249 takes): the activation
+ * lrelu(x * a + b), rounded to bf16, is formed at the operand load from ab [groups][2][Cc] (a | b per BatchNorm group of group_rows rows of
+ * cols_raw; 0: one group).  bf16, Rc <= 32, K and group_rows multiples of 64. */
+int favae_conv_wgrad_prefolded_bn(const void* rows, int Rc, int Rst, const void* cols_raw, int Cc, int Cst, const float* ab,
+                                  long long group_rows, float* dw, long long K, int splitk, int dtype, void* stream);
 
 /* The same pair with (almost) fp32 operands on bf16 matrix cores, for encoder.0 of the bf16 training step (the image is the one
  * operand whose bf16 rounding passes through every BatchNorm of the encoder; celeba_deepvanilla_vae.py:31-33, 80-87):
@@ -333,6 +339,14 @@ int favae_conv_out_wprep(const void* w, void* wk, int Cout, int dtype, void* str
 int favae_conv_out_ll_finish(const double* partial, int Nb, int H, int W, int Cout, float var_x, double* rec_err, float* dbias,
                              void* stream);
 int favae_conv_out_ll_ride(const double* partial, int Nb, int H, int W, int Cout, float var_x, double* rec_err, float* dbias);
+/* favae_conv_out_ll whose input is the conv output raw_in [Nb][H][W][64] (bf16) in front of final_layer.1/.2 (BatchNorm2d(train) + LeakyReLU,
+ * condition_a_VAE/celeba_deepvanilla_vae.py:72-73, applied by decode() :86-92): the activation lrelu(raw_in * a + b), rounded to bf16 as
+ * favae_bn_train_fwd_bins / favae_gbn_fwd store it, is formed at the operand load from ab [groups][2][64] (a | b per BatchNorm group of
+ * group_images images; 0: one group), so the activation tensor need not exist.  bf16 only (dtype FAVAE_BF16, optionally | FAVAE_DBIAS_DEFER),
+ * W a multiple of 64. */
+int favae_conv_out_ll_bn(const void* raw_in, const float* ab, int group_images, const void* wk, const float* bias, const float* x, int Nb,
+                         int H, int W, int Cout, float var_x, float* raw, void* draw, double* rec_err, float* dbias, double* scratch,
+                         size_t scratch_doubles, int dtype, void* stream);
 /* The convolution of favae_conv_out_ll alone (final_layer.3 of the eval decoder, cA/celeba_deepvanilla_vae.py:71-77 under
  * decoder() :94-99): raw [Nb][H][W][Cout] fp32 = conv3x3(act) + bias.  bf16 activations, W a multiple of 64, wk from favae_conv_out_wprep. */
 int favae_conv_out_raw(const void* act, const void* wk, const float* bias, int Nb, int H, int W, int Cout, float* raw, int dtype,

@@ -781,6 +781,80 @@ def test_final_conv_with_loss_in_one_launch(dt, tol, Nb, H, Co):
         assert_close(dbias.cpu(), dbias0.cpu(), 1e-6)
 
 
+@pytest.mark.parametrize("Nb,group_images", [(3, 0), (4, 2), (6, 3)])
+def test_final_conv_and_its_weight_gradient_without_the_stored_activation(Nb, group_images):
+    """favae_conv_out_ll_bn / favae_conv_wgrad_prefolded_bn: final_layer.3 (celeba_deepvanilla_vae.py:74-76) forward + loss and weight gradient
+    reading the conv output in front of final_layer.1/.2 (BatchNorm2d(train) + LeakyReLU, :72-73) and forming the activation at the operand
+    load, per BatchNorm group: bit-identical to favae_conv_out_ll / favae_conv_wgrad_prefolded on the activation tensor the BatchNorm
+    kernels would have stored, bf16(lrelu(raw * a + b))."""
+    import ctypes
+    lib = _lib()
+    rawl = lib.raw()
+    i_, f_, sz_, ll_ = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_longlong
+    dt = torch.bfloat16
+    H, Co, C, var_x = 64, 3, 64, 0.01
+    g = torch.Generator().manual_seed(500 + Nb)
+    G = Nb // group_images if group_images else 1
+    rawin = (torch.randn(Nb, H, H, C, generator=g) * 2).to(dt)
+    ab = torch.stack([torch.rand(G, C, generator=g) + 0.5, torch.randn(G, C, generator=g) * 0.5], 1).contiguous()    # [G][2][C]
+    gi = group_images if group_images else Nb
+    a_full = ab[:, 0].repeat_interleave(gi, 0).view(Nb, 1, 1, C)
+    b_full = ab[:, 1].repeat_interleave(gi, 0).view(Nb, 1, 1, C)
+    y = rawin.float() * a_full + b_full
+    act_cpu = torch.where(y > 0, y, 0.01 * y).to(dt)
+    w = q(torch.randn(Co, C, 3, 3, generator=g) * 0.05, dt)
+    b = torch.randn(Co, generator=g) * 0.1
+    x = torch.rand(Nb, H, H, Co, generator=g)
+    wd = w.permute(0, 2, 3, 1).reshape(Co, 9, C).contiguous().to(dt).cuda()
+    wk = torch.zeros(9, 16, 4, 4, device="cuda", dtype=dt)
+    lib.check(rawl.favae_conv_out_wprep(lib.ptr(wd), lib.ptr(wk), i_(Co), i_(lib.BF16), lib.stream_ptr()))
+    scratch = torch.zeros(5 * ((Nb * H * H + 255) // 256) + 8, dtype=torch.float64, device="cuda")
+    rd, abd, xd, bd = rawin.cuda(), ab.cuda(), x.cuda(), b.cuda()
+
+    def run_bn():
+        raw = torch.zeros(Nb, H, H, Co, device="cuda"); draw = torch.zeros(Nb, H, H, Co, device="cuda", dtype=dt)
+        rec, dbias = torch.zeros(1, dtype=torch.float64, device="cuda"), torch.zeros(Co, device="cuda")
+        lib.check(rawl.favae_conv_out_ll_bn(lib.ptr(rd), lib.ptr(abd), i_(group_images), lib.ptr(wk), lib.ptr(bd), lib.ptr(xd), i_(Nb), i_(H), i_(H),
+                                            i_(Co), f_(var_x), lib.ptr(raw), lib.ptr(draw), lib.ptr(rec), lib.ptr(dbias), lib.ptr(scratch),
+                                            sz_(scratch.numel()), i_(lib.BF16), lib.stream_ptr()))
+        return raw, draw, rec, dbias
+
+    def run_plain(act):
+        raw = torch.zeros(Nb, H, H, Co, device="cuda"); draw = torch.zeros(Nb, H, H, Co, device="cuda", dtype=dt)
+        rec, dbias = torch.zeros(1, dtype=torch.float64, device="cuda"), torch.zeros(Co, device="cuda")
+        lib.check(rawl.favae_conv_out_ll(lib.ptr(act), lib.ptr(wk), lib.ptr(bd), lib.ptr(xd), i_(Nb), i_(H), i_(H), i_(Co), f_(var_x),
+                                         lib.ptr(raw), lib.ptr(draw), lib.ptr(rec), lib.ptr(dbias), lib.ptr(scratch), sz_(scratch.numel()),
+                                         i_(lib.BF16), lib.stream_ptr()))
+        return raw, draw, rec, dbias
+
+    # the activation as the library's BatchNorm apply stores it, group by group (fp32 copy of the bf16 conv output: the same values)
+    act_dev = torch.empty(Nb, H, H, C, device="cuda", dtype=dt)
+    raw32 = rd.float()
+    for gidx in range(G):
+        lo = gidx * gi
+        lib.check(rawl.favae_bn_lrelu_fwd_ab(lib.ptr(raw32[lo:lo + gi]), lib.ptr(abd[gidx]), lib.ptr(act_dev[lo:lo + gi]), ll_(gi * H * H), i_(C),
+                                             i_(lib.BF16), lib.stream_ptr()))
+    assert (act_dev.cpu() != act_cpu).float().mean().item() < 0.02      # (fma in the kernels against mul + add here: the odd last bit)
+    got = run_bn()
+    want = run_plain(act_dev)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[3], want[3])
+    assert got[2].item() == want[2].item()
+
+    # the weight gradient over the folded output gradient: rows [K][32] (27 live columns), cols = raw / the activation [K][64]
+    K = Nb * H * H
+    rows = torch.zeros(K, 32, dtype=dt)
+    rows[:, :27] = (torch.randn(K, 27, generator=g) * 0.1).to(dt)
+    rows_d = rows.cuda()
+    dw_bn = torch.zeros(27, 64, device="cuda"); dw_pl = torch.zeros(27, 64, device="cuda")
+    lib.check(rawl.favae_conv_wgrad_prefolded_bn(lib.ptr(rows_d), i_(32), i_(27), lib.ptr(rd), i_(C), i_(C), lib.ptr(abd), ll_(group_images * H * H),
+                                                 lib.ptr(dw_bn), ll_(K), i_(-1), i_(lib.BF16), lib.stream_ptr()))
+    lib.check(rawl.favae_conv_wgrad_prefolded(lib.ptr(rows_d), i_(32), i_(27), lib.ptr(act_dev), i_(C), i_(C), lib.ptr(dw_pl), ll_(K), i_(-1),
+                                              i_(lib.BF16), lib.stream_ptr()))
+    ref = rows[:, :27].double().t() @ act_dev.cpu().double().view(K, C)
+    assert_close(dw_bn.cpu(), ref, 1e-4)
+    assert_close(dw_bn.cpu(), dw_pl.cpu(), 1e-6)      # (the slices of the reduction arrive through fp32 atomics: the order of the sums is not fixed)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("kind,Nb,Cin,Cout,H", [("conv", 64, 512, 1024, 4), ("convT", 64, 1024, 512, 4), ("conv", 64, 256, 512, 8), ("conv", 64, 64, 128, 32)])
 def test_weight_gradient_with_the_adam_step_in_its_epilogue(dt, kind, Nb, Cin, Cout, H):

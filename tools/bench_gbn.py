@@ -62,7 +62,7 @@ for name, Rg, C in (("final_layer.0", 64 * 4096, 64), ("enc.0/dec.3", 64 * 1024,
 
     def bwd():
         L.check(raw_.favae_gbn_bwd(L.ptr(dact), L.ptr(act), L.ptr(raw), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), AB, L.ptr(gbins), _i(nb), L.ptr(draw),
-                                   L.ptr(dg), L.ptr(db), L.ptr(dbias), _i(G), _ll(Rg), _i(C), _i(L.BF16), st))
+                                   L.ptr(dg), L.ptr(db), (L.ptr(dbias) if os.environ.get("GBN_DBIAS", "1") == "1" else None), _i(G), _ll(Rg), _i(C), _i(L.BF16), st))
 
     def sums2():
         L.check(raw_.favae_gbn_sums(L.ptr(dact), L.ptr(act), L.ptr(raw), L.ptr(mean), L.ptr(invstd), AB, L.ptr(gbins), _i(nb), _i(G), _ll(Rg), _i(C), _i(2),

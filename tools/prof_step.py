@@ -6,8 +6,10 @@ from favae_hip.engine import VaeEngine
 dtype = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+groups = int(sys.argv[4]) if len(sys.argv) > 4 else 1      # BatchNorm groups of 64 per step (grouped-batch mode)
+B = 64 * groups
 z = 20
-eng = VaeEngine(z, 3, dtype=dtype)
+eng = VaeEngine(z, 3, dtype=dtype) if groups == 1 else VaeEngine(z, 3, batch_max=B, dtype=dtype)
 torch.manual_seed(0)
 sys.path.insert(0, '/root/repo')
 from oracle import vae_torch as vt
@@ -20,17 +22,17 @@ data = eng.upload_images(img)
 perm = torch.randperm(N).to(torch.int32).cuda()
 eps = torch.randn(N, z).cuda()
 prior = torch.randn(N, z, dtype=torch.float64).cuda()
-nsteps = (N + 63) // 64
+nsteps = (N + B - 1) // B
 metrics = torch.zeros(nsteps, 2, dtype=torch.float64, device='cuda')
 import os
 stream = torch.cuda.Stream(priority=int(os.environ.get('FAVAE_MAIN_PRIO', '0'))) if os.environ.get('FAVAE_OWN_STREAM', '1') == '1' else torch.cuda.current_stream()
 torch.cuda.synchronize()
 torch.cuda.set_stream(stream)
-eng.train_epoch(data, perm, eps, prior, 1.5, 1.0, 0.01, 1e-3, 64, metrics)
+eng.train_epoch(data, perm, eps, prior, 1.5, 1.0, 0.01, 1e-3, B, metrics)
 torch.cuda.synchronize()
 for r in range(reps):
     t = time.time()
-    eng.train_epoch(data, perm, eps, prior, 1.5, 1.0, 0.01, 1e-3, 64, metrics)
+    eng.train_epoch(data, perm, eps, prior, 1.5, 1.0, 0.01, 1e-3, B, metrics)
     t_enq = time.time() - t
     torch.cuda.synchronize()
     dt = time.time() - t
