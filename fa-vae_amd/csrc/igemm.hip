@@ -1977,13 +1977,33 @@ extern "C" int favae_conv_folded_fwd_split(const void* fold_hl, const float* w, 
 extern "C" int favae_conv_folded_dgrad(const void* fold, const void* w, void* out, long long P, int K, int Cin, double* bins, int nbins,
                                        const void* act, const void* raw, const float* mean, const float* invstd, const float* ab, int groups,
                                        int dtype, void* stream) {
-    FAVAE_CHECK_ARG(fold && w && out && P > 0 && P < (1ll << 31) && groups >= 1, "favae_conv_folded_dgrad: bad argument");
+    FAVAE_CHECK_ARG(fold && w && (out || bins) && P > 0 && P < (1ll << 31) && groups >= 1, "favae_conv_folded_dgrad: bad argument");
     FAVAE_CHECK_ARG((dtype & 0xF) == FAVAE_BF16 && Cin == 64 && K >= 1 && K <= 32, "favae_conv_folded_dgrad: bf16, 64 input channels, K <= 32");
     FAVAE_CHECK_ARG((dtype & ~(0xF | FAVAE_OUT_BF16 | FAVAE_RAW_BF16)) == 0, "favae_conv_folded_dgrad: unknown storage flag in dtype 0x%x", dtype);
     FAVAE_CHECK_ARG(!bins || (nbins >= 1 && (act || ab) && raw && mean && invstd), "favae_conv_folded_dgrad: the sums need nbins, act (or ab), raw, mean, invstd");
     FAVAE_CHECK_ARG(((uintptr_t)fold % 16) == 0 && ((uintptr_t)out % 16) == 0, "favae_conv_folded_dgrad: 16-byte alignment");
     return folded_dgrad_launch(fold, w, K, out, P, groups, (dtype & FAVAE_OUT_BF16) != 0, bins, nbins, act, raw, (dtype & FAVAE_RAW_BF16) != 0, mean,
                                invstd, ab, (hipStream_t)stream);
+}
+
+/* The input gradient of favae_conv_folded_dgrad formed again and the backward of the BatchNorm2d(train) + LeakyReLU in front applied to it at
+ * once (final_layer.1/.2, celeba_deepvanilla_vae.py:72-73, under loss.backward() :249): draw [P][64] (bf16) = gamma invstd (dd - s1 / R - xhat s2 / R)
+ * per BatchNorm group, s1 / s2 the totals of bins [groups][nbins][2][64] that a favae_conv_folded_dgrad call with out == NULL left; dgamma / dbeta
+ * are ADDED to (first block of a group); dbias_partial (may be NULL) [*slabs][64] doubles takes the column sums of draw per block, at most
+ * slabs_cap of them, for favae_bn_dbias_finish / _ride.  FAVAE_OUT_BF16 in dtype: the gradient is rounded to bf16 before use, as a stored
+ * bf16 gradient would be (draw then equals that of favae_conv_folded_dgrad + favae_bn_lrelu_bwd_bins_ab / favae_gbn_bwd up to the odd last bf16 bit). */
+extern "C" int favae_conv_folded_dgrad_bn(const void* fold, const void* w, void* draw, long long P, int K, int Cin, const double* bins, int nbins,
+                                          const void* act, const void* raw, const float* mean, const float* invstd, const float* gamma, const float* ab,
+                                          int groups, float* dgamma, float* dbeta, double* dbias_partial, int slabs_cap, int* slabs, int dtype,
+                                          void* stream) {
+    FAVAE_CHECK_ARG(fold && w && draw && bins && nbins >= 1 && (act || ab) && raw && mean && invstd && gamma && dgamma && dbeta && P > 0 && P < (1ll << 31) &&
+                        groups >= 1, "favae_conv_folded_dgrad_bn: bad argument");
+    FAVAE_CHECK_ARG((dtype & 0xF) == FAVAE_BF16 && Cin == 64 && K >= 1 && K <= 32, "favae_conv_folded_dgrad_bn: bf16, 64 input channels, K <= 32");
+    FAVAE_CHECK_ARG((dtype & ~(0xF | FAVAE_OUT_BF16 | FAVAE_RAW_BF16)) == 0, "favae_conv_folded_dgrad_bn: unknown storage flag in dtype 0x%x", dtype);
+    FAVAE_CHECK_ARG(!dbias_partial || (slabs && slabs_cap >= groups), "favae_conv_folded_dgrad_bn: dbias_partial needs slabs and slabs_cap >= groups");
+    FAVAE_CHECK_ARG(((uintptr_t)fold % 16) == 0 && ((uintptr_t)draw % 16) == 0, "favae_conv_folded_dgrad_bn: 16-byte alignment");
+    return folded_dgrad_bn_launch(fold, w, K, draw, P, groups, (dtype & FAVAE_OUT_BF16) != 0, bins, nbins, act, raw, (dtype & FAVAE_RAW_BF16) != 0, mean,
+                                  invstd, gamma, ab, dgamma, dbeta, dbias_partial, slabs_cap, slabs, (hipStream_t)stream);
 }
 
 extern "C" int favae_conv_wgrad_prefolded(const void* rows, int Rc, int Rst, const void* cols, int Cc, int Cst, float* dw,

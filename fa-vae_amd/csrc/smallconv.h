@@ -36,4 +36,7 @@ int folded_fwd_launch(const void* fold, const void* w, int K, const float* bias,
 // raw fp32 or bf16, mean / invstd [groups][64]).
 int folded_dgrad_launch(const void* fold, const void* w, int K, void* out, long long P, int groups, int out_bf16, double* bins, int nbin,
                         const void* act, const void* raw, int raw_bf16, const float* mean, const float* invstd, const float* ab, hipStream_t st);
+int folded_dgrad_bn_launch(const void* fold, const void* w, int K, void* draw, long long P, int groups, int grad_bf16, const double* bins, int nbin,
+                           const void* act, const void* raw, int raw_bf16, const float* mean, const float* invstd, const float* gamma, const float* ab,
+                           float* dgamma, float* dbeta, double* dbias_part, int slabs_cap, int* slabs_out, hipStream_t st);
 int fold_taps_hl_launch(const float* src, void* dst, int Nb, int Hq, int Wq, int Hn, int Wn, int Cs, int stride, hipStream_t st);

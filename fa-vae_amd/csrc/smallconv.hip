@@ -473,12 +473,22 @@ __global__ __launch_bounds__(256) void folded_fwd_kernel(const bf16_t* __restric
 // (final_layer.0) per channel, sum dd and sum dd * xhat with dd = dact * lrelu'(act), from the fp32 accumulators (igemm_kc red_mode 2),
 // fp64 atomics into bins[nbin][2][64].  blockIdx.y = BatchNorm group (P pixels each, own bins / mean / invstd).
 // The VALU form (conv_thin_in: 27 * 64 FMAs per pixel in one thread, 203 registers, two waves per SIMD) took 71 us per 64 images.
-template <bool OUT_BF, bool RAW_BF, bool RED>
+// MODE 0: dact only; 1: dact and the two sums (RED); 2: the two sums only, dact is not stored; 3: dact is formed again and the BatchNorm
+// backward applied to it at once: out = draw (bf16) = gamma invstd (dd - s1 / R - xhat s2 / R) with s1, s2 the totals of `bins`, dgamma / dbeta
+// added by the first block of a group, the column sums of draw (the bias gradient in front of the BatchNorm: rounding noise) per block into
+// dbias_part [gridDim.x][64] (may be NULL).  MODE 2 + MODE 3 replace MODE 1 + the BatchNorm-backward apply pass: the gradient tensor
+// (16.8 M elements per 64 images) is neither written nor read back, the folded output gradient (half its size) is read twice.  In MODE 3
+// OUT_BF says that the gradient would have been stored as bf16: it is rounded so before use, as the two-pass form reads it.
+template <bool OUT_BF, bool RAW_BF, int MODE>
 __global__ __launch_bounds__(256) void folded_dgrad_kernel(const bf16_t* __restrict__ fold, const bf16_t* __restrict__ w, int K,
                                                            void* __restrict__ out_, int P, double* __restrict__ bins, int nbin,
                                                            const bf16_t* __restrict__ act, const void* __restrict__ raw_,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ ab, const FlagCarry carry) {
+                                                           const float* __restrict__ ab, const FlagCarry carry,
+                                                           const float* __restrict__ gamma = nullptr, float* __restrict__ dgamma = nullptr,
+                                                           float* __restrict__ dbeta = nullptr, double* __restrict__ dbias_part = nullptr,
+                                                           float invR = 0.f) {
+    constexpr bool RED = MODE == 1 || MODE == 2, APPLY = MODE == 3, STORE = MODE <= 1, NEED = MODE != 0;
     carry_store(carry);
     const size_t goff = (size_t)blockIdx.y * P;
     fold += goff * 32;
@@ -487,6 +497,15 @@ __global__ __launch_bounds__(256) void folded_dgrad_kernel(const bf16_t* __restr
     for (int i = threadIdx.x; i < 64 * 32; i += 256) {
         const int k = i >> 6, o = i & 63;                          // (consecutive threads read consecutive channels of row k)
         wl[o * 40 + k] = k < K ? w[k * 64 + o] : (bf16_t)0;
+    }
+    if (APPLY) {   // totals of the group's bins, in bin order (as gbn_bwd_kernel adds them)
+        if (threadIdx.x < 128) {
+            const int qq = threadIdx.x >> 6, col = threadIdx.x & 63;
+            double t = 0.0;
+            for (int b = 0; b < nbin; ++b) t += bins[(((size_t)blockIdx.y * nbin + b) * 2 + qq) * 64 + col];
+            redsm[qq * 64 + col] = t;
+            if (blockIdx.x == 0) atomicAdd((qq ? dgamma : dbeta) + col, (float)t);
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -497,15 +516,22 @@ __global__ __launch_bounds__(256) void folded_dgrad_kernel(const bf16_t* __restr
     b10.u = *(const uint4*)(wl + (2 * r + 1) * 40 + h * 8);
     b11.u = *(const uint4*)(wl + (2 * r + 1) * 40 + 16 + h * 8);
     float mu0 = 0.f, mu1 = 0.f, is0 = 0.f, is1 = 0.f;
-    if (RED) {
+    if (NEED) {
         mu0 = mean[blockIdx.y * 64 + 2 * r]; mu1 = mean[blockIdx.y * 64 + 2 * r + 1];
         is0 = invstd[blockIdx.y * 64 + 2 * r]; is1 = invstd[blockIdx.y * 64 + 2 * r + 1];
     }
     // ab != NULL: the slope of the LeakyReLU from the forward pass's affine form raw * a + b instead of the stored activation
     float fa0 = 0.f, fa1 = 0.f, fb0 = 0.f, fb1 = 0.f;
-    if (RED && ab) {
+    if (NEED && ab) {
         fa0 = ab[(blockIdx.y * 2) * 64 + 2 * r]; fa1 = ab[(blockIdx.y * 2) * 64 + 2 * r + 1];
         fb0 = ab[(blockIdx.y * 2 + 1) * 64 + 2 * r]; fb1 = ab[(blockIdx.y * 2 + 1) * 64 + 2 * r + 1];
+    }
+    [[maybe_unused]] float gi0 = 0.f, gi1 = 0.f, k10 = 0.f, k11 = 0.f, k20 = 0.f, k21 = 0.f;
+    if (APPLY) {
+        gi0 = gamma[2 * r] * is0; gi1 = gamma[2 * r + 1] * is1;
+        k10 = (float)redsm[2 * r] * invR; k11 = (float)redsm[2 * r + 1] * invR;
+        k20 = (float)redsm[64 + 2 * r] * invR; k21 = (float)redsm[64 + 2 * r + 1] * invR;
+        __syncthreads();   // (redsm is used again below)
     }
     double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
     const int ngroup = (P + 31) / 32, nw = gridDim.x * 4;
@@ -517,7 +543,7 @@ __global__ __launch_bounds__(256) void folded_dgrad_kernel(const bf16_t* __restr
         // act / raw of the 16 pixel rows this lane finishes, fetched ahead of the MFMAs
         [[maybe_unused]] unsigned pa2[16];
         [[maybe_unused]] float2 px[16];
-        if (RED) {
+        if (NEED) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int p = min(p0 + (i & 3) + 8 * (i >> 2) + 4 * h, P - 1);
@@ -543,19 +569,32 @@ __global__ __launch_bounds__(256) void folded_dgrad_kernel(const bf16_t* __restr
             const int p = p0 + (i & 3) + 8 * (i >> 2) + 4 * h;
             if (p < P) {
                 const size_t e = (goff + p) * 64 + 2 * r;
-                if (OUT_BF) *(unsigned*)((bf16_t*)out_ + e) = pack_bf16x2(c0[i], c1[i]);
-                else *(float2*)((float*)out_ + e) = make_float2(c0[i], c1[i]);
-                if (RED) {
+                if (STORE) {
+                    if (OUT_BF) *(unsigned*)((bf16_t*)out_ + e) = pack_bf16x2(c0[i], c1[i]);
+                    else *(float2*)((float*)out_ + e) = make_float2(c0[i], c1[i]);
+                }
+                if (NEED) {
                     float a_e = __uint_as_float(pa2[i] << 16), a_o = __uint_as_float(pa2[i] & 0xffff0000u);
                     if (ab) { a_e = px[i].x * fa0 + fb0; a_o = px[i].y * fa1 + fb1; }   // uniform
-                    const float d0 = c0[i] * (a_e > 0.f ? 1.f : 0.01f), d1 = c1[i] * (a_o > 0.f ? 1.f : 0.01f);
-                    s0 += d0; s1 += d1;
-                    q0 += (double)d0 * ((px[i].x - mu0) * is0); q1 += (double)d1 * ((px[i].y - mu1) * is1);
+                    if (RED) {
+                        const float d0 = c0[i] * (a_e > 0.f ? 1.f : 0.01f), d1 = c1[i] * (a_o > 0.f ? 1.f : 0.01f);
+                        s0 += d0; s1 += d1;
+                        q0 += (double)d0 * ((px[i].x - mu0) * is0); q1 += (double)d1 * ((px[i].y - mu1) * is1);
+                    } else {   // APPLY
+                        float g0 = c0[i], g1 = c1[i];
+                        if (OUT_BF) { const unsigned u = pack_bf16x2(g0, g1); g0 = __uint_as_float(u << 16); g1 = __uint_as_float(u & 0xffff0000u); }
+                        const float d0 = g0 * (a_e > 0.f ? 1.f : 0.01f), d1 = g1 * (a_o > 0.f ? 1.f : 0.01f);
+                        const float xh0 = (px[i].x - mu0) * is0, xh1 = (px[i].y - mu1) * is1;
+                        const float o0 = gi0 * (d0 - k10 - xh0 * k20), o1 = gi1 * (d1 - k11 - xh1 * k21);
+                        *(unsigned*)((bf16_t*)out_ + e) = pack_bf16x2(o0, o1);
+                        s0 += o0; s1 += o1;
+                    }
                 }
             }
         }
     }
-    if (!RED) return;
+    if (!NEED) return;
+    if (APPLY && !dbias_part) return;   // uniform
     s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
     s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
     if (h == 0) {
@@ -566,7 +605,8 @@ __global__ __launch_bounds__(256) void folded_dgrad_kernel(const bf16_t* __restr
     if (threadIdx.x < 128) {
         const int qq = threadIdx.x >> 6, col = threadIdx.x & 63;
         const double t = (redsm[(0 * 2 + qq) * 64 + col] + redsm[(1 * 2 + qq) * 64 + col]) + (redsm[(2 * 2 + qq) * 64 + col] + redsm[(3 * 2 + qq) * 64 + col]);
-        unsafeAtomicAdd(bins + (((size_t)blockIdx.y * nbin + blockIdx.x % (unsigned)nbin) * 2 + qq) * 64 + col, t);
+        if (APPLY) { if (qq == 0) dbias_part[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + col] = t; }
+        else unsafeAtomicAdd(bins + (((size_t)blockIdx.y * nbin + blockIdx.x % (unsigned)nbin) * 2 + qq) * 64 + col, t);
     }
 }
 }  // namespace
@@ -578,11 +618,38 @@ int folded_dgrad_launch(const void* fold, const void* w, int K, void* out, long 
     const int Pg = (int)(P / groups);
     const int ngroup = (Pg + 31) / 32;
     const int grid = std::max(1, std::min((ngroup + 3) / 4, std::max(128, 1024 / groups)));
-#define FD_LAUNCH(OB, RB, RD) hipLaunchKernelGGL((folded_dgrad_kernel<OB, RB, RD>), dim3(grid, groups), dim3(256), 0, st, (const bf16_t*)fold, (const bf16_t*)w, K, \
+#define FD_LAUNCH(OB, RB, MD) hipLaunchKernelGGL((folded_dgrad_kernel<OB, RB, MD>), dim3(grid, groups), dim3(256), 0, st, (const bf16_t*)fold, (const bf16_t*)w, K, \
                                                  out, Pg, bins, std::max(1, nbin), (const bf16_t*)act, raw, mean, invstd, ab, carry)
-    if (!bins) { if (out_bf16) FD_LAUNCH(true, false, false); else FD_LAUNCH(false, false, false); }
-    else if (out_bf16) { if (raw_bf16) FD_LAUNCH(true, true, true); else FD_LAUNCH(true, false, true); }
-    else { if (raw_bf16) FD_LAUNCH(false, true, true); else FD_LAUNCH(false, false, true); }
+    if (!bins) { if (out_bf16) FD_LAUNCH(true, false, 0); else FD_LAUNCH(false, false, 0); }
+    else if (!out) { if (raw_bf16) FD_LAUNCH(false, true, 2); else FD_LAUNCH(false, false, 2); }   // the sums only
+    else if (out_bf16) { if (raw_bf16) FD_LAUNCH(true, true, 1); else FD_LAUNCH(true, false, 1); }
+    else { if (raw_bf16) FD_LAUNCH(false, true, 1); else FD_LAUNCH(false, false, 1); }
+#undef FD_LAUNCH
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
+// MODE 3 of the kernel (see there).  grad_bf16: the gradient is rounded to bf16 before use, as its stored form would be.  slabs_cap: blocks per
+// group at most when dbias_part is given ([groups * blocks][64] doubles); *slabs_out = groups * blocks.
+int folded_dgrad_bn_launch(const void* fold, const void* w, int K, void* draw, long long P, int groups, int grad_bf16, const double* bins, int nbin,
+                           const void* act, const void* raw, int raw_bf16, const float* mean, const float* invstd, const float* gamma, const float* ab,
+                           float* dgamma, float* dbeta, double* dbias_part, int slabs_cap, int* slabs_out, hipStream_t st) {
+    const FlagCarry carry = favae_take_flag_carry();
+    FAVAE_CHECK_ARG(groups >= 1 && P % groups == 0 && (groups == 1 || (P / groups) % 32 == 0), "folded input gradient: %lld pixels in %d groups", P, groups);
+    const int Pg = (int)(P / groups);
+    const int ngroup = (Pg + 31) / 32;
+    int grid = std::max(1, std::min((ngroup + 3) / 4, std::max(128, 1024 / groups)));
+    if (dbias_part) {
+        FAVAE_CHECK_ARG(slabs_cap >= groups, "folded input gradient: room for %d slabs, %d groups", slabs_cap, groups);
+        grid = std::max(1, std::min(grid, slabs_cap / groups));
+    }
+    if (slabs_out) *slabs_out = grid * groups;
+    const float invR = (float)(1.0 / (double)Pg);
+#define FD_LAUNCH(OB, RB) hipLaunchKernelGGL((folded_dgrad_kernel<OB, RB, 3>), dim3(grid, groups), dim3(256), 0, st, (const bf16_t*)fold, (const bf16_t*)w, K, \
+                                             draw, Pg, (double*)bins, std::max(1, nbin), (const bf16_t*)act, raw, mean, invstd, ab, carry, gamma, dgamma, dbeta, \
+                                             dbias_part, invR)
+    if (grad_bf16) { if (raw_bf16) FD_LAUNCH(true, true); else FD_LAUNCH(true, false); }
+    else { if (raw_bf16) FD_LAUNCH(false, true); else FD_LAUNCH(false, false); }
 #undef FD_LAUNCH
     FAVAE_LAUNCH_CHECK();
     return FAVAE_OK;

@@ -191,6 +191,9 @@ struct Vae {
     // (favae_conv_wgrad_prefolded_bn) apply the BatchNorm + LeakyReLU to raw[11] at their operand loads, the backward pass takes the slope
     // from raw * a + b.  act11_skip_ok: this step may do so (set before the decoder's forward pass); act11_raw: it did.
     bool act11_skip_ok, act11_raw;
+    // the gradient w.r.t. final_layer.0's activation is not stored: the input-gradient launch of final_layer.3 leaves the two BatchNorm-backward
+    // sums only and bn_bwd forms the gradient again with the BatchNorm backward applied (favae_conv_folded_dgrad_bn)
+    bool dact11_recompute;
     bool dp_epoch;   // steps of favae_vae_train_epoch_dp: gradients cleared by the bucket-wise Adam, joins through the communication stream
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
     bool rk_done;   // stage 6 of this step already ran the reparameterisation backward (fused launch)
@@ -770,6 +773,19 @@ int decoder_fwd(Vae& v, int B, bool train, void* st, bool pooled = false, bool s
 
 int bn_bwd(Vae& v, int l, int B, void* st) {
     const Layer& L = v.L[l];
+    if (l == 11 && v.dact11_recompute) {   // the gradient was not stored (dgrad): form it again from the folded output gradient and apply
+        v.dact11_recompute = false;
+        v.grad_fused[l] = false;
+        const int G = B > 64 ? B / 64 : 1;
+        const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0) | (v.dact_bf[l] ? FAVAE_OUT_BF16 : 0);
+        const Layer& LO = v.L[L_OUT];
+        int slabs = 0;
+        RC(favae_conv_folded_dgrad_bn(v.fold, v.Wf(L_OUT), v.draw[l], (long long)B * LO.Hin * LO.Hin, 9 * LO.Cout, LO.Cin, v.gbins[l],
+                                      bins_for(v.rows(l, B > 64 ? 64 : B)), nullptr, v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off,
+                                      B > 64 ? v.gab(l) : v.ab[l], G, v.G + L.g_off, v.G + L.be_off, B > 64 ? nullptr : v.dbp[l], DBP_SLABS, &slabs, dt, st));
+        v.dbias_slabs[l] = B > 64 ? 0 : slabs;
+        return FAVAE_OK;
+    }
     if (B > 64) {   // grouped-batch mode: the two sums per group from the epilogue of the GEMM that produced dact[l], else from a pass
         const int G = B / 64, nb = bins_for(v.rows(l, 64));
         const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0) | (v.dact_bf[l] ? FAVAE_DACT_BF16 : 0);
@@ -1039,8 +1055,12 @@ int dgrad(Vae& v, int l, float* out, int B, void* st, bool out_zeroed, bool out_
         // final_layer.0's BatchNorm backward ride along, per BatchNorm group in the grouped-batch mode
         const int G = B > 64 ? B / 64 : 1;
         double* bins = B > 64 ? v.gbins[o] : ((v.fuse & 4u) ? gbins64(v, o) : nullptr);
-        RC(favae_conv_folded_dgrad(v.fold, v.Wf(L_OUT), out, (long long)B * L.Hin * L.Hin, 9 * L.Cout, L.Cin, bins, bins_for(v.rows(o, B > 64 ? 64 : B)),
-                                   v.act[o], v.raw[o], v.mean[o], v.invstd[o], B > 64 ? v.gab(o) : (v.ab_live[o] ? v.ab[o] : nullptr), G,
+        const float* ab = B > 64 ? v.gab(o) : (v.ab_live[o] ? v.ab[o] : nullptr);
+        // (FAVAE_DACT11=1: the gradient is stored and read back by the BatchNorm backward, as before)
+        static const bool dact11_keep = getenv("FAVAE_DACT11") && atoi(getenv("FAVAE_DACT11")) == 1;
+        v.dact11_recompute = !dact11_keep && bins && ab && (B > 64 || (v.dbp[o] && !(v.fuse & 0x400000u)));
+        RC(favae_conv_folded_dgrad(v.fold, v.Wf(L_OUT), v.dact11_recompute ? nullptr : out, (long long)B * L.Hin * L.Hin, 9 * L.Cout, L.Cin, bins,
+                                   bins_for(v.rows(o, B > 64 ? 64 : B)), v.act[o], v.raw[o], v.mean[o], v.invstd[o], ab, G,
                                    dt | (v.raw_bf[o] ? FAVAE_RAW_BF16 : 0), st));
         v.grad_fused[o] = bins != nullptr;
         return FAVAE_OK;
@@ -1184,7 +1204,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     // need not zero it (4 of the 32 bytes per weight it moves; encoder.4, decoder.0, decoder.1: 10.6 M of 12.8 M parameters).
     // Executors of the grouped-batch mode (Bmax > 64) keep the zeroing: their tail steps and group steps split differently.
     for (int l = 0; l < NL; ++l) v.ab_live[l] = false;
-    v.act11_skip_ok = v.act11_raw = false;
+    v.act11_skip_ok = v.act11_raw = v.dact11_recompute = false;
     for (int l = 0; l < NL; ++l) {
         const Layer& L = v.L[l];
         v.wg_keeps[l] = false;

@@ -199,6 +199,16 @@ int favae_conv_folded_fwd_split(const void* fold_hl, const float* w, const float
 int favae_conv_folded_dgrad(const void* fold, const void* w, void* out, long long P, int K, int Cin, double* bins, int nbins,
                             const void* act, const void* raw, const float* mean, const float* invstd, const float* ab, int groups,
                             int dtype, void* stream);
+/* The input gradient of favae_conv_folded_dgrad formed again and the backward of the BatchNorm2d(train) + LeakyReLU in front of the layer
+ * applied to it at once (final_layer.1/.2, celeba_deepvanilla_vae.py:72-73, under loss.backward() :249), so that the gradient tensor is neither
+ * written nor read back: first favae_conv_folded_dgrad with out == NULL (the two sums into bins only), then this call: draw [P][64] (bf16) =
+ * gamma invstd (dd - s1 / R - xhat s2 / R) per BatchNorm group (R = P / groups), s1 / s2 the totals of bins [groups][nbins][2][64];
+ * dgamma / dbeta are ADDED to; dbias_partial (may be NULL) [*slabs][64] doubles takes the column sums of draw per block, at most slabs_cap
+ * of them, for favae_bn_dbias_finish / _ride.  FAVAE_OUT_BF16 in dtype: the gradient is rounded to bf16 before use, as a stored bf16
+ * gradient would be (draw then equals that of favae_conv_folded_dgrad + favae_bn_lrelu_bwd_bins_ab / favae_gbn_bwd up to the odd last bf16 bit). */
+int favae_conv_folded_dgrad_bn(const void* fold, const void* w, void* draw, long long P, int K, int Cin, const double* bins, int nbins,
+                               const void* act, const void* raw, const float* mean, const float* invstd, const float* gamma, const float* ab,
+                               int groups, float* dgamma, float* dbeta, double* dbias_partial, int slabs_cap, int* slabs, int dtype, void* stream);
 
 /* Live HIP-event timing of selected launches (measurement only; no reference counterpart). Every stride-th launch of each
  * kernel class is timed on its launch stream; collect() synchronises and returns [16][3] = launches, seconds, algorithmic

@@ -698,6 +698,82 @@ def test_input_gradient_of_the_final_conv_over_the_folded_gradient(Nb, H, Co, gr
     assert_close(tot[:, 1], (dd2 * xh).reshape(groups, Pg, Cin).sum(1), 1e-4)
 
 
+@pytest.mark.parametrize("grad_dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("Nb,H,groups", [(2, 64, 1), (4, 32, 2), (6, 16, 3)])
+def test_input_gradient_of_the_final_conv_with_the_batchnorm_backward_applied(Nb, H, groups, grad_dt):
+    """favae_conv_folded_dgrad(out = NULL) + favae_conv_folded_dgrad_bn: the gradient w.r.t. final_layer.0's activation is never stored
+    (celeba_deepvanilla_vae.py:72-76 under loss.backward() :249): the first call leaves the two BatchNorm-backward sums, the second forms the
+    gradient again and applies the BatchNorm backward.  Against the stored form (favae_conv_folded_dgrad + favae_gbn_bwd): the same sums, the
+    same draw up to the odd last bf16 bit, the same dgamma / dbeta, and per-block column sums of draw that add up to its column sums."""
+    import ctypes
+    lib = _lib()
+    rawl = lib.raw()
+    i_, ll_ = ctypes.c_int, ctypes.c_longlong
+    g = torch.Generator().manual_seed(700 + Nb + H)
+    Cin, Co = 64, 3
+    P = Nb * H * H
+    Pg = P // groups
+    dy = (torch.randn(Nb, H, H, Co, generator=g) * 0.1).to(torch.bfloat16).cuda()
+    fold = lib.conv_fold_taps(dy, Nb, H, H, H, H, 1, shifted=1)
+    wd = (torch.randn(Co, 9, Cin, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    raw = torch.randn(P, Cin, generator=g).to(torch.bfloat16).cuda()
+    mean = (torch.randn(groups, Cin, generator=g) * 0.1).cuda()
+    invstd = (torch.rand(groups, Cin, generator=g) + 0.5).cuda()
+    gamma = (torch.rand(Cin, generator=g) + 0.5).cuda()
+    ab = torch.stack([torch.rand(groups, Cin, generator=g) + 0.5, torch.randn(groups, Cin, generator=g) * 0.3], 1).contiguous().cuda()
+    nb = 8
+    # stored form
+    dact = torch.empty(P, Cin, device="cuda", dtype=grad_dt)
+    bins1 = torch.zeros(groups, nb, 2, Cin, dtype=torch.float64, device="cuda")
+    lib.conv_folded_dgrad(fold, wd, dact, bins1, None, raw, mean, invstd, groups, ab=ab)
+    draw1 = torch.empty(P, Cin, device="cuda", dtype=torch.bfloat16)
+    dg1, db1 = torch.zeros(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
+    flags = lib.BF16 | lib.RAW_BF16 | (lib.DACT_BF16 if grad_dt == torch.bfloat16 else 0)
+    lib.check(rawl.favae_gbn_bwd(lib.ptr(dact), None, lib.ptr(raw), lib.ptr(mean), lib.ptr(invstd), lib.ptr(gamma), lib.ptr(ab), lib.ptr(bins1), i_(nb),
+                                 lib.ptr(draw1), lib.ptr(dg1), lib.ptr(db1), None, i_(groups), ll_(Pg), i_(Cin), i_(flags), lib.stream_ptr()))
+    # recomputed form
+    bins2 = torch.zeros_like(bins1)
+    oflag = lib.OUT_BF16 if grad_dt == torch.bfloat16 else 0
+    lib.check(rawl.favae_conv_folded_dgrad(lib.ptr(fold), lib.ptr(wd), None, ll_(P), i_(27), i_(64), lib.ptr(bins2), i_(nb), None, lib.ptr(raw),
+                                           lib.ptr(mean), lib.ptr(invstd), lib.ptr(ab), i_(groups), i_(lib.BF16 | lib.RAW_BF16 | oflag), lib.stream_ptr()))
+    # (the blocks' sums arrive in the bins through fp64 atomics, a bin may take several blocks: equal to rounding of the fp64 sums)
+    assert torch.allclose(bins2.sum(1), bins1.sum(1), rtol=1e-12, atol=1e-9)
+    draw2 = torch.full((P, Cin), 9.0, device="cuda", dtype=torch.bfloat16)
+    dg2, db2 = torch.zeros(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
+    cap = 256
+    part = torch.full((cap, Cin), float("nan"), dtype=torch.float64, device="cuda")
+    slabs = ctypes.c_int(0)
+    lib.check(rawl.favae_conv_folded_dgrad_bn(lib.ptr(fold), lib.ptr(wd), lib.ptr(draw2), ll_(P), i_(27), i_(64), lib.ptr(bins1), i_(nb), None,
+                                              lib.ptr(raw), lib.ptr(mean), lib.ptr(invstd), lib.ptr(gamma), lib.ptr(ab), i_(groups), lib.ptr(dg2),
+                                              lib.ptr(db2), lib.ptr(part), i_(cap), ctypes.byref(slabs), i_(lib.BF16 | lib.RAW_BF16 | oflag),
+                                              lib.stream_ptr()))
+    torch.cuda.synchronize()
+
+    def same_draw(a, b):
+        # the same expressions in two kernels: the compiler's choice of fused multiply-adds may differ, which flips the odd last bf16 bit
+        a, b = a.float(), b.float()
+        diff = (a - b).abs()
+        assert (diff <= 2.0 ** -7 * b.abs() + 1e-30).all(), "more than one bf16 ulp apart"
+        assert (diff > 0).float().mean().item() < 0.01, "more than 1 % of the elements differ"
+
+    same_draw(draw2, draw1)
+    assert_close(dg2.cpu(), dg1.cpu(), 1e-6); assert_close(db2.cpu(), db1.cpu(), 1e-6)      # (one fp32 atomic per group: their order is not fixed)
+    assert 1 <= slabs.value <= cap
+    # the per-block column sums are sums of the unrounded draw; the stored draw is rounded to bf16: agreement to the rounding of P / groups terms
+    col = part[:slabs.value].sum(0).cpu()
+    ref = draw1.double().sum(0).cpu()
+    scale = draw1.double().abs().sum(0).cpu().max().item()
+    assert (col - ref).abs().max().item() <= 2.0 ** -8 * scale / np.sqrt(P) * 8 + 1e-9
+    # without the partial sums: the same draw
+    draw3 = torch.empty_like(draw2)
+    dg3, db3 = torch.zeros(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
+    lib.check(rawl.favae_conv_folded_dgrad_bn(lib.ptr(fold), lib.ptr(wd), lib.ptr(draw3), ll_(P), i_(27), i_(64), lib.ptr(bins1), i_(nb), None,
+                                              lib.ptr(raw), lib.ptr(mean), lib.ptr(invstd), lib.ptr(gamma), lib.ptr(ab), i_(groups), lib.ptr(dg3),
+                                              lib.ptr(db3), None, i_(0), None, i_(lib.BF16 | lib.RAW_BF16 | oflag), lib.stream_ptr()))
+    assert torch.equal(draw3, draw2)
+    assert_close(dg3.cpu(), dg1.cpu(), 1e-6)
+
+
 @pytest.mark.parametrize("dt,tol", DT)
 @pytest.mark.parametrize("Nb,H,Co", [(2, 64, 3), (3, 18, 2), (64, 64, 3)])
 def test_folded_weight_gradient_final_conv(dt, tol, Nb, H, Co):
