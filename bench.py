@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra (untimed) iteration that splits VAE and FA time")
-    ap.add_argument("--groups", type=str, default="8,16", help="BatchNorm groups per step of the grouped-batch figures: the first of the list goes to "
+    ap.add_argument("--groups", type=str, default="8,16,32", help="BatchNorm groups per step of the grouped-batch figures: the first of the list goes to "
                     "secondary.grouped, every one to secondary.grouped_sweep (0: skip)")
     a = ap.parse_args()
 

@@ -780,9 +780,12 @@ int bn_bwd(Vae& v, int l, int B, void* st) {
         const int dt = v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0) | (v.dact_bf[l] ? FAVAE_OUT_BF16 : 0);
         const Layer& LO = v.L[L_OUT];
         int slabs = 0;
+        // (blocks of the batch-64 launch = slabs of its bias-gradient sums; same-box sweep with room for 1024: 128 blocks 0.794 ms per step,
+        // 192 0.785, 256 0.779, 320 0.780, 512 0.782, 1024 0.790)
+        static const int dact11_slabs = getenv("FAVAE_DACT11_SLABS") ? std::min(DBP_SLABS, std::max(1, atoi(getenv("FAVAE_DACT11_SLABS")))) : DBP_SLABS;
         RC(favae_conv_folded_dgrad_bn(v.fold, v.Wf(L_OUT), v.draw[l], (long long)B * LO.Hin * LO.Hin, 9 * LO.Cout, LO.Cin, v.gbins[l],
                                       bins_for(v.rows(l, B > 64 ? 64 : B)), nullptr, v.raw[l], v.mean[l], v.invstd[l], v.P + L.g_off,
-                                      B > 64 ? v.gab(l) : v.ab[l], G, v.G + L.g_off, v.G + L.be_off, B > 64 ? nullptr : v.dbp[l], DBP_SLABS, &slabs, dt, st));
+                                      B > 64 ? v.gab(l) : v.ab[l], G, v.G + L.g_off, v.G + L.be_off, B > 64 ? nullptr : v.dbp[l], dact11_slabs, &slabs, dt, st));
         v.dbias_slabs[l] = B > 64 ? 0 : slabs;
         return FAVAE_OK;
     }
