@@ -261,6 +261,17 @@ extern "C" int favae_gbn_fwd(const void* raw, const double* bins, int nbins, con
     return FAVAE_OK;
 }
 
+/* The running statistics alone, from mean / invstd [G][C] as favae_gbn_fwd left them (favae_gbn_fwd with run_mean == NULL skips them): what
+ * nn.BatchNorm2d(train) does to running_mean / running_var (celeba_deepvanilla_vae.py:34,58,72), averaged over the groups.  Nothing in a
+ * training step reads them, so the executor takes this launch off the main chain (the stream of the layer's weight gradient). */
+extern "C" int favae_gbn_running(const float* mean, const float* invstd, int G, long long Rg, int C, float eps, float momentum, float* run_mean,
+                                 float* run_var, void* stream) {
+    FAVAE_CHECK_ARG(mean && invstd && run_mean && run_var && G >= 1 && Rg >= 1 && C >= 1, "favae_gbn_running: bad argument");
+    hipLaunchKernelGGL(gbn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, mean, invstd, G, C, (int)Rg, eps, momentum, run_mean, run_var);
+    FAVAE_LAUNCH_CHECK();
+    return FAVAE_OK;
+}
+
 /* BatchNorm2d(train) + LeakyReLU backward of G groups: bins [G][nbins][2][C] hold (sum dd, sum dd xhat) per group; draw (dtype) =
  * gradient w.r.t. the conv output; dgamma / dbeta / dbias (may be NULL) are ADDED to (fp32 atomics: the caller's gradient arena is
  * zero at the start of a step).  dact / raw fp32, or bf16 with FAVAE_DACT_BF16 / FAVAE_RAW_BF16. */

@@ -194,6 +194,7 @@ struct Vae {
     // the gradient w.r.t. final_layer.0's activation is not stored: the input-gradient launch of final_layer.3 leaves the two BatchNorm-backward
     // sums only and bn_bwd forms the gradient again with the BatchNorm backward applied (favae_conv_folded_dgrad_bn)
     bool dact11_recompute;
+    bool run_defer[NL];   // grouped-batch mode: the running statistics of the layer's BatchNorm are still to be updated (on the stream of its weight gradient)
     bool dp_epoch;   // steps of favae_vae_train_epoch_dp: gradients cleared by the bucket-wise Adam, joins through the communication stream
     hipEvent_t ev_fence[2]; bool ev_fence_ok;
     bool rk_done;   // stage 6 of this step already ran the reparameterisation backward (fused launch)
@@ -650,8 +651,16 @@ int bn_fwd(Vae& v, int l, int B, bool train, void* st) {
         v.stats_fused[l] = false;
         const bool skip = l == 11 && v.act11_skip_ok && v.ab[l] && v.raw_bf[l];
         if (skip) v.act11_raw = true;
+        // the running statistics (a 5 us launch per layer that nothing in the step waits for) leave the main chain: wgrad() queues them
+        // (FAVAE_GBN_RUN_INLINE=1: behind this launch, as before)
+        static const bool run_inline = getenv("FAVAE_GBN_RUN_INLINE") && atoi(getenv("FAVAE_GBN_RUN_INLINE")) == 1;
+        if (v.run_defer[l])   // (a step that never reached the layer's weight gradient: the update it owes, from the statistics still in place)
+            RC(favae_gbn_running(v.mean[l], v.invstd[l], B / 64, v.rows(l, 64), L.Cout, 1e-5f, 0.1f, v.BUF + L.rm_off, v.BUF + L.rv_off, st));
+        const bool run_here = run_inline || l == 0;   // (encoder.0's weight gradient closes the step on the main chain, by a path of its own)
+        v.run_defer[l] = !run_here;
         return favae_gbn_fwd(v.raw[l], v.sbins[l], bins_for(v.rows(l, 64)), v.P + L.g_off, v.P + L.be_off, skip ? nullptr : v.act[l], v.mean[l],
-                             v.invstd[l], v.ab[l], v.BUF + L.rm_off, v.BUF + L.rv_off, B / 64, v.rows(l, 64), L.Cout, 1e-5f, 0.1f, dt, st);
+                             v.invstd[l], v.ab[l], run_here ? v.BUF + L.rm_off : nullptr, run_here ? v.BUF + L.rv_off : nullptr, B / 64,
+                             v.rows(l, 64), L.Cout, 1e-5f, 0.1f, dt, st);
     }
     if (train && v.bn_published[l]) {   // the producing GEMM finished the statistics (mean, invstd, running stats, a | b)
         v.bn_published[l] = v.stats_fused[l] = false;
@@ -915,13 +924,20 @@ int wgrad(Vae& v, int l, const void* in, int B, void* st) {
     const float ll_var = v.ll_var;
     double* const ll_out = v.ll_out;
     if (l == L_OUT) v.ll_B = 0;
-    if (!v.overlap) { RC(dbias_finish(v, l, slabs, st)); return wgrad_launch(v, l, in, B, st); }
+    const bool run_l = v.run_defer[l];
+    v.run_defer[l] = false;
+    auto running = [&v, l, B](void* s) -> int {   // grouped-batch mode: the BatchNorm's running statistics, off the main chain (bn_fwd)
+        const Layer& L = v.L[l];
+        return favae_gbn_running(v.mean[l], v.invstd[l], B / 64, v.rows(l, 64), L.Cout, 1e-5f, 0.1f, v.BUF + L.rm_off, v.BUF + L.rv_off, s);
+    };
+    if (!v.overlap) { if (run_l) RC(running(st)); RC(dbias_finish(v, l, slabs, st)); return wgrad_launch(v, l, in, B, st); }
     const unsigned seq = v.step_no;
     RC(sp_record(v, SP_FORK + l, (hipStream_t)st, seq, true));   // rides with the input-gradient GEMM queued next
     const Ada ada = v.ada;
     const bool merged = v.merged; const int half = v.upd_half;
-    return side_do(v, [&v, l, in, B, ada, merged, half, seq, slabs, ll_B, ll_var, ll_out]() -> int {
+    return side_do(v, [&v, l, in, B, ada, merged, half, seq, slabs, ll_B, ll_var, ll_out, run_l, running]() -> int {
         RC(sp_wait(v, SP_FORK + l, v.side, seq));
+        if (run_l) RC(running((void*)v.side));
         RC(dbias_finish(v, l, slabs, (void*)v.side));
         if (ll_B > 0) RC(favae_conv_out_ll_ride(v.llp, ll_B, 64, 64, v.ch, ll_var, ll_out, v.G + v.L[L_OUT].b_off));
         const int grp = merged ? group_of(v, l) : -1;
@@ -1208,6 +1224,7 @@ extern "C" int favae_vae_create(favae_vae** out, int z, int channels, int batch_
     // Executors of the grouped-batch mode (Bmax > 64) keep the zeroing: their tail steps and group steps split differently.
     for (int l = 0; l < NL; ++l) v.ab_live[l] = false;
     v.act11_skip_ok = v.act11_raw = v.dact11_recompute = false;
+    for (int l = 0; l < NL; ++l) v.run_defer[l] = false;
     for (int l = 0; l < NL; ++l) {
         const Layer& L = v.L[l];
         v.wg_keeps[l] = false;

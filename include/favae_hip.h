@@ -110,6 +110,11 @@ int favae_gbn_sums(const void* y, const void* act, const void* raw, const float*
 int favae_gbn_fwd(const void* raw, const double* bins, int nbins, const float* gamma, const float* beta, void* act, float* mean,
                   float* invstd, float* ab, float* run_mean, float* run_var, int G, long long Rg, int C, float eps, float momentum,
                   int dtype, void* stream);
+/* The running statistics of favae_gbn_fwd alone (favae_gbn_fwd with run_mean == NULL leaves them out): running_mean / running_var of
+ * nn.BatchNorm2d(train) (celeba_deepvanilla_vae.py:34,58,72) from mean / invstd [G][C], averaged over the groups.  No launch of a training
+ * step reads them: the executor queues this one beside the main chain. */
+int favae_gbn_running(const float* mean, const float* invstd, int G, long long Rg, int C, float eps, float momentum, float* run_mean,
+                      float* run_var, void* stream);
 long long favae_vae_epoch_steps(long long n, int batch);
 int favae_gbn_bwd(const void* dact, const void* act, const void* raw, const float* mean, const float* invstd, const float* gamma,
                   const float* ab, const double* bins, int nbins, void* draw, float* dgamma, float* dbeta, float* dbias, int G, long long Rg, int C,
