@@ -838,7 +838,7 @@ int bn_bwd(Vae& v, int l, int B, void* st) {
                               v.dtype | (v.raw_bf[l] ? FAVAE_RAW_BF16 : 0) | (v.dact_bf[l] ? FAVAE_DACT_BF16 : 0), st);
 }
 
-int wgrad_launch(Vae& v, int l, const void* in, int B, void* st);
+int wgrad_launch(Vae& v, int l, const void* in, int B, void* st, bool in_raw11 = false);
 int wgrad_launch_adam(Vae& v, int l, const void* in, int B, void* st, const Ada& a, int half, int* applied);
 int adam_layer(Vae& v, int l, void* st, const Ada& a, int half);
 
@@ -930,12 +930,14 @@ int wgrad(Vae& v, int l, const void* in, int B, void* st) {
         const Layer& L = v.L[l];
         return favae_gbn_running(v.mean[l], v.invstd[l], B / 64, v.rows(l, 64), L.Cout, 1e-5f, 0.1f, v.BUF + L.rm_off, v.BUF + L.rv_off, s);
     };
-    if (!v.overlap) { if (run_l) RC(running(st)); RC(dbias_finish(v, l, slabs, st)); return wgrad_launch(v, l, in, B, st); }
+    // (by value into the job as well: the worker may launch final_layer.3's weight gradient while the caller's thread is in the next step's forward pass)
+    const bool in_raw11 = l == L_OUT && v.act11_raw;
+    if (!v.overlap) { if (run_l) RC(running(st)); RC(dbias_finish(v, l, slabs, st)); return wgrad_launch(v, l, in, B, st, in_raw11); }
     const unsigned seq = v.step_no;
     RC(sp_record(v, SP_FORK + l, (hipStream_t)st, seq, true));   // rides with the input-gradient GEMM queued next
     const Ada ada = v.ada;
     const bool merged = v.merged; const int half = v.upd_half;
-    return side_do(v, [&v, l, in, B, ada, merged, half, seq, slabs, ll_B, ll_var, ll_out, run_l, running]() -> int {
+    return side_do(v, [&v, l, in, B, ada, merged, half, seq, slabs, ll_B, ll_var, ll_out, run_l, running, in_raw11]() -> int {
         RC(sp_wait(v, SP_FORK + l, v.side, seq));
         if (run_l) RC(running((void*)v.side));
         RC(dbias_finish(v, l, slabs, (void*)v.side));
@@ -960,7 +962,7 @@ int wgrad(Vae& v, int l, const void* in, int B, void* st) {
                 return sp_wait(v, SP_WG + l, v.side2, seq);   // (the step-end join is taken on the optimiser stream)
             }
         } else {
-            RC(wgrad_launch(v, l, in, B, (void*)v.side));
+            RC(wgrad_launch(v, l, in, B, (void*)v.side, in_raw11));
         }
         if (!ada.on) return FAVAE_OK;
         if (merged && (v.fuse & 0x20000u)) return adam_layer(v, l, (void*)v.side, ada, half);   // same stream: no further event
@@ -1036,14 +1038,14 @@ int wgrad_launch_adam(Vae& v, int l, const void* in, int B, void* st, const Ada&
                                  1, -1, a.lr, a.b1, a.b2, a.eps, a.step, v.dtype, applied, st);
 }
 
-int wgrad_launch(Vae& v, int l, const void* in, int B, void* st) {
+int wgrad_launch(Vae& v, int l, const void* in, int B, void* st, bool in_raw11) {
     const Layer& L = v.L[l];
     float* dw = v.G + L.w_off;
     if (l == 0 && v.x_folded) {   // the batch was folded at the start of the step (train_stages)
         // (256 slices of the 65536-pixel reduction, the automatic choice: 64 to 1024 measured the same or slower)
         return favae_conv_wgrad_prefolded(v.draw[0], L.Cout, L.Cout, v.fold0, 32, 9 * L.Cin, dw, (long long)B * L.Hout * L.Hout, -1, v.dtype, st);
     }
-    if (l == L_OUT && v.out_folded && v.act11_raw)   // `in` (final_layer.0's activation) does not exist this step: its BatchNorm + LeakyReLU at the load
+    if (l == L_OUT && v.out_folded && in_raw11)   // `in` (final_layer.0's activation) does not exist this step: its BatchNorm + LeakyReLU at the load
         return favae_conv_wgrad_prefolded_bn(v.fold, 32, 9 * L.Cout, v.raw[11], L.Cin, L.Cin, B > 64 ? v.gab(11) : v.ab[11],
                                              B > 64 ? (long long)64 * L.Hout * L.Hout : 0, dw, (long long)B * L.Hout * L.Hout, -1, v.dtype, st);
     if (l == L_OUT && v.out_folded)   // the output gradient was folded on the caller's stream (train_stages, stage 0): its input gradient reads it too
