@@ -1464,6 +1464,7 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
             // bf16, image-sized channel count: the output gradient of final_layer.3 is folded once, here, for both its weight gradient
             // (weight-gradient stream) and its input gradient (next launch)   (FAVAE_FUSE_MASK bit 0x8000000: the thin-input kernel, as before)
             v.out_folded = v.dtype == FAVAE_BF16 && (v.fuse & 64u) && v.ch <= 3 && !(v.fuse & 0x8000000u) && v.L[11].Cout == 64;
+            v.dact11_recompute = false;   // (set by this step's dgrad below; a step that ended early must not leave it behind)
             if (v.out_folded)
                 RC(favae_conv_fold_taps(v.draw[L_OUT], v.fold, v.fold_bytes, B, 64, 64, 64, 64, v.ch, 1, 1, v.dtype, st));
             RC(wgrad(v, L_OUT, v.act[11], B, st));
