@@ -1443,9 +1443,9 @@ int train_stages(Vae& v, const float* data_nhwc, const int* idx, int B, const fl
                                         var_x, v.raw[L_OUT], v.draw[L_OUT], metrics2_out, v.G + v.L[L_OUT].b_off, defer ? v.llp : v.scratch,
                                         defer ? (size_t)((B * 64 * 64 + 255) / 256) * 5 : v.scratch_doubles, v.dtype | (defer ? FAVAE_DBIAS_DEFER : 0), st));
             else
-            RC(favae_conv_out_ll(v.act[11], v.wk_out, v.P + v.L[L_OUT].b_off, v.xf, B, 64, 64, v.ch, var_x, v.raw[L_OUT], v.draw[L_OUT],
-                                 metrics2_out, v.G + v.L[L_OUT].b_off, defer ? v.llp : v.scratch,
-                                 defer ? (size_t)((B * 64 * 64 + 255) / 256) * 5 : v.scratch_doubles, v.dtype | (defer ? FAVAE_DBIAS_DEFER : 0), st));
+                RC(favae_conv_out_ll(v.act[11], v.wk_out, v.P + v.L[L_OUT].b_off, v.xf, B, 64, 64, v.ch, var_x, v.raw[L_OUT], v.draw[L_OUT],
+                                     metrics2_out, v.G + v.L[L_OUT].b_off, defer ? v.llp : v.scratch,
+                                     defer ? (size_t)((B * 64 * 64 + 255) / 256) * 5 : v.scratch_doubles, v.dtype | (defer ? FAVAE_DBIAS_DEFER : 0), st));
         } else if (v.fuse & 8u) {
             RC(favae_sigmoid_ll_bias(v.raw[L_OUT], v.xf, B, D, v.ch, var_x, v.draw[L_OUT], metrics2_out, v.G + v.L[L_OUT].b_off, v.scratch,
                                      v.scratch_doubles, v.dtype, st));
